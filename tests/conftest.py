@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "slow: longer CPU oracle case")
+
+
+@pytest.fixture(scope="session")
+def kat_setup():
+    """SRS + compiled MinimalCircuit of the reference KAT (prover.rs:1132-1147)."""
+    from oracle.plonk import Composer, compile_circuit, srs_setup
+    from oracle.rng import StdRng
+
+    pp = srs_setup(1 << 10, StdRng.seed_from_u64(0x9235E700), keep=23)
+
+    def circuit():
+        c = Composer()
+        w = c.append_witness(7)
+        c.assert_equal_constant(w, 7)
+        return c
+
+    prover = compile_circuit(pp, b"proof-compatibility", circuit())
+    return pp, prover, circuit
