@@ -1,0 +1,114 @@
+/* libplonk_hip.so — C-ABI of the MI355X (gfx950) backend for dusk-plonk's prover hot path.
+ *
+ * The reference has no FFI seam; the path sits behind two crate-private leaf
+ * call families.  Each entry point below names the reference
+ * interface it replaces (paths relative to the dusk-network/plonk tree):
+ *
+ *   plonk_ntt / plonk_ntt_batch   bodies of EvaluationDomain::{fft,ifft,coset_fft,
+ *                                 coset_ifft}_in_place, src/fft/domain.rs:173-232
+ *                                 (i.e. best_fft :383-422 + n^-1 scale :195 +
+ *                                 distribute_powers :198-204)
+ *   plonk_srs_load                CommitKey { powers_of_g } upload,
+ *                                 src/commitment_scheme/kzg10/key.rs:37-41
+ *   plonk_msm / plonk_msm_batch   the msm_variable_base call inside
+ *                                 CommitKey::commit, key.rs:376-388, and the 4-way
+ *                                 rayon::join fan-out of Prover::commit_polynomials,
+ *                                 src/compiler/prover.rs:187-210
+ *
+ * Data conventions (bit-identical to the reference's in-memory types):
+ *   Fr  = BlsScalar.0 : 4 x uint64 little-endian limbs, Montgomery form, R = 2^256.
+ *   G1 base           : 96 bytes = x || y, each 6 x uint64 LE limbs, Montgomery,
+ *                       R = 2^384 (first 96 bytes of G1Affine::to_raw_bytes,
+ *                       key.rs:215-229).  An SRS never contains the identity.
+ *   MSM result        : 97 bytes = x || y (as above) || infinity flag (0/1); the Rust
+ *                       shim rebuilds G1Affine / Commitment from it.
+ *
+ * Ownership: the caller owns every host buffer; nothing is retained after return
+ * except the SRS copy made by plonk_srs_load.  The context owns all device memory.
+ * Errors: 0 = ok, < 0 = error code below; nothing throws or aborts across the ABI.
+ * The shim maps a non-zero NTT code to a panic (the reference asserts,
+ * domain.rs:394,449) and PLONK_ERR_DEGREE to Error::PolynomialDegreeTooLarge
+ * (key.rs:362-370).  Threading: every entry point takes a per-context mutex, so
+ * rayon workers may call concurrently (prover.rs:174-177,194-197).
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plonk_ctx plonk_ctx;
+
+enum {
+  PLONK_OK = 0,
+  PLONK_ERR_ARG = -1,     /* null pointer, log_n out of range, length mismatch          */
+  PLONK_ERR_HIP = -2,     /* a HIP runtime call failed; see plonk_last_error()          */
+  PLONK_ERR_DEGREE = -3,  /* more scalars than SRS points (PolynomialDegreeTooLarge)    */
+  PLONK_ERR_NO_SRS = -4,  /* plonk_msm before plonk_srs_load                            */
+  PLONK_ERR_NO_GPU = -5,  /* no gfx950 device visible                                   */
+  PLONK_ERR_UNSAT = -6,   /* prover: quotient degree check failed (CircuitUnsatisfied)  */
+  PLONK_ERR_STATE = -7    /* prover: called out of order / missing key                  */
+};
+
+/* `devices`: HIP device ordinals; ndev must be 1 (one process per GPU — multi-GPU runs
+ * use one context per rank).  devices == NULL -> device 0. */
+int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev);
+void plonk_ctx_destroy(plonk_ctx* ctx);
+const char* plonk_last_error(void);
+
+/* In-place transform of a[0 .. 1<<log_n) (host memory).
+ *   inverse = 0: forward with w;  1: inverse with w^-1 and the n^-1 scale.
+ *   coset   = 1: forward pre-scales coefficient i by 7^i for i < in_len;
+ *                inverse post-scales output i by 7^-i.
+ *   in_len  : number of valid leading coefficients; the rest are treated as zero
+ *             (the zero-padding of Vec::resize, domain.rs:174).  Use 1<<log_n for
+ *             inverse transforms. */
+int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int coset, uint64_t in_len);
+int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_n, int inverse,
+                    int coset, const uint64_t* in_len);
+
+/* Upload the commit key (npoints x 96 B).  Builds the per-window tables
+ * 2^(16 w) * P_i in HBM (16 x 96 B per point). */
+int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
+
+/* sum_i scalars[i] * P_i for i < m.  m == 0 -> identity. */
+int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_xy_inf[97]);
+int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64_t* m, int count,
+                    uint8_t* out /* count x 97 */);
+
+/* ---- device-resident variants (buffers stay in HBM between calls) -------------
+ * Pointers are device pointers on the context's GPU (e.g. torch.Tensor.data_ptr()).
+ * dst may equal src.  tmp must hold 1<<log_n elements when log_n > 10. */
+int plonk_ntt_dev(plonk_ctx* ctx, const void* src, void* dst, void* tmp, uint32_t log_n,
+                  int inverse, int coset, uint64_t in_len);
+int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_dev);
+int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints);
+/* Synthetic "random SRS" [tau^i] G for i < npoints generated on the GPU
+ * (PublicParameters::setup semantics, src/commitment_scheme/kzg10/srs.rs:61-100);
+ * tau and g_scalar are Fr (Montgomery).  Writes npoints x 96 B to out_dev. */
+int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t g_scalar[4],
+                           uint64_t npoints, void* out_dev);
+
+/* plain device memory helpers so callers need no HIP bindings of their own */
+int plonk_dev_alloc(plonk_ctx* ctx, uint64_t bytes, void** out);
+int plonk_dev_free(plonk_ctx* ctx, void* p);
+int plonk_dev_h2d(plonk_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
+int plonk_dev_d2h(plonk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
+int plonk_dev_sync(plonk_ctx* ctx);
+void* plonk_ctx_stream(plonk_ctx* ctx); /* hipStream_t the library launches on */
+
+/* ---- measurement --------------------------------------------------------------
+ * When enabled, every launch of the dominant kernels is bracketed by a hipEvent
+ * pair ON THE LIBRARY'S STREAM and accumulated per slot.  Slots:
+ *   0 ntt pass kernels, 1 msm bucket accumulation, 2 msm (all other kernels),
+ *   3 quotient/pointwise kernels. */
+int plonk_profile_enable(plonk_ctx* ctx, int on);
+int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches);
+int plonk_profile_reset(plonk_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_HIP_H */

@@ -1,0 +1,259 @@
+"""plonk_amd — MI355X (gfx950) backend for dusk-plonk's prover hot path.
+
+Host-side mirror of the reference's two crate-private seams, over the C-ABI of
+libplonk_hip.so (include/plonk_hip.h):
+
+  Context.ntt(...)   EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}
+                     (reference src/fft/domain.rs:166-232)
+  Context.srs_load   CommitKey { powers_of_g } (src/commitment_scheme/kzg10/key.rs:37-41)
+  Context.msm / commit   CommitKey::commit -> msm_variable_base (key.rs:376-388)
+
+There is NO CPU fallback: if the HIP library or a GPU is missing every call
+raises.  Nothing in this package imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Iterable, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplonk_hip.so")
+
+# field constants needed to marshal Python ints <-> Montgomery limbs at the ABI
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+_FR_R = (1 << 256) % Q
+_FR_RINV = pow(_FR_R, -1, Q)
+_FP_R = (1 << 384) % P
+_FP_RINV = pow(_FP_R, -1, P)
+
+PLONK_OK = 0
+ERRORS = {
+    -1: "PLONK_ERR_ARG", -2: "PLONK_ERR_HIP", -3: "PLONK_ERR_DEGREE (PolynomialDegreeTooLarge)",
+    -4: "PLONK_ERR_NO_SRS", -5: "PLONK_ERR_NO_GPU", -6: "PLONK_ERR_UNSAT (CircuitUnsatisfied)",
+    -7: "PLONK_ERR_STATE",
+}
+
+# every symbol include/plonk_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = [
+    "plonk_ctx_create", "plonk_ctx_destroy", "plonk_last_error", "plonk_ntt", "plonk_ntt_batch",
+    "plonk_srs_load", "plonk_msm", "plonk_msm_batch", "plonk_ntt_dev", "plonk_msm_dev",
+    "plonk_srs_load_dev", "plonk_srs_generate_dev", "plonk_dev_alloc", "plonk_dev_free",
+    "plonk_dev_h2d", "plonk_dev_d2h", "plonk_dev_sync", "plonk_ctx_stream",
+    "plonk_profile_enable", "plonk_profile_read", "plonk_profile_reset",
+]
+
+
+class PlonkError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"{ERRORS.get(code, code)} {detail}".strip())
+
+
+class PolynomialDegreeTooLarge(PlonkError):
+    """Mirrors Error::PolynomialDegreeTooLarge (reference key.rs:362-370)."""
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen libplonk_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} not built — run `python __graft_entry__.py` (hipcc --offload-arch=gfx950)")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, u64, u32, ci = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int
+    lib.plonk_last_error.restype = ctypes.c_char_p
+    lib.plonk_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ci), ci]
+    lib.plonk_ctx_destroy.argtypes = [vp]
+    lib.plonk_ctx_destroy.restype = None
+    lib.plonk_ntt.argtypes = [vp, vp, u32, ci, ci, u64]
+    lib.plonk_ntt_batch.argtypes = [vp, ctypes.POINTER(vp), ci, u32, ci, ci, ctypes.POINTER(u64)]
+    lib.plonk_srs_load.argtypes = [vp, vp, u64]
+    lib.plonk_msm.argtypes = [vp, vp, u64, vp]
+    lib.plonk_msm_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(u64), ci, vp]
+    lib.plonk_ntt_dev.argtypes = [vp, vp, vp, vp, u32, ci, ci, u64]
+    lib.plonk_msm_dev.argtypes = [vp, vp, u64, vp]
+    lib.plonk_srs_load_dev.argtypes = [vp, vp, u64]
+    lib.plonk_srs_generate_dev.argtypes = [vp, vp, vp, u64, vp]
+    lib.plonk_dev_alloc.argtypes = [vp, u64, ctypes.POINTER(vp)]
+    lib.plonk_dev_free.argtypes = [vp, vp]
+    lib.plonk_dev_h2d.argtypes = [vp, vp, vp, u64]
+    lib.plonk_dev_d2h.argtypes = [vp, vp, vp, u64]
+    lib.plonk_dev_sync.argtypes = [vp]
+    lib.plonk_ctx_stream.argtypes = [vp]
+    lib.plonk_ctx_stream.restype = vp
+    lib.plonk_profile_enable.argtypes = [vp, ci]
+    lib.plonk_profile_read.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    lib.plonk_profile_reset.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+# ---- marshalling -----------------------------------------------------------------
+def fr_to_bytes_mont(vals: Iterable[int]) -> bytes:
+    return b"".join(((v % Q) * _FR_R % Q).to_bytes(32, "little") for v in vals)
+
+
+def fr_from_bytes_mont(buf: bytes) -> list[int]:
+    return [int.from_bytes(buf[i:i + 32], "little") * _FR_RINV % Q for i in range(0, len(buf), 32)]
+
+
+def g1_to_raw96(pt) -> bytes:
+    x, y = pt
+    return (x * _FP_R % P).to_bytes(48, "little") + (y * _FP_R % P).to_bytes(48, "little")
+
+
+def g1_from_raw97(buf: bytes):
+    if buf[96]:
+        return None
+    return (int.from_bytes(buf[:48], "little") * _FP_RINV % P,
+            int.from_bytes(buf[48:96], "little") * _FP_RINV % P)
+
+
+def g1_compress(pt) -> bytes:
+    """Commitment::to_bytes — 48-byte compressed G1 (reference commitment.rs:46-57)."""
+    if pt is None:
+        return bytes([0xC0]) + bytes(47)
+    x, y = pt
+    b = bytearray(x.to_bytes(48, "big"))
+    b[0] |= 0x80
+    if y > (P - y) % P:
+        b[0] |= 0x20
+    return bytes(b)
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = ctypes.c_void_p()
+        ctx._check(ctx.lib.plonk_dev_alloc(ctx.handle, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, data: bytes, offset: int = 0):
+        assert offset + len(data) <= self.nbytes
+        self.ctx._check(self.ctx.lib.plonk_dev_h2d(self.ctx.handle, self.ptr + offset, data, len(data)))
+
+    def download(self, nbytes: int | None = None, offset: int = 0) -> bytes:
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(nbytes)
+        self.ctx._check(self.ctx.lib.plonk_dev_d2h(self.ctx.handle, out, self.ptr + offset, nbytes))
+        return out.raw
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.plonk_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """One GPU, one stream (plonk_ctx).  One process per GPU in multi-GPU runs."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        dev = (ctypes.c_int * 1)(device)
+        rc = self.lib.plonk_ctx_create(ctypes.byref(h), dev, 1)
+        if rc != PLONK_OK:
+            raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
+        self.handle = h
+        self.srs_points = 0
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.plonk_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc == -3:
+            raise PolynomialDegreeTooLarge(rc)
+        if rc != PLONK_OK:
+            raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
+
+    # ---- EvaluationDomain seam ------------------------------------------------------
+    def ntt_bytes(self, data: bytes, log_n: int, inverse: bool, coset: bool, in_len: int) -> bytes:
+        n = 1 << log_n
+        buf = ctypes.create_string_buffer(32 * n)
+        ctypes.memmove(buf, data, min(len(data), 32 * n))
+        self._check(self.lib.plonk_ntt(self.handle, buf, log_n, int(inverse), int(coset), in_len))
+        return buf.raw
+
+    def ntt(self, values: Sequence[int], log_n: int, inverse: bool = False, coset: bool = False) -> list[int]:
+        """fft / ifft / coset_fft / coset_ifft on Python ints: zero-pads or truncates to
+        2^log_n exactly like Vec::resize at reference domain.rs:174."""
+        n = 1 << log_n
+        vals = list(values[:n])
+        return fr_from_bytes_mont(self.ntt_bytes(fr_to_bytes_mont(vals), log_n, inverse, coset,
+                                                 len(vals) if not inverse else n))
+
+    # ---- CommitKey seam ------------------------------------------------------------
+    def srs_load(self, points) -> None:
+        raw = b"".join(g1_to_raw96(p) for p in points)
+        self.srs_load_bytes(raw, len(points))
+
+    def srs_load_bytes(self, raw: bytes, npoints: int) -> None:
+        self._check(self.lib.plonk_srs_load(self.handle, raw, npoints))
+        self.srs_points = npoints
+
+    def msm_bytes(self, scalars_mont: bytes, m: int) -> bytes:
+        out = ctypes.create_string_buffer(97)
+        self._check(self.lib.plonk_msm(self.handle, scalars_mont, m, out))
+        return out.raw
+
+    def msm(self, scalars: Sequence[int]):
+        """msm_variable_base(&powers_of_g, scalars) -> affine point or None (identity)."""
+        return g1_from_raw97(self.msm_bytes(fr_to_bytes_mont(scalars), len(scalars)))
+
+    def commit(self, coeffs: Sequence[int]):
+        """CommitKey::commit (key.rs:376-388): trailing zeros trimmed like
+        Polynomial::from_coefficients_vec; degree check before the MSM."""
+        c = list(coeffs)
+        while c and c[-1] % Q == 0:
+            c.pop()
+        if len(c) > self.srs_points:
+            raise PolynomialDegreeTooLarge(-3)
+        return self.msm(c)
+
+    # ---- device-resident API ----------------------------------------------------
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def ntt_dev(self, src: int, dst: int, tmp: int, log_n: int, inverse=False, coset=False, in_len=None):
+        in_len = (1 << log_n) if in_len is None else in_len
+        self._check(self.lib.plonk_ntt_dev(self.handle, src, dst, tmp, log_n, int(inverse), int(coset), in_len))
+
+    def msm_dev(self, scalars: int, m: int, out97: int):
+        self._check(self.lib.plonk_msm_dev(self.handle, scalars, m, out97))
+
+    def srs_load_dev(self, ptr: int, npoints: int):
+        self._check(self.lib.plonk_srs_load_dev(self.handle, ptr, npoints))
+        self.srs_points = npoints
+
+    def srs_generate_dev(self, tau: int, g_scalar: int, npoints: int, out_ptr: int):
+        self._check(self.lib.plonk_srs_generate_dev(self.handle, fr_to_bytes_mont([tau]),
+                                                    fr_to_bytes_mont([g_scalar]), npoints, out_ptr))
+
+    def sync(self):
+        self._check(self.lib.plonk_dev_sync(self.handle))
+
+    def profile(self, on: bool):
+        self._check(self.lib.plonk_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        self._check(self.lib.plonk_profile_reset(self.handle))
+
+    def profile_read(self, slot: int):
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        self._check(self.lib.plonk_profile_read(self.handle, slot, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value

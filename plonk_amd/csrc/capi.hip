@@ -1,0 +1,314 @@
+// C-ABI of libplonk_hip.so (see include/plonk_hip.h for the contract and the
+// reference interfaces each entry point replaces).
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "plonk_internal.hpp"
+
+namespace plonk {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const char* what, const char* detail, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s:%d: %s -> %s", file, line, what, detail);
+  g_last_error = buf;
+}
+
+int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G1Affine* out_dev);
+
+// ---- hipEvent instrumentation ------------------------------------------------
+struct ProfRec { int slot; hipEvent_t a, b; };
+struct ProfState {
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  std::vector<ProfRec> recs;
+  hipEvent_t open[8] = {nullptr};
+};
+static std::map<Ctx*, ProfState*> g_prof;
+static std::mutex g_prof_mu;
+
+static ProfState* prof_state(Ctx* c) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  auto it = g_prof.find(c);
+  if (it != g_prof.end()) return it->second;
+  return g_prof[c] = new ProfState();
+}
+static hipEvent_t prof_event(ProfState* ps) {
+  if (ps->used == ps->pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    ps->pool.push_back(e);
+  }
+  return ps->pool[ps->used++];
+}
+void prof_begin(Ctx* c, int slot) {
+  if (!c->profile) return;
+  ProfState* ps = prof_state(c);
+  hipEvent_t e = prof_event(ps);
+  if (!e) return;
+  (void)hipEventRecord(e, c->stream);
+  ps->open[slot] = e;
+}
+void prof_end(Ctx* c, int slot) {
+  if (!c->profile) return;
+  ProfState* ps = prof_state(c);
+  if (!ps->open[slot]) return;
+  hipEvent_t e = prof_event(ps);
+  if (!e) return;
+  (void)hipEventRecord(e, c->stream);
+  ps->recs.push_back({slot, ps->open[slot], e});
+  ps->open[slot] = nullptr;
+}
+static int prof_collect(Ctx* c) {
+  ProfState* ps = prof_state(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (auto& r : ps->recs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->acc_ms[r.slot] += ms;
+      c->acc_n[r.slot] += 1;
+    }
+  }
+  ps->recs.clear();
+  ps->used = 0;
+  return PLONK_OK;
+}
+
+static int ensure_ntt_staging(Ctx* c, uint64_t n) {
+  if (n <= c->ntt_cap) return PLONK_OK;
+  if (c->ntt_buf) { HIP_TRY(hipFree(c->ntt_buf)); HIP_TRY(hipFree(c->ntt_tmp)); c->ntt_buf = c->ntt_tmp = nullptr; c->ntt_cap = 0; }
+  HIP_TRY(hipMalloc((void**)&c->ntt_buf, sizeof(Fr) * n));
+  HIP_TRY(hipMalloc((void**)&c->ntt_tmp, sizeof(Fr) * n));
+  c->ntt_cap = n;
+  return PLONK_OK;
+}
+
+static int ensure_scalar_staging(Ctx* c, uint64_t m) {
+  MsmWork& w = c->msm;
+  if (m <= w.cap_stage) return PLONK_OK;
+  if (w.scalars_stage) { HIP_TRY(hipFree(w.scalars_stage)); w.scalars_stage = nullptr; w.cap_stage = 0; }
+  HIP_TRY(hipMalloc((void**)&w.scalars_stage, sizeof(Fr) * m));
+  w.cap_stage = m;
+  return PLONK_OK;
+}
+
+}  // namespace plonk
+
+using namespace plonk;
+
+extern "C" {
+
+const char* plonk_last_error(void) { return g_last_error.c_str(); }
+
+int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
+  if (!out || ndev > 1 || ndev < 0) return PLONK_ERR_ARG;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    set_last_error("hipGetDeviceCount", "no HIP device visible", __FILE__, __LINE__);
+    return PLONK_ERR_NO_GPU;
+  }
+  const int dev = (devices && ndev == 1) ? devices[0] : 0;
+  if (dev < 0 || dev >= count) return PLONK_ERR_ARG;
+  HIP_TRY(hipSetDevice(dev));
+  auto* ctx = new plonk_ctx();
+  ctx->c.device = dev;
+  hipError_t e = hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_last_error("hipStreamCreate", hipGetErrorString(e), __FILE__, __LINE__);
+    delete ctx;
+    return PLONK_ERR_HIP;
+  }
+  *out = ctx;
+  return PLONK_OK;
+}
+
+void plonk_ctx_destroy(plonk_ctx* ctx) {
+  if (!ctx) return;
+  Ctx& c = ctx->c;
+  (void)hipSetDevice(c.device);
+  (void)hipStreamSynchronize(c.stream);
+  for (auto& kv : c.ntt_tables) {
+    NttTables* t = kv.second;
+    (void)hipFree(t->tw_lo); (void)hipFree(t->tw_hi); (void)hipFree(t->tw_lo_scaled);
+    (void)hipFree(t->w512); (void)hipFree(t->g_lo); (void)hipFree(t->g_hi);
+    delete t;
+  }
+  (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_tmp); (void)hipFree(c.srs_table);
+  MsmWork& w = c.msm;
+  (void)hipFree(w.digits); (void)hipFree(w.entries); (void)hipFree(w.counts); (void)hipFree(w.offsets);
+  (void)hipFree(w.cursors); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
+  (void)hipFree(w.chunk); (void)hipFree(w.result); (void)hipFree(w.scalars_stage);
+  if (w.result_host) (void)hipHostFree(w.result_host);
+  (void)hipStreamDestroy(c.stream);
+  delete ctx;
+}
+
+void* plonk_ctx_stream(plonk_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+
+// ---- device memory helpers ----------------------------------------------------
+int plonk_dev_alloc(plonk_ctx* ctx, uint64_t bytes, void** out) {
+  if (!ctx || !out) return PLONK_ERR_ARG;
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+  return PLONK_OK;
+}
+int plonk_dev_free(plonk_ctx* ctx, void* p) {
+  if (!ctx) return PLONK_ERR_ARG;
+  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  HIP_TRY(hipFree(p));
+  return PLONK_OK;
+}
+int plonk_dev_h2d(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
+  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  return PLONK_OK;
+}
+int plonk_dev_d2h(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
+  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  return PLONK_OK;
+}
+int plonk_dev_sync(plonk_ctx* ctx) {
+  if (!ctx) return PLONK_ERR_ARG;
+  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  return PLONK_OK;
+}
+
+// ---- NTT ------------------------------------------------------------------------
+int plonk_ntt_dev(plonk_ctx* ctx, const void* src, void* dst, void* tmp, uint32_t log_n, int inverse,
+                  int coset, uint64_t in_len) {
+  if (!ctx || !src || !dst || log_n >= 28) return PLONK_ERR_ARG;
+  if (log_n > 10 && !tmp) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  prof_begin(&ctx->c, 0);
+  int rc = ntt_device(&ctx->c, (const Fr*)src, (Fr*)dst, (Fr*)tmp, log_n, inverse != 0, coset != 0, in_len);
+  prof_end(&ctx->c, 0);
+  return rc;
+}
+
+int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int coset, uint64_t in_len) {
+  if (!ctx || !a || log_n >= 28) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  const uint64_t n = 1ull << log_n;
+  if (in_len > n) in_len = n;
+  int rc = ensure_ntt_staging(&c, n);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c.ntt_buf, a, sizeof(Fr) * in_len, hipMemcpyHostToDevice, c.stream));
+  rc = ntt_device(&c, c.ntt_buf, c.ntt_buf, c.ntt_tmp, log_n, inverse != 0, coset != 0, in_len);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(a, c.ntt_buf, sizeof(Fr) * n, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  return PLONK_OK;
+}
+
+int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_n, int inverse, int coset,
+                    const uint64_t* in_len) {
+  if (!ctx || !a || count < 0) return PLONK_ERR_ARG;
+  for (int i = 0; i < count; ++i) {
+    int rc = plonk_ntt(ctx, a[i], log_n, inverse, coset, in_len ? in_len[i] : (1ull << log_n));
+    if (rc) return rc;
+  }
+  return PLONK_OK;
+}
+
+// ---- SRS / MSM ---------------------------------------------------------------------
+int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints) {
+  if (!ctx || (!xy96_dev && npoints)) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  return srs_load_device(&ctx->c, (const G1Affine*)xy96_dev, npoints);
+}
+
+int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
+  if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  G1Affine* tmp = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(G1Affine) * (npoints ? npoints : 1)));
+  hipError_t e = hipMemcpyAsync(tmp, xy96, sizeof(G1Affine) * npoints, hipMemcpyHostToDevice, c.stream);
+  int rc = (e == hipSuccess) ? srs_load_device(&c, tmp, npoints) : PLONK_ERR_HIP;
+  (void)hipStreamSynchronize(c.stream);
+  (void)hipFree(tmp);
+  return rc;
+}
+
+int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t g_scalar[4], uint64_t npoints,
+                           void* out_dev) {
+  if (!ctx || !tau || !g_scalar || !out_dev) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  Fr t, g;
+  memcpy(&t, tau, 32);
+  memcpy(&g, g_scalar, 32);
+  return srs_generate_device(&ctx->c, t, g, npoints, (G1Affine*)out_dev);
+}
+
+int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_dev) {
+  if (!ctx || (!scalars && m) || !out97_dev) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  return msm_device(&ctx->c, (const Fr*)scalars, m, (uint8_t*)out97_dev);
+}
+
+int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_xy_inf[97]) {
+  if (!ctx || (!scalars && m) || !out_xy_inf) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  if (m && !c.srs_table) return PLONK_ERR_NO_SRS;
+  if (m > c.srs_n) return PLONK_ERR_DEGREE;
+  int rc = msm_reserve(&c, m ? m : 1);
+  if (rc) return rc;
+  rc = ensure_scalar_staging(&c, m ? m : 1);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c.msm.scalars_stage, scalars, sizeof(Fr) * m, hipMemcpyHostToDevice, c.stream));
+  rc = msm_device(&c, c.msm.scalars_stage, m, c.msm.result);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, 97, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  memcpy(out_xy_inf, c.msm.result_host, 97);
+  return PLONK_OK;
+}
+
+int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64_t* m, int count, uint8_t* out) {
+  if (!ctx || !scalars || !m || !out || count < 0) return PLONK_ERR_ARG;
+  for (int i = 0; i < count; ++i) {
+    int rc = plonk_msm(ctx, scalars[i], m[i], out + 97 * (size_t)i);
+    if (rc) return rc;
+  }
+  return PLONK_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------
+int plonk_profile_enable(plonk_ctx* ctx, int on) {
+  if (!ctx) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  ctx->c.profile = on != 0;
+  return PLONK_OK;
+}
+int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches) {
+  if (!ctx || slot < 0 || slot >= 8) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  int rc = prof_collect(&ctx->c);
+  if (rc) return rc;
+  if (total_ms) *total_ms = ctx->c.acc_ms[slot];
+  if (launches) *launches = ctx->c.acc_n[slot];
+  return PLONK_OK;
+}
+int plonk_profile_reset(plonk_ctx* ctx) {
+  if (!ctx) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  int rc = prof_collect(&ctx->c);
+  for (int i = 0; i < 8; ++i) { ctx->c.acc_ms[i] = 0; ctx->c.acc_n[i] = 0; }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,374 @@
+// KZG10 commitment MSM on G1 for gfx950 (MI355X): sum_i s_i * [tau^i]G.
+//
+// Replaces dusk_bls12_381::multiscalar_mul::msm_variable_base as called from
+// CommitKey::commit (reference src/commitment_scheme/kzg10/key.rs:376-388).
+// The result is a unique group element, so the schedule is free; this one is
+// sized for 288 GB of HBM rather than copied from the CPU Pippenger:
+//
+//   * plonk_srs_load precomputes T[w][i] = 2^(16 w) * P_i for the 16 windows
+//     (16 x 96 B per SRS point; 1.5 GiB at 2^20 points).  All windows then share
+//     ONE set of 2^15 signed-digit buckets, so there is no per-window bucket
+//     reduction and no Horner doubling chain at the end.
+//   * msm_digits   : scalars -> canonical form -> 16 signed 16-bit digits,
+//                    bucket histogram (global atomics).
+//   * msm_scan     : exclusive scans -> bucket offsets and slice offsets
+//                    (a slice = at most MSM_KSL entries of one bucket).
+//   * msm_scatter  : counting-sort scatter of (table index | sign) by bucket.
+//   * msm_accumulate (dominant): one lane per slice; gathers affine table points
+//                    and folds them into an XYZZ accumulator (mixed addition,
+//                    384-bit Montgomery arithmetic on the VALU).
+//   * msm_bucket_sum, msm_chunk_reduce, msm_final: slice partials -> buckets ->
+//                    sum_b b * B_b -> affine.
+//
+// Algorithmic HBM bytes per MSM of m terms: 128 * m (32 B scalar + 96 B base).
+#include "plonk_internal.hpp"
+
+namespace plonk {
+
+static constexpr uint32_t MSM_KSL = 32;   // entries per slice
+static constexpr uint32_t MSM_CHUNK = 16; // buckets per chunk in the weighted reduction
+
+__device__ __forceinline__ Fr ld_fr_g(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ Fp ld_fp(const Fp* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2];
+  Fp r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+  return r;
+}
+__device__ __forceinline__ void st_fp(Fp* p, const Fp& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+}
+__device__ __forceinline__ G1Affine ld_aff(const G1Affine* p) {
+  G1Affine a;
+  a.x = ld_fp(&p->x);
+  a.y = ld_fp(&p->y);
+  return a;
+}
+__device__ __forceinline__ void st_aff(G1Affine* p, const G1Affine& a) {
+  st_fp(&p->x, a.x);
+  st_fp(&p->y, a.y);
+}
+__device__ __forceinline__ G1 ld_g1(const G1* p) {
+  G1 r;
+  r.X = ld_fp(&p->X); r.Y = ld_fp(&p->Y); r.ZZ = ld_fp(&p->ZZ); r.ZZZ = ld_fp(&p->ZZZ);
+  return r;
+}
+__device__ __forceinline__ void st_g1(G1* p, const G1& v) {
+  st_fp(&p->X, v.X); st_fp(&p->Y, v.Y); st_fp(&p->ZZ, v.ZZ); st_fp(&p->ZZZ, v.ZZZ);
+}
+
+// ---------------------------------------------------------------------------
+// SRS tables
+// ---------------------------------------------------------------------------
+// T[w * n + i] = 2^(16 w) * P_i, affine.  One lane per point; 16 doublings and one
+// Fp inversion per window (one-off per Prover, outside every timed region).
+__global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1Affine* __restrict__ table, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine a = ld_aff(pts + i);
+  st_aff(table + i, a);
+  for (int w = 1; w < MSM_W; ++w) {
+    G1 p = G1::dbl_affine(a);
+    for (int k = 1; k < MSM_C; ++k) p = p.dbl();
+    p.to_affine(&a);   // order of P_i is the (prime) group order: never the identity
+    st_aff(table + (uint64_t)w * n + i, a);
+  }
+}
+
+__device__ __forceinline__ G1Affine g1_generator() {
+  G1Affine g;
+  const uint32_t gx[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                           0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+  const uint32_t gy[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                           0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { g.x.l[k] = gx[k]; g.y.l[k] = gy[k]; }
+  return g;
+}
+
+// out[i] = (g_scalar * tau^i) * G   — synthetic SRS (srs.rs:61-100 semantics)
+__global__ void srs_generate_kernel(Fr tau, Fr g_scalar, uint64_t n, G1Affine* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr k = (g_scalar * tau.pow_u64(i)).from_mont();
+  const G1Affine g = g1_generator();
+  G1 acc = G1::identity();
+  for (int w = 7; w >= 0; --w)
+    for (int b = 31; b >= 0; --b) {
+      acc = acc.dbl();
+      if ((k.l[w] >> b) & 1) acc = acc.add_affine(g);
+    }
+  G1Affine a;
+  acc.to_affine(&a);
+  st_aff(out + i, a);
+}
+
+// ---------------------------------------------------------------------------
+// digits, histogram, scatter
+// ---------------------------------------------------------------------------
+// digit word: 0 = skip; else (bucket_index + 1) | sign << 31, bucket_index = |d| - 1
+__global__ void msm_digits_kernel(const Fr* __restrict__ scalars, uint64_t m, uint32_t* __restrict__ digits,
+                                  uint32_t* __restrict__ counts) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const Fr s = ld_fr_g(scalars + i).from_mont();
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < MSM_W; ++w) {
+    const uint32_t raw = (s.l[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+    uint32_t v = raw + carry;
+    uint32_t word = 0;
+    carry = 0;
+    if (v > MSM_NB) {          // negative digit d = v - 65536
+      carry = 1;
+      const uint32_t mag = 65536u - v;
+      if (mag) word = mag | 0x80000000u;
+    } else if (v) {
+      word = v;
+    }
+    digits[(uint64_t)w * m + i] = word;
+    if (word) atomicAdd(&counts[(word & 0x7fffffffu) - 1], 1u);
+  }
+}
+
+// exclusive scans over NB entries, single workgroup of 1024 threads:
+//   offsets[b]   = sum_{b' < b} counts[b']
+//   slice_off[b] = sum_{b' < b} ceil(counts[b'] / KSL)
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ offsets,
+                                                        uint32_t* __restrict__ slice_off,
+                                                        uint32_t* __restrict__ cursors) {
+  __shared__ uint32_t sa[1024], sb[1024];
+  constexpr uint32_t PER = MSM_NB / 1024;
+  const uint32_t t = threadIdx.x;
+  uint32_t a = 0, b = 0;
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t c = counts[t * PER + k];
+    a += c;
+    b += (c + MSM_KSL - 1) / MSM_KSL;
+  }
+  sa[t] = a;
+  sb[t] = b;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t xa = 0, xb = 0;
+    if (t >= d) { xa = sa[t - d]; xb = sb[t - d]; }
+    __syncthreads();
+    sa[t] += xa;
+    sb[t] += xb;
+    __syncthreads();
+  }
+  uint32_t ra = sa[t] - a, rb = sb[t] - b;   // exclusive prefix of this thread's chunk
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t idx = t * PER + k;
+    const uint32_t c = counts[idx];
+    offsets[idx] = ra;
+    slice_off[idx] = rb;
+    cursors[idx] = 0;
+    ra += c;
+    rb += (c + MSM_KSL - 1) / MSM_KSL;
+  }
+  if (t == 1023) {
+    offsets[MSM_NB] = ra;
+    slice_off[MSM_NB] = rb;
+  }
+}
+
+// entries[offsets[b] + k] = (w * srs_n + i) | sign
+__global__ void msm_scatter_kernel(const uint32_t* __restrict__ digits, uint64_t m, uint64_t srs_n,
+                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors,
+                                   uint32_t* __restrict__ entries) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+#pragma unroll
+  for (int w = 0; w < MSM_W; ++w) {
+    const uint32_t word = digits[(uint64_t)w * m + i];
+    if (!word) continue;
+    const uint32_t b = (word & 0x7fffffffu) - 1;
+    const uint32_t pos = atomicAdd(&cursors[b], 1u);
+    entries[offsets[b] + pos] = (uint32_t)((uint64_t)w * srs_n + i) | (word & 0x80000000u);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// accumulation
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine* __restrict__ table,
+                                                             const uint32_t* __restrict__ entries,
+                                                             const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ slice_off,
+                                                             G1* __restrict__ partial) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nslices = slice_off[MSM_NB];
+  if (s >= nslices) return;
+  // bucket of this slice: largest b with slice_off[b] <= s
+  uint32_t lo = 0, hi = MSM_NB - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (slice_off[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t b = lo;
+  const uint32_t q = s - slice_off[b];
+  const uint32_t beg = offsets[b] + q * MSM_KSL;
+  uint32_t end = beg + MSM_KSL;
+  const uint32_t bend = offsets[b + 1];
+  if (end > bend) end = bend;
+  G1 acc = G1::identity();
+  for (uint32_t k = beg; k < end; ++k) {
+    const uint32_t ent = entries[k];
+    G1Affine a = ld_aff(table + (ent & 0x7fffffffu));
+    if (ent & 0x80000000u) a.y = a.y.neg();
+    acc = acc.add_affine(a);
+  }
+  st_g1(partial + s, acc);
+}
+
+__global__ void __launch_bounds__(128) msm_bucket_sum_kernel(const G1* __restrict__ partial,
+                                                             const uint32_t* __restrict__ slice_off,
+                                                             G1* __restrict__ buckets) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= MSM_NB) return;
+  const uint32_t beg = slice_off[b], end = slice_off[b + 1];
+  G1 acc = G1::identity();
+  for (uint32_t k = beg; k < end; ++k) acc = acc.add(ld_g1(partial + k));
+  st_g1(buckets + b, acc);
+}
+
+// V_j = sum_{i < CHUNK} (CHUNK*j + i + 1) * B[CHUNK*j + i]
+__global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1* __restrict__ buckets, G1* __restrict__ chunk) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= MSM_NB / MSM_CHUNK) return;
+  G1 run = G1::identity(), acc = G1::identity();
+  for (int i = MSM_CHUNK - 1; i >= 0; --i) {
+    run = run.add(ld_g1(buckets + j * MSM_CHUNK + i));
+    acc = acc.add(run);
+  }
+  if (j) acc = acc.add(run.mul_u32(j * MSM_CHUNK));
+  st_g1(chunk + j, acc);
+}
+
+// sum of NB/CHUNK = 2048 chunk results -> affine (x || y || inf flag)
+__global__ void __launch_bounds__(256) msm_final_kernel(const G1* __restrict__ chunk, uint8_t* __restrict__ out97) {
+  __shared__ G1 sh[256];
+  const uint32_t t = threadIdx.x;
+  constexpr uint32_t PER = (MSM_NB / MSM_CHUNK) / 256;
+  G1 acc = G1::identity();
+  for (uint32_t k = 0; k < PER; ++k) acc = acc.add(ld_g1(chunk + t * PER + k));
+  sh[t] = acc;
+  __syncthreads();
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    if (t < d) sh[t] = sh[t].add(sh[t + d]);
+    __syncthreads();
+  }
+  if (t == 0) {
+    G1Affine a;
+    const bool finite = sh[0].to_affine(&a);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out97);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) { o[k] = a.x.l[k]; o[12 + k] = a.y.l[k]; }
+    out97[96] = finite ? 0 : 1;
+  }
+}
+
+__global__ void msm_identity_kernel(uint8_t* out97) {
+  if (threadIdx.x < 96) out97[threadIdx.x] = 0;
+  if (threadIdx.x == 96) out97[96] = 1;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
+  if (c->srs_table) { HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
+  if (n == 0) return PLONK_OK;
+  if ((uint64_t)MSM_W * n >= (1ull << 31)) return PLONK_ERR_ARG;   // entry word: 31-bit table index
+  HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1Affine) * (size_t)MSM_W * n));
+  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, c->srs_table, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->srs_n = n;
+  return PLONK_OK;
+}
+
+int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G1Affine* out_dev) {
+  hipLaunchKernelGGL(srs_generate_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, tau, g_scalar, n, out_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return PLONK_OK;
+}
+
+int msm_reserve(Ctx* c, uint64_t m) {
+  MsmWork& w = c->msm;
+  if (!w.counts) {
+    HIP_TRY(hipMalloc((void**)&w.counts, sizeof(uint32_t) * MSM_NB));
+    HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1)));
+    HIP_TRY(hipMalloc((void**)&w.cursors, sizeof(uint32_t) * MSM_NB));
+    HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1)));
+    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1) * MSM_NB));
+    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1) * (MSM_NB / MSM_CHUNK)));
+    HIP_TRY(hipMalloc((void**)&w.result, 128));
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, 128, hipHostMallocDefault));
+  }
+  if (m > w.cap_m) {
+    if (w.digits) { HIP_TRY(hipFree(w.digits)); HIP_TRY(hipFree(w.entries)); HIP_TRY(hipFree(w.partial)); }
+    const uint64_t cap = m;
+    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap));
+    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap));
+    w.cap_slices = (MSM_W * cap) / MSM_KSL + MSM_NB + 1;
+    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1) * w.cap_slices));
+    w.cap_m = cap;
+  }
+  return PLONK_OK;
+}
+
+void prof_begin(Ctx* c, int slot);
+void prof_end(Ctx* c, int slot);
+
+int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, uint8_t* out97_dev) {
+  if (m == 0) {
+    hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(128), 0, c->stream, out97_dev);
+    HIP_TRY(hipGetLastError());
+    return PLONK_OK;
+  }
+  if (!c->srs_table) return PLONK_ERR_NO_SRS;
+  if (m > c->srs_n) return PLONK_ERR_DEGREE;
+  int rc = msm_reserve(c, m);
+  if (rc) return rc;
+  MsmWork& w = c->msm;
+  hipStream_t st = c->stream;
+  prof_begin(c, 2);
+  HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * MSM_NB, st));
+  const uint32_t gb = (uint32_t)((m + 255) / 256);
+  hipLaunchKernelGGL(msm_digits_kernel, dim3(gb), dim3(256), 0, st, scalars_dev, m, w.digits, w.counts);
+  hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors);
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, st, w.digits, m, c->srs_n, w.offsets, w.cursors, w.entries);
+  prof_end(c, 2);
+  // upper bound on slices known on the host: no device->host sync on the path
+  const uint64_t max_slices = (MSM_W * m) / MSM_KSL + MSM_NB + 1;
+  prof_begin(c, 1);
+  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128)), dim3(128), 0, st,
+                     c->srs_table, w.entries, w.offsets, w.slice_off, w.partial);
+  prof_end(c, 1);
+  prof_begin(c, 2);
+  hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB / 128), dim3(128), 0, st, w.partial, w.slice_off, w.buckets);
+  hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64), dim3(64), 0, st, w.buckets, w.chunk);
+  hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, w.chunk, out97_dev);
+  prof_end(c, 2);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
+}  // namespace plonk

@@ -1,0 +1,460 @@
+// Radix-2 NTT / iNTT / coset variants over BLS12-381 Fr for gfx950 (MI355X).
+//
+// Replaces the bodies of EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place
+// (reference src/fft/domain.rs:166-232) i.e. best_fft (:383-422) + bitreverse
+// (:434) + the n^-1 scale (:195) + distribute_powers (:198-204).  Results are the
+// same field elements bit for bit (an NTT is a unique linear map); only the
+// schedule differs:
+//
+//   N = R1 * R2 * R3 (each <= 512).  Pass A does R1-point transforms down the
+//   most significant index digit (stride N/R1), multiplies by w_N^(k1 * col) and
+//   stores TRANSPOSED; pass B (3-pass only) and pass C run the remaining digits
+//   in place.  Natural order in, natural order out, no bit-reversal pass
+//   (Stockham-style autosort through the transposed store).  Every pass moves a
+//   [R rows][C cols] tile of 2048 elements per 256-thread workgroup: global
+//   loads/stores are runs of C (>= 4) consecutive 32-byte elements, the
+//   transposed store writes runs of R1 consecutive elements.
+//
+//   Inside a tile each thread keeps 8 elements (64 VGPRs) and performs radix-8
+//   decimation-in-frequency rounds in registers; rounds exchange data through LDS
+//   kept limb-planar (8 planes of u32) so DS traffic is plain 4-byte accesses.
+//   Small twiddles (w_512^e) sit in LDS; the inter-pass twiddle w_N^e is
+//   TWLO[e & 8191] * TWHI[e >> 13].
+//
+// HBM traffic: 64*N bytes per pass (32 read + 32 written), i.e. 128*N / 192*N
+// for the 2- / 3-pass plans against the algorithmic 64*N.  The kernel is bound by
+// 32-bit integer multiply issue (one Fr product ~ 128 v_mad_u64_u32), not HBM.
+//
+// tests/ntt_model.py mirrors the index arithmetic below (same names) and is
+// checked against the oracle on CPU.
+#include "plonk_internal.hpp"
+
+namespace plonk {
+
+static constexpr int TILE_LOG = 11;
+static constexpr int NTT_THREADS = 256;
+static constexpr int TWLO_BITS = 13;
+static constexpr int GLO_BITS = 10;
+
+struct NttPass {
+  const Fr* src;
+  Fr* dst;
+  uint32_t logN;
+  // element address = row * rs + (cg >> hshift) * hs + (cg & ((1<<hshift)-1)) * ls
+  uint64_t in_rs, in_hs;
+  uint32_t in_hshift;
+  uint64_t out_rs, out_hs, out_ls;
+  uint32_t out_hshift;
+  // inter-pass twiddle: value *= w_N^(k * ((cg >> tw_shr) << tw_shr))
+  int tw_mode;
+  uint32_t tw_shr;
+  const Fr* tw_lo;
+  const Fr* tw_hi;
+  // first pass: zero beyond in_len, optional coset scale g^i
+  uint64_t in_len;
+  int pre_coset;
+  // last pass: 0 none, 1 multiply by `scale`, 2 multiply by GLO[o & 1023] * GHI[o >> 10]
+  int post_mode;
+  Fr scale;
+  const Fr* g_lo;
+  const Fr* g_hi;
+  const Fr* w512;   // w_512^e, e < 256 (direction specific)
+};
+
+__device__ __forceinline__ Fr ld_fr(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// LDS planes: data[l * 2048 + idx], wtab[l * 256 + e]
+__device__ __forceinline__ Fr lds_get(const uint32_t* base, int stride, int idx) {
+  Fr r;
+#pragma unroll
+  for (int l = 0; l < 8; ++l) r.l[l] = base[l * stride + idx];
+  return r;
+}
+__device__ __forceinline__ void lds_put(uint32_t* base, int stride, int idx, const Fr& v) {
+#pragma unroll
+  for (int l = 0; l < 8; ++l) base[l * stride + idx] = v.l[l];
+}
+
+// tests/ntt_model.py: elem_index
+template <int POS, int RB>
+__device__ __forceinline__ int elem_index(int t, int e) {
+  const int j = e & ((1 << RB) - 1);
+  const int ge = e >> RB;
+  const int rest = (ge << (TILE_LOG - 3)) | t;
+  const int lo = rest & ((1 << POS) - 1);
+  const int hi = rest >> POS;
+  return (hi << (POS + RB)) | (j << POS) | lo;
+}
+
+// One DIF stage on local bit LB of a register round (global row bit LO + LB).
+template <int RLOG, int LO, int LB>
+__device__ __forceinline__ void dif_stage(Fr (&v)[8], int rlow_thread, const uint32_t* wtab) {
+  constexpr int bitpos = LO + LB;
+#pragma unroll
+  for (int x = 0; x < (1 << LB); ++x) {
+    Fr w;
+    if constexpr (bitpos > 0) {
+      const int rlow = rlow_thread | (x << LO);          // row & (2^bitpos - 1)
+      w = lds_get(wtab, 256, rlow << (8 - bitpos));
+    }
+#pragma unroll
+    for (int y = 0; y < (8 >> (LB + 1)); ++y) {         // bits above LB (incl. extra groups)
+      const int e = (y << (LB + 1)) | x;
+      const int e2 = e | (1 << LB);
+      Fr a = v[e], b = v[e2];
+      v[e] = a + b;
+      Fr d = a - b;
+      if constexpr (bitpos > 0) v[e2] = d * w; else v[e2] = d;
+    }
+  }
+}
+
+// One register round: RB DIF stages on the row bits [LO, LO+RB), top bit first.
+template <int RLOG, int LO, int RB>
+__device__ __forceinline__ void dif_round(Fr (&v)[8], int t, const uint32_t* wtab) {
+  constexpr int CLOG = TILE_LOG - RLOG;
+  const int rlow_thread = (LO > 0) ? ((t >> CLOG) & ((1 << LO) - 1)) : 0;
+  if constexpr (RB >= 3) dif_stage<RLOG, LO, 2>(v, rlow_thread, wtab);
+  if constexpr (RB >= 2) dif_stage<RLOG, LO, 1>(v, rlow_thread, wtab);
+  dif_stage<RLOG, LO, 0>(v, rlow_thread, wtab);
+}
+
+template <int RLOG, int R_IDX>
+struct RoundGeom {
+  static constexpr int HI = RLOG - 3 * R_IDX;
+  static constexpr int LO = (HI - 3 > 0) ? HI - 3 : 0;
+  static constexpr int RB = HI - LO;
+  static constexpr int POS = (TILE_LOG - RLOG) + LO;
+};
+
+template <int RLOG, int R_IDX, int NR>
+struct Rounds {
+  // rounds R_IDX .. NR-1; on entry v holds round R_IDX's elements
+  __device__ static __forceinline__ void run(Fr (&v)[8], int t, uint32_t* data, const uint32_t* wtab) {
+    using G = RoundGeom<RLOG, R_IDX>;
+    dif_round<RLOG, G::LO, G::RB>(v, t, wtab);
+    if constexpr (R_IDX + 1 < NR) {
+      using Gn = RoundGeom<RLOG, R_IDX + 1>;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lds_put(data, 1 << TILE_LOG, elem_index<G::POS, G::RB>(t, e), v[e]);
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = lds_get(data, 1 << TILE_LOG, elem_index<Gn::POS, Gn::RB>(t, e));
+      Rounds<RLOG, R_IDX + 1, NR>::run(v, t, data, wtab);
+    }
+  }
+};
+
+__device__ __forceinline__ Fr two_level(const Fr* lo, const Fr* hi, uint64_t e, int lobits, bool use_hi) {
+  Fr w = ld_fr(lo + (e & ((1ull << lobits) - 1)));
+  if (use_hi) w = w * ld_fr(hi + (e >> lobits));
+  return w;
+}
+
+template <int RLOG, bool TRANSPOSE>
+__global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
+  constexpr int CLOG = TILE_LOG - RLOG;
+  constexpr int C = 1 << CLOG;
+  constexpr int NR = (RLOG + 2) / 3;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint32_t* data = smem;                       // 8 * 2048 u32
+  uint32_t* wtab = smem + 8 * (1 << TILE_LOG);  // 8 * 256 u32
+  const int t = threadIdx.x;
+  const uint64_t cg0 = (uint64_t)blockIdx.x * C;
+
+  {  // small twiddles -> LDS (planar)
+    Fr w = ld_fr(p.w512 + t);
+    lds_put(wtab, 256, t, w);
+  }
+
+  // ---- load round 0 operands straight from HBM
+  using G0 = RoundGeom<RLOG, 0>;
+  Fr v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int idx = elem_index<G0::POS, G0::RB>(t, e);
+    const uint64_t row = idx >> CLOG;
+    const uint64_t cg = cg0 + (idx & (C - 1));
+    const uint64_t gi = row * p.in_rs + (cg >> p.in_hshift) * p.in_hs + (cg & ((1ull << p.in_hshift) - 1));
+    if (gi < p.in_len) {
+      Fr x = ld_fr(p.src + gi);
+      if (p.pre_coset) x = x * two_level(p.g_lo, p.g_hi, gi, GLO_BITS, true);
+      v[e] = x;
+    } else {
+      v[e] = Fr::zero();
+    }
+  }
+  __syncthreads();   // wtab visible
+  Rounds<RLOG, 0, NR>::run(v, t, data, wtab);
+
+  // ---- epilogue: inter-pass twiddle / scaling, then store
+  using GL = RoundGeom<RLOG, NR - 1>;
+  const uint64_t nmask = (1ull << p.logN) - 1;
+  const bool use_hi = p.logN > TWLO_BITS;
+  if constexpr (!TRANSPOSE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = elem_index<GL::POS, GL::RB>(t, e);
+      const uint32_t prow = idx >> CLOG;
+      const uint64_t k = __brev(prow) >> (32 - RLOG);
+      const uint64_t cg = cg0 + (idx & (C - 1));
+      Fr x = v[e];
+      if (p.tw_mode) {
+        const uint64_t twcol = (cg >> p.tw_shr) << p.tw_shr;
+        x = x * two_level(p.tw_lo, p.tw_hi, (k * twcol) & nmask, TWLO_BITS, use_hi);
+      }
+      const uint64_t o = k * p.out_rs + (cg >> p.out_hshift) * p.out_hs +
+                         (cg & ((1ull << p.out_hshift) - 1)) * p.out_ls;
+      if (p.post_mode == 1) x = x * p.scale;
+      else if (p.post_mode == 2) x = x * two_level(p.g_lo, p.g_hi, o, GLO_BITS, true);
+      st_fr(p.dst + o, x);
+    }
+  } else {
+    constexpr int R = 1 << RLOG;
+    __syncthreads();   // everyone finished reading `data` for the last round
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = elem_index<GL::POS, GL::RB>(t, e);
+      const uint32_t prow = idx >> CLOG;
+      const uint32_t k = __brev(prow) >> (32 - RLOG);
+      const int col = idx & (C - 1);
+      const uint64_t cg = cg0 + col;
+      Fr x = v[e];
+      if (p.tw_mode) {
+        const uint64_t twcol = (cg >> p.tw_shr) << p.tw_shr;
+        x = x * two_level(p.tw_lo, p.tw_hi, ((uint64_t)k * twcol) & nmask, TWLO_BITS, use_hi);
+      }
+      lds_put(data, 1 << TILE_LOG, col * R + (int)k, x);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int u = i * NTT_THREADS + t;
+      const int col = u >> RLOG;
+      const uint64_t k = u & (R - 1);
+      const uint64_t cg = cg0 + col;
+      Fr x = lds_get(data, 1 << TILE_LOG, u);
+      const uint64_t o = k * p.out_rs + (cg >> p.out_hshift) * p.out_hs +
+                         (cg & ((1ull << p.out_hshift) - 1)) * p.out_ls;
+      st_fr(p.dst + o, x);
+    }
+  }
+}
+
+// ---- small transforms (N <= 1024): one workgroup, DIT on a bit-reversed load,
+// twiddles straight from the full w_N^e table (TWLO holds all of them for L <= 13).
+struct NttSmall {
+  const Fr* src;
+  Fr* dst;
+  uint32_t logN;
+  uint64_t in_len;
+  int pre_coset, post_mode;
+  Fr scale;
+  const Fr* tw_lo;
+  const Fr* g_lo;
+  const Fr* g_hi;
+};
+
+__global__ void __launch_bounds__(NTT_THREADS) ntt_small_kernel(NttSmall p) {
+  __shared__ __attribute__((aligned(16))) Fr buf[1024];
+  const uint32_t L = p.logN, N = 1u << L;
+  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) {
+    const uint32_t s = L ? (__brev(i) >> (32 - L)) : 0;
+    Fr x = Fr::zero();
+    if (s < p.in_len) {
+      x = ld_fr(p.src + s);
+      if (p.pre_coset) x = x * two_level(p.g_lo, p.g_hi, s, GLO_BITS, true);
+    }
+    buf[i] = x;
+  }
+  __syncthreads();
+  for (uint32_t s = 0; s < L; ++s) {
+    const uint32_t m = 1u << s;
+    for (uint32_t b = threadIdx.x; b < N / 2; b += blockDim.x) {
+      const uint32_t j = b & (m - 1);
+      const uint32_t lo = ((b >> s) << (s + 1)) | j;
+      const uint32_t hi = lo + m;
+      Fr tt = buf[hi];
+      if (j) tt = tt * ld_fr(p.tw_lo + ((uint64_t)j << (L - 1 - s)));
+      Fr a = buf[lo];
+      buf[hi] = a - tt;
+      buf[lo] = a + tt;
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) {
+    Fr x = buf[i];
+    if (p.post_mode) x = x * p.scale;                                                    // n^-1
+    if (p.post_mode == 2) x = x * two_level(p.g_lo, p.g_hi, i, GLO_BITS, true);          // g^-i
+    st_fr(p.dst + i, x);
+  }
+}
+
+// out[i] = first * base^(i * step_mul)   (table builder)
+__global__ void pow_table_kernel(Fr* out, Fr base, Fr first, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  st_fr(out + i, first * base.pow_u64(i));
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+void ntt_plan(uint32_t L, int r[3], int* npass) {   // tests/ntt_model.py: plan
+  if (L <= 10) { *npass = 1; r[0] = (int)L; return; }
+  if (L <= 18) { *npass = 2; r[0] = (int)(L + 1) / 2; r[1] = (int)L - r[0]; return; }
+  *npass = 3;
+  r[0] = (int)(L + 2) / 3;
+  r[1] = ((int)L - r[0] + 1) / 2;
+  r[2] = (int)L - r[0] - r[1];
+}
+
+static Fr host_omega(uint32_t L, bool inverse) {   // domain.rs:142-145,155
+  Fr g = fr_root_of_unity();
+  for (uint32_t i = L; i < 32; ++i) g = g.sqr();
+  return inverse ? g.inv() : g;
+}
+
+static int build_pow_table(Ctx* c, Fr** out, const Fr& base, const Fr& first, uint32_t count) {
+  HIP_TRY(hipMalloc((void**)out, sizeof(Fr) * (size_t)count));
+  hipLaunchKernelGGL(pow_table_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, *out, base, first, count);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
+int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
+  std::lock_guard<std::mutex> lk(c->table_mu);
+  const uint32_t key = (L << 1) | (inverse ? 1u : 0u);
+  auto it = c->ntt_tables.find(key);
+  if (it != c->ntt_tables.end()) { *out = it->second; return PLONK_OK; }
+  auto* tb = new NttTables();
+  const Fr w = host_omega(L, inverse);
+  const uint32_t lo_n = 1u << (L < (uint32_t)TWLO_BITS ? L : (uint32_t)TWLO_BITS);
+  const uint32_t hi_n = L > (uint32_t)TWLO_BITS ? (1u << (L - TWLO_BITS)) : 1u;
+  const Fr n_inv = Fr::from_u64(1ull << L).inv();
+  int rc;
+  if ((rc = build_pow_table(c, &tb->tw_lo, w, Fr::one(), lo_n))) return rc;
+  if ((rc = build_pow_table(c, &tb->tw_hi, w.pow_u64(1ull << TWLO_BITS), Fr::one(), hi_n))) return rc;
+  if (inverse) {
+    if ((rc = build_pow_table(c, &tb->tw_lo_scaled, w, n_inv, lo_n))) return rc;
+  }
+  if ((rc = build_pow_table(c, &tb->w512, host_omega(9, inverse), Fr::one(), 256))) return rc;
+  // coset tables: forward g^i ; inverse g^-i
+  const Fr g = inverse ? fr_generator().inv() : fr_generator();
+  const uint32_t ghi_n = L > (uint32_t)GLO_BITS ? (1u << (L - GLO_BITS)) : 1u;
+  if ((rc = build_pow_table(c, &tb->g_lo, g, Fr::one(), 1u << GLO_BITS))) return rc;
+  if ((rc = build_pow_table(c, &tb->g_hi, g.pow_u64(1ull << GLO_BITS), Fr::one(), ghi_n))) return rc;
+  tb->n_inv = n_inv;
+  c->ntt_tables[key] = tb;
+  *out = tb;
+  return PLONK_OK;
+}
+
+template <int RLOG>
+static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint32_t nblocks) {
+  constexpr size_t smem = (8 * (1 << TILE_LOG) + 8 * 256) * sizeof(uint32_t);
+  if (transpose) {
+    static bool attr_t = false;
+    if (!attr_t) { (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<RLOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_t = true; }
+    hipLaunchKernelGGL((ntt_pass_kernel<RLOG, true>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
+  } else {
+    static bool attr_n = false;
+    if (!attr_n) { (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<RLOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_n = true; }
+    hipLaunchKernelGGL((ntt_pass_kernel<RLOG, false>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
+  }
+}
+
+static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, uint32_t nblocks) {
+  switch (rlog) {
+    // ntt_plan() only produces radices 5..9 for N >= 2^11
+    case 5: launch_pass<5>(c, p, transpose, nblocks); break;
+    case 6: launch_pass<6>(c, p, transpose, nblocks); break;
+    case 7: launch_pass<7>(c, p, transpose, nblocks); break;
+    case 8: launch_pass<8>(c, p, transpose, nblocks); break;
+    case 9: launch_pass<9>(c, p, transpose, nblocks); break;
+    default: return PLONK_ERR_ARG;
+  }
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
+// Device-resident transform: src (in_len valid elements) -> dst (N elements).
+// src == dst is allowed.  `tmp` must hold N elements (N > 1024 only).
+int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len) {
+  if (L >= 28) return PLONK_ERR_ARG;   // 3 passes of <= 2^9; reference limit is 2^32 (domain.rs:132)
+  const uint64_t N = 1ull << L;
+  if (in_len > N) in_len = N;          // Vec::resize truncation, domain.rs:174
+  NttTables* tb;
+  int rc = ntt_tables(c, L, inverse, &tb);
+  if (rc) return rc;
+  int r[3], np;
+  ntt_plan(L, r, &np);
+  const int post = inverse ? (coset ? 2 : 1) : 0;
+  if (np == 1) {
+    NttSmall s{};
+    s.src = src; s.dst = dst; s.logN = L; s.in_len = in_len;
+    s.pre_coset = (coset && !inverse) ? 1 : 0;
+    s.post_mode = post; s.scale = tb->n_inv;
+    s.tw_lo = tb->tw_lo; s.g_lo = tb->g_lo; s.g_hi = tb->g_hi;
+    hipLaunchKernelGGL(ntt_small_kernel, dim3(1), dim3(NTT_THREADS), 0, c->stream, s);
+    HIP_TRY(hipGetLastError());
+    return PLONK_OK;
+  }
+  const uint64_t R1 = 1ull << r[0];
+  const int rl = r[np - 1];
+  // ---- pass A : src -> tmp (transposed)
+  {
+    NttPass p{};
+    p.src = src; p.dst = tmp; p.logN = L;
+    p.in_rs = N >> r[0]; p.in_hshift = 63; p.in_hs = 0;
+    p.out_rs = 1; p.out_hshift = (uint32_t)rl; p.out_hs = R1; p.out_ls = N >> rl;
+    p.tw_mode = 1; p.tw_shr = 0;
+    p.tw_lo = inverse ? tb->tw_lo_scaled : tb->tw_lo;   // n^-1 folded into pass A's twiddles
+    p.tw_hi = tb->tw_hi;
+    p.in_len = in_len; p.pre_coset = (coset && !inverse) ? 1 : 0;
+    p.post_mode = 0; p.g_lo = tb->g_lo; p.g_hi = tb->g_hi; p.w512 = tb->w512;
+    const uint32_t nb = (uint32_t)((N >> r[0]) >> (TILE_LOG - r[0]));
+    if ((rc = launch_pass_rt(c, r[0], p, true, nb))) return rc;
+  }
+  // ---- pass B : tmp in place
+  if (np == 3) {
+    NttPass p{};
+    p.src = tmp; p.dst = tmp; p.logN = L;
+    p.in_rs = R1; p.in_hshift = (uint32_t)r[0]; p.in_hs = R1 << r[1];
+    p.out_rs = R1; p.out_hshift = (uint32_t)r[0]; p.out_hs = R1 << r[1]; p.out_ls = 1;
+    p.tw_mode = 1; p.tw_shr = (uint32_t)r[0];
+    p.tw_lo = tb->tw_lo; p.tw_hi = tb->tw_hi;
+    p.in_len = N; p.pre_coset = 0; p.post_mode = 0; p.w512 = tb->w512;
+    p.g_lo = tb->g_lo; p.g_hi = tb->g_hi;
+    const uint32_t nb = (uint32_t)((N >> r[1]) >> (TILE_LOG - r[1]));
+    if ((rc = launch_pass_rt(c, r[1], p, false, nb))) return rc;
+  }
+  // ---- pass C : tmp -> dst
+  {
+    NttPass p{};
+    p.src = tmp; p.dst = dst; p.logN = L;
+    p.in_rs = N >> rl; p.in_hshift = 63; p.in_hs = 0;
+    p.out_rs = N >> rl; p.out_hshift = 63; p.out_hs = 0; p.out_ls = 1;
+    p.tw_mode = 0; p.tw_shr = 0; p.tw_lo = tb->tw_lo; p.tw_hi = tb->tw_hi;
+    p.in_len = N; p.pre_coset = 0;
+    p.post_mode = (inverse && coset) ? 2 : 0;   // n^-1 already folded in pass A
+    p.scale = tb->n_inv; p.g_lo = tb->g_lo; p.g_hi = tb->g_hi; p.w512 = tb->w512;
+    const uint32_t nb = (uint32_t)((N >> rl) >> (TILE_LOG - rl));
+    if ((rc = launch_pass_rt(c, rl, p, false, nb))) return rc;
+  }
+  return PLONK_OK;
+}
+
+}  // namespace plonk

@@ -1,0 +1,94 @@
+// Internal declarations shared by the HIP translation units of libplonk_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/plonk_hip.h"
+#include "curve.cuh"
+
+#define HIP_TRY(expr)                                                    \
+  do {                                                                   \
+    hipError_t _e = (expr);                                              \
+    if (_e != hipSuccess) {                                              \
+      plonk::set_last_error(#expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return PLONK_ERR_HIP;                                              \
+    }                                                                    \
+  } while (0)
+
+namespace plonk {
+
+void set_last_error(const char* what, const char* detail, const char* file, int line);
+
+struct NttTables {
+  Fr* tw_lo = nullptr;         // w_N^e, e < 2^min(L,13)
+  Fr* tw_hi = nullptr;         // w_N^(e << 13)
+  Fr* tw_lo_scaled = nullptr;  // n^-1 * w_N^e (inverse only)
+  Fr* w512 = nullptr;          // w_512^e, e < 256
+  Fr* g_lo = nullptr;          // g^i (fwd) or g^-i (inv), i < 1024
+  Fr* g_hi = nullptr;          // g^(i << 10)
+  Fr n_inv;
+};
+
+// MSM geometry: 16-bit signed windows over precomputed 2^(16w) * P_i tables.
+static constexpr int MSM_C = 16;
+static constexpr int MSM_W = 16;
+static constexpr uint32_t MSM_NB = 1u << (MSM_C - 1);   // buckets 1..32768
+
+struct MsmWork {   // per-stream scratch, grown on demand
+  uint64_t cap_m = 0;
+  uint32_t* digits = nullptr;      // W * m
+  uint32_t* entries = nullptr;     // W * m
+  uint32_t* counts = nullptr;      // NB
+  uint32_t* offsets = nullptr;     // NB + 1
+  uint32_t* cursors = nullptr;     // NB
+  uint32_t* slice_off = nullptr;   // NB + 1
+  uint64_t cap_slices = 0;
+  G1* partial = nullptr;           // slices
+  G1* buckets = nullptr;           // NB
+  G1* chunk = nullptr;             // NB / 16
+  uint8_t* result = nullptr;       // 97 B device
+  uint8_t* result_host = nullptr;  // pinned
+  Fr* scalars_stage = nullptr;     // H2D staging for host-pointer API
+  uint64_t cap_stage = 0;
+};
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;         // serialises entry points (reference calls concurrently from rayon)
+  std::mutex table_mu;
+  std::map<uint32_t, NttTables*> ntt_tables;
+  // NTT staging for the host-pointer API
+  Fr* ntt_buf = nullptr;
+  Fr* ntt_tmp = nullptr;
+  uint64_t ntt_cap = 0;
+  // SRS
+  G1Affine* srs_table = nullptr;   // [MSM_W][npoints] affine, 2^(16 w) * P_i
+  uint64_t srs_n = 0;
+  MsmWork msm;
+  // instrumentation: hipEvent pairs around the dominant kernels
+  bool profile = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double acc_ms[8] = {0};
+  uint64_t acc_n[8] = {0};
+};
+
+// ntt.hip
+int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len);
+int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out);
+void ntt_plan(uint32_t L, int r[3], int* npass);
+
+// msm.hip
+int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
+int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, uint8_t* out97_dev);
+int msm_reserve(Ctx* c, uint64_t m);
+
+}  // namespace plonk
+
+struct plonk_ctx {
+  plonk::Ctx c;
+};

@@ -1,0 +1,138 @@
+"""GPU parity: plonk_msm / CommitKey::commit (HIP, through the C-ABI) vs the oracle's
+definition of msm_variable_base (reference src/commitment_scheme/kzg10/key.rs:376-388).
+Bit-exact on the affine coordinates (and therefore on the 48-byte compressed form)."""
+import random
+
+import pytest
+
+from oracle import bls12_381 as E
+
+pytestmark = pytest.mark.gpu
+Q = E.Q
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonk_amd
+    c = plonk_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def srs300():
+    r = random.Random(11)
+    tau, g = r.randrange(1, Q), r.randrange(1, Q)
+    base = E.g1_mul(E.G1_GEN, g)
+    pts, p = [], 1
+    for _ in range(300):
+        pts.append(E.g1_mul(base, p))
+        p = p * tau % Q
+    return pts
+
+
+def test_basic_sizes(ctx, srs300):
+    r = random.Random(1)
+    ctx.srs_load(srs300)
+    for m in (1, 2, 3, 31, 32, 33, 64, 300):
+        sc = [r.randrange(Q) for _ in range(m)]
+        assert ctx.msm(sc) == E.msm_pippenger(srs300, sc), m
+
+
+def test_edge_scalars(ctx, srs300):
+    """Digit-recoding boundaries (16-bit signed windows), 0, 1, q-1."""
+    ctx.srs_load(srs300)
+    edge = [0, 1, 2, Q - 1, Q - 2, 32767, 32768, 32769, 65535, 65536, 65537,
+            (1 << 254) + 12345, (1 << 16) * 32768, (1 << 32) - 1, 0x8000800080008000, 0xFFFFFFFFFFFFFFFF,
+            int("8000" * 15, 16), int("7fff" * 15, 16), int("ffff" * 15, 16) % Q]
+    assert ctx.msm(edge) == E.msm_naive(srs300, edge)
+    for s in edge:
+        assert ctx.msm([s]) == (E.g1_mul(srs300[0], s) if s % Q else None)
+    assert ctx.msm([0] * 50) is None
+    assert ctx.msm([]) is None
+    assert ctx.msm([1] * 300) == E.msm_naive(srs300, [1] * 300)       # one hot bucket
+    assert ctx.msm([5, Q - 5]) == E.msm_naive(srs300, [5, Q - 5])
+
+
+def test_repeated_bases_hit_doubling_branch(ctx):
+    G2 = E.g1_mul(E.G1_GEN, 2)
+    pts = [E.G1_GEN, E.G1_GEN, E.G1_GEN, G2, E.g1_mul(E.G1_GEN, Q - 1)]
+    ctx.srs_load(pts)
+    assert ctx.msm([1, 1, 1]) == E.g1_mul(E.G1_GEN, 3)
+    assert ctx.msm([7, 7, 7, 7]) == E.g1_mul(E.G1_GEN, 35)
+    assert ctx.msm([1, 0, 0, 0, 1]) is None                           # G + (-G)
+    assert ctx.msm([3, 5, 0, 9, 2]) == E.g1_mul(E.G1_GEN, 3 + 5 + 18 - 2)
+
+
+def test_commit_rejects_oversized_polynomial(ctx, srs300):
+    """reference key.rs:816-824 test_commit_rejects_oversized_polynomial."""
+    import plonk_amd
+    ctx.srs_load(srs300[:10])
+    with pytest.raises(plonk_amd.PolynomialDegreeTooLarge):
+        ctx.commit([1] * 11)
+    with pytest.raises(plonk_amd.PolynomialDegreeTooLarge):
+        ctx.msm([1] * 11)
+    assert ctx.commit([1] * 10 + [0, 0]) == E.msm_naive(srs300[:10], [1] * 10)   # trailing zeros trimmed
+
+
+def test_msm_before_srs_load_errors():
+    import plonk_amd
+    c = plonk_amd.Context(0)
+    with pytest.raises(plonk_amd.PlonkError):
+        c.msm([1, 2, 3])
+    c.close()
+
+
+def test_aggregate_flatten_small_kat(ctx):
+    """reference kzg10/proof.rs:120-158: 2G, 3G, 5G with v = 7."""
+    G = E.G1_GEN
+    ctx.srs_load([E.g1_mul(G, 2), E.g1_mul(G, 3), E.g1_mul(G, 5)])
+    assert ctx.msm([1, 7, 49]) == E.g1_mul(G, 2 + 21 + 245)
+
+
+def _gen_srs_dev(ctx, n, tau, g):
+    buf = ctx.alloc(96 * n)
+    ctx.srs_generate_dev(tau, g, n, buf.ptr)
+    return buf
+
+
+def test_generated_srs_matches_oracle_and_msm_4096(ctx):
+    """PublicParameters::setup semantics (srs.rs:61-100): P_i = (g * tau^i) G."""
+    import plonk_amd
+    r = random.Random(3)
+    n = 4096
+    tau, g = r.randrange(1, Q), r.randrange(1, Q)
+    buf = _gen_srs_dev(ctx, n, tau, g)
+    raw = buf.download()
+    pts = [plonk_amd.g1_from_raw97(raw[96 * i:96 * i + 96] + b"\0") for i in range(n)]
+    for i in (0, 1, 2, 77, n - 1):
+        assert pts[i] == E.g1_mul(E.G1_GEN, g * pow(tau, i, Q) % Q)
+    ctx.srs_load_dev(buf.ptr, n)
+    sc = [r.randrange(Q) for _ in range(n)]
+    # sum_i s_i * g tau^i G == (g * sum_i s_i tau^i) G   — closed form, no big MSM oracle needed
+    k = g * sum(s * pow(tau, i, Q) for i, s in enumerate(sc)) % Q
+    assert ctx.msm(sc) == E.g1_mul(E.G1_GEN, k)
+    assert ctx.msm(sc[:1000]) == E.msm_pippenger(pts[:1000], sc[:1000])
+    buf.free()
+
+
+@pytest.mark.parametrize("logm", [16, 20])
+def test_full_size_closed_form(ctx, logm):
+    """BASELINE sizes (2^16, 2^20 gates => m = n + 6): the SRS is [g tau^i]G, so the
+    commitment of f is (g * f(tau)) G — a size-independent exact check."""
+    r = random.Random(logm)
+    n = (1 << logm) + 7
+    tau, g = r.randrange(1, Q), r.randrange(1, Q)
+    buf = _gen_srs_dev(ctx, n, tau, g)
+    ctx.srs_load_dev(buf.ptr, n)
+    buf.free()
+    m = (1 << logm) + 6
+    import plonk_amd
+    sc = [r.randrange(Q) for _ in range(m)]
+    acc, p = 0, 1
+    for s in sc:
+        acc = (acc + s * p) % Q
+        p = p * tau % Q
+    got = ctx.msm(sc)
+    assert got == E.g1_mul(E.G1_GEN, g * acc % Q)
+    assert len(plonk_amd.g1_compress(got)) == 48

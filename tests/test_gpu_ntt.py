@@ -1,0 +1,130 @@
+"""GPU parity: plonk_ntt (HIP, through the C-ABI) vs the oracle restatement of
+EvaluationDomain::{fft,ifft,coset_fft,coset_ifft} (reference src/fft/domain.rs:166-232).
+Bit-exact: values are compared as canonical integers recovered from the Montgomery
+limbs the library returns."""
+import random
+
+import pytest
+
+from oracle.bls12_381 import GENERATOR, Q
+from oracle.fft import EvaluationDomain
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonk_amd
+    c = plonk_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _all_modes(ctx, a, L, in_len):
+    d = EvaluationDomain(1 << L)
+    assert ctx.ntt(a, L) == d.fft(a)
+    assert ctx.ntt(a, L, inverse=True) == d.ifft(a)
+    assert ctx.ntt(a[:in_len], L, coset=True) == d.coset_fft(a[:in_len])
+    assert ctx.ntt(a, L, inverse=True, coset=True) == d.coset_ifft(a)
+
+
+@pytest.mark.parametrize("L", [0, 1, 3, 6, 10])
+def test_small_single_kernel(ctx, L):
+    r = random.Random(100 + L)
+    a = [r.randrange(Q) for _ in range(1 << L)]
+    _all_modes(ctx, a, L, max(1, (1 << L) // 8 + 3) if L >= 4 else 1 << L)
+
+
+@pytest.mark.parametrize("L", [11, 12, 13, 16])
+def test_two_pass(ctx, L):
+    r = random.Random(200 + L)
+    a = [r.randrange(Q) for _ in range(1 << L)]
+    _all_modes(ctx, a, L, (1 << L) // 8 + 3)
+
+
+def test_reference_inputs_i_plus_1(ctx):
+    """reference domain.rs:570-618: 2^12 domain, inputs i+1; ifft(fft(x)) == x."""
+    L = 12
+    a = [i + 1 for i in range(1 << L)]
+    d = EvaluationDomain(1 << L)
+    ev = ctx.ntt(a, L)
+    assert ev == d.fft(a)
+    assert ctx.ntt(ev, L, inverse=True) == a
+
+
+def test_linear_coset_closed_form(ctx):
+    """reference domain.rs:620-636: coset_fft([0,1]) on 2^8 equals 7*w^i; same on 2^16."""
+    for L in (8, 16):
+        d = EvaluationDomain(1 << L)
+        ev = ctx.ntt([0, 1], L, coset=True)
+        cur, exp = GENERATOR, []
+        for _ in range(1 << L):
+            exp.append(cur)
+            cur = cur * d.group_gen % Q
+        assert ev == exp
+
+
+def test_batch_of_five_coset_ffts(ctx):
+    """reference quotient_poly.rs:315-349: 5 polys on 2^12, values idx*n+i+1."""
+    L = 12
+    n = 1 << L
+    d = EvaluationDomain(n)
+    for idx in range(5):
+        poly = [idx * n + i + 1 for i in range(n)]
+        assert ctx.ntt(poly, L, coset=True) == d.coset_fft(poly)
+
+
+def test_truncates_longer_input(ctx):
+    """Vec::resize truncation (domain.rs:174)."""
+    L = 11
+    r = random.Random(5)
+    a = [r.randrange(Q) for _ in range((1 << L) + 100)]
+    assert ctx.ntt(a, L) == EvaluationDomain(1 << L).fft(a[: 1 << L])
+
+
+def test_rejects_bad_log_n(ctx):
+    import plonk_amd
+    with pytest.raises(plonk_amd.PlonkError):
+        ctx.ntt_bytes(b"", 28, False, False, 0)
+
+
+@pytest.mark.parametrize("L", [19, 20])
+def test_three_pass_vs_oracle(ctx, L):
+    r = random.Random(300 + L)
+    N = 1 << L
+    a = [r.randrange(Q) for _ in range(N)]
+    d = EvaluationDomain(N)
+    assert ctx.ntt(a, L) == d.fft(a)
+    il = N // 8 + 3
+    got = ctx.ntt(a[:il], L, coset=True)
+    assert got == d.coset_fft(a[:il])
+    assert ctx.ntt(got, L, inverse=True, coset=True) == a[:il] + [0] * (N - il)
+
+
+@pytest.mark.parametrize("L", [23])
+def test_full_size_properties(ctx, L):
+    """BASELINE quotient-domain size 8n = 2^23 (n = 2^20): size-independent checks.
+    A sparse input has a closed-form spectrum: X[k] = sum_j x_j w^(j k)."""
+    import plonk_amd
+    r = random.Random(23)
+    N = 1 << L
+    d = EvaluationDomain(N)
+    pos = [0, 1, 12345, N // 2 + 7, N - 1]
+    val = [r.randrange(Q) for _ in pos]
+    raw = bytearray(32 * N)
+    mont = plonk_amd.fr_to_bytes_mont(val)
+    for j, p in enumerate(pos):
+        raw[32 * p:32 * p + 32] = mont[32 * j:32 * j + 32]
+    out = ctx.ntt_bytes(bytes(raw), L, False, False, N)
+    ks = [0, 1, 2, 255, 256, 65537, N // 2, N - 1] + [r.randrange(N) for _ in range(40)]
+    for k in ks:
+        exp = sum(v * pow(d.group_gen, p * k, Q) for p, v in zip(pos, val)) % Q
+        assert plonk_amd.fr_from_bytes_mont(out[32 * k:32 * k + 32])[0] == exp
+    back = ctx.ntt_bytes(out, L, True, False, N)
+    assert back == bytes(raw)                          # ifft(fft(x)) == x, bit for bit
+    # coset round trip at full size
+    cf = ctx.ntt_bytes(bytes(raw), L, False, True, N)
+    assert ctx.ntt_bytes(cf, L, True, True, N) == bytes(raw)
+    k = 4242
+    exp = sum(v * pow(GENERATOR, p, Q) * pow(d.group_gen, p * k, Q) for p, v in zip(pos, val)) % Q
+    assert plonk_amd.fr_from_bytes_mont(cf[32 * k:32 * k + 32])[0] == exp
