@@ -99,6 +99,50 @@ int plonk_dev_d2h(plonk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t 
 int plonk_dev_sync(plonk_ctx* ctx);
 void* plonk_ctx_stream(plonk_ctx* ctx); /* hipStream_t the library launches on */
 
+/* ---- device-resident Prover::prove (V3) -------------------------------------------
+ * Replaces prove_inner (src/compiler/prover.rs:415-761) minus witness generation and the
+ * RNG, which stay with the caller (Composer::prove, src/composer.rs:442; BlsScalar::random).
+ * The context must hold the commit key (plonk_srs_load: >= size + 7 points).
+ *
+ * desc.polys: the 15 ProverKey polynomials in coefficient form (Fr Montgomery limbs), order
+ *   q_m q_l q_r q_o q_f q_c q_arith q_range q_logic q_fixed_group_add q_variable_group_add
+ *   s_sigma_1 s_sigma_2 s_sigma_3 s_sigma_4   (src/proof_system/widget.rs:284-313)
+ * desc.vk_commitments: the 15 VerifierKey commitments (48-byte compressed, same order) that
+ *   seed the transcript (widget.rs:218-258); NULL = commit to the polynomials on the GPU as
+ *   Compiler::preprocess does (src/compiler.rs:213-232).
+ * The 8n coset evaluations, sigma evaluations and vanishing inverses (compiler.rs:310-425,
+ * prover.rs:78-100) are rebuilt on the device. */
+typedef struct plonk_prover plonk_prover;
+typedef struct {
+  uint64_t constraints;          /* gate count; domain size = next power of two        */
+  const uint8_t* label;          /* transcript label (Compiler::compile `label`)        */
+  uint64_t label_len;
+  const uint64_t* polys[15];
+  uint64_t poly_len[15];         /* coefficients per polynomial, <= size                */
+  const uint8_t* vk_commitments; /* 15 x 48 bytes or NULL                               */
+} plonk_prover_desc;
+int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out);
+void plonk_prover_destroy(plonk_prover* p);
+int plonk_prover_vk(plonk_prover* p, uint8_t out[15 * 48]);
+uint64_t plonk_prover_size(plonk_prover* p);
+/* diagnostic: read `count` Fr at `offset` of internal array `which` (0 wire polys, 1 z poly,
+ * 2 pi poly, 3 coset evals z|a|b|c|d|pi, 4 quotient, 5 t_low|t_mid|t_high, 6 lin. comb., 7 opening
+ * witness, 8 key coset evals, 9 sigma evals, 10 scratch, 11 evaluations, 12 key polynomials) */
+int plonk_prover_peek(plonk_prover* p, int which, uint64_t offset, uint64_t count, uint64_t* out);
+/* wires: a, b, c, d columns padded to `size` (prover.rs:446-460), Fr Montgomery.
+ * pi_idx/pi_val: sparse public inputs (gate row, value), rows ascending (composer.rs:465-485).
+ * blinders: 14 Fr in the reference's RNG draw order: a0 a1 b0 b1 c0 c1 d0 d1 (prover.rs:154-161),
+ *           z0 z1 z2 (:133-135,503), b12 b13 b14 (:553-555).
+ * proof: 1008 bytes = Proof::to_bytes (src/proof_system/proof.rs:137-162).
+ * PLONK_ERR_UNSAT mirrors Error::CircuitUnsatisfied (quotient_poly.rs:132). */
+int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const uint64_t* pi_idx,
+                       const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
+                       uint8_t proof[1008]);
+/* same with the 4 x size wire columns already resident in HBM (contiguous a|b|c|d) */
+int plonk_prover_prove_dev(plonk_prover* p, const void* wires_dev, const uint64_t* pi_idx,
+                           const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
+                           uint8_t proof[1008]);
+
 /* ---- measurement --------------------------------------------------------------
  * When enabled, every launch of the dominant kernels is bracketed by a hipEvent
  * pair ON THE LIBRARY'S STREAM and accumulated per slot.  Slots:

@@ -42,7 +42,22 @@ EXPORTS = [
     "plonk_srs_load_dev", "plonk_srs_generate_dev", "plonk_dev_alloc", "plonk_dev_free",
     "plonk_dev_h2d", "plonk_dev_d2h", "plonk_dev_sync", "plonk_ctx_stream",
     "plonk_profile_enable", "plonk_profile_read", "plonk_profile_reset",
+    "plonk_prover_create", "plonk_prover_destroy", "plonk_prover_vk", "plonk_prover_size",
+    "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
 ]
+
+POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
+              "q_fixed_group_add", "q_variable_group_add", "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+
+
+class _ProverDesc(ctypes.Structure):
+    _fields_ = [("constraints", ctypes.c_uint64), ("label", ctypes.c_char_p), ("label_len", ctypes.c_uint64),
+                ("polys", ctypes.c_void_p * 15), ("poly_len", ctypes.c_uint64 * 15),
+                ("vk_commitments", ctypes.c_char_p)]
+
+
+class CircuitUnsatisfied(Exception):
+    """Mirrors Error::CircuitUnsatisfied (reference quotient_poly.rs:132)."""
 
 
 class PlonkError(RuntimeError):
@@ -91,6 +106,15 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_profile_enable.argtypes = [vp, ci]
     lib.plonk_profile_read.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.plonk_profile_reset.argtypes = [vp]
+    lib.plonk_prover_create.argtypes = [vp, ctypes.POINTER(_ProverDesc), ctypes.POINTER(vp)]
+    lib.plonk_prover_destroy.argtypes = [vp]
+    lib.plonk_prover_destroy.restype = None
+    lib.plonk_prover_vk.argtypes = [vp, vp]
+    lib.plonk_prover_size.argtypes = [vp]
+    lib.plonk_prover_size.restype = u64
+    lib.plonk_prover_peek.argtypes = [vp, ci, u64, u64, vp]
+    lib.plonk_prover_prove.argtypes = [vp, ctypes.POINTER(vp), vp, vp, u64, vp, vp]
+    lib.plonk_prover_prove_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     _lib = lib
     return lib
 
@@ -178,6 +202,8 @@ class Context:
     def _check(self, rc: int):
         if rc == -3:
             raise PolynomialDegreeTooLarge(rc)
+        if rc == -6:
+            raise CircuitUnsatisfied()
         if rc != PLONK_OK:
             raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
 
@@ -257,3 +283,82 @@ class Context:
         ms, n = ctypes.c_double(), ctypes.c_uint64()
         self._check(self.lib.plonk_profile_read(self.handle, slot, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+
+class Prover:
+    """Device-resident mirror of the reference `Prover` (src/compiler/prover.rs:27-42):
+    built from the 15 ProverKey polynomials + label + constraint count; `prove` takes the
+    padded wire columns, sparse public inputs and the 14 blinders drawn by the caller's RNG
+    (prover.rs:154-161,133-135,553-555) and returns Proof::to_bytes (1008 bytes)."""
+
+    def __init__(self, ctx: Context, constraints: int, label: bytes, polys: dict, vk_commitments: bytes | None = None):
+        self.ctx = ctx
+        desc = _ProverDesc()
+        desc.constraints = constraints
+        desc.label = label
+        desc.label_len = len(label)
+        self._keep = []
+        for k, name in enumerate(POLY_ORDER):
+            coeffs = polys.get(name, [])
+            raw = coeffs if isinstance(coeffs, (bytes, bytearray)) else fr_to_bytes_mont(coeffs)
+            buf = ctypes.create_string_buffer(bytes(raw), max(len(raw), 1))
+            self._keep.append(buf)
+            desc.polys[k] = ctypes.cast(buf, ctypes.c_void_p)
+            desc.poly_len[k] = len(raw) // 32
+        desc.vk_commitments = vk_commitments
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.plonk_prover_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
+        self.handle = h
+        self.size = ctx.lib.plonk_prover_size(h)
+        self._keep = None
+
+    def vk_commitments(self) -> bytes:
+        out = ctypes.create_string_buffer(15 * 48)
+        self.ctx._check(self.ctx.lib.plonk_prover_vk(self.handle, out))
+        return out.raw
+
+    @staticmethod
+    def _pi(public_inputs):
+        items = sorted(public_inputs.items()) if isinstance(public_inputs, dict) else list(public_inputs or [])
+        idx = (ctypes.c_uint64 * max(len(items), 1))(*[i for i, _ in items])
+        val = fr_to_bytes_mont([v for _, v in items])
+        return idx, val, len(items)
+
+    def prove(self, wires, public_inputs, blinders) -> bytes:
+        """wires: 4 sequences of ints (length <= size, zero padded); blinders: 14 ints."""
+        assert len(blinders) == 14
+        n = self.size
+        bufs = []
+        for w in wires:
+            raw = w if isinstance(w, (bytes, bytearray)) else fr_to_bytes_mont(list(w) + [0] * (n - len(w)))
+            assert len(raw) == 32 * n
+            bufs.append(ctypes.create_string_buffer(bytes(raw), len(raw)))
+        arr = (ctypes.c_void_p * 4)(*[ctypes.cast(b, ctypes.c_void_p) for b in bufs])
+        idx, val, cnt = self._pi(public_inputs)
+        proof = ctypes.create_string_buffer(1008)
+        self.ctx._check(self.ctx.lib.plonk_prover_prove(self.handle, arr, idx, val, cnt,
+                                                        fr_to_bytes_mont(blinders), proof))
+        return proof.raw
+
+    def prove_dev(self, wires_ptr: int, public_inputs, blinders_mont: bytes) -> bytes:
+        idx, val, cnt = self._pi(public_inputs)
+        proof = ctypes.create_string_buffer(1008)
+        self.ctx._check(self.ctx.lib.plonk_prover_prove_dev(self.handle, wires_ptr, idx, val, cnt,
+                                                            blinders_mont, proof))
+        return proof.raw
+
+    def peek(self, which: int, offset: int, count: int) -> list[int]:
+        out = ctypes.create_string_buffer(32 * count)
+        self.ctx._check(self.ctx.lib.plonk_prover_peek(self.handle, which, offset, count, out))
+        return fr_from_bytes_mont(out.raw)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.plonk_prover_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,517 @@
+// Device-resident polynomial kernels around the NTT/MSM hot path:
+// everything Prover::prove does between the transforms and the commitments, so that the
+// 8n-sized arrays never leave HBM.
+//
+//   quotient_kernel        quotient_poly::compute point-wise part, reference
+//                          src/proof_system/quotient_poly.rs:160-310 + every widget's
+//                          compute_quotient_i (src/proof_system/widget/**/proverkey.rs)
+//   perm_ratio / scans     Permutation::compute_permutation_vec, src/composer/permutation.rs:213-294
+//   batch_inverse_kernel   util::batch_inversion, src/util.rs:87-117 (zeros stay zero)
+//   eval_kernel            Polynomial::evaluate, src/fft/polynomial.rs:120-137
+//   lincomb_kernel         linearization_poly::compute + compute_aggregate_witness sums,
+//                          src/proof_system/linearization_poly.rs:168-264, key.rs:394-414
+//   ruffini_*              Polynomial::ruffini, src/fft/polynomial.rs:345-367
+// All arithmetic is exact Fr; results are the same field elements as the reference's.
+#include "plonk_internal.hpp"
+#include "poly.hpp"
+
+namespace plonk {
+
+__device__ __forceinline__ Fr ldf(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void stf(Fr* p, const Fr& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ Fr small(uint32_t v, const Fr& one) {   // v * 1 in Montgomery form, v <= 128
+  Fr acc = Fr::zero();
+  Fr p = one;
+  for (uint32_t b = v; b; b >>= 1) {
+    if (b & 1) acc = acc + p;
+    p = p.dbl();
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------
+__global__ void fill_zero_kernel(Fr* p, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stf(p + i, Fr::zero());
+}
+
+// blind_poly_with_blinders (prover.rs:139-152): c[i] -= b_i ; c[n + i] = b_i
+__global__ void blind_kernel(Fr* coeffs, uint64_t n, BlindArgs a) {
+  const int i = threadIdx.x;
+  if (i < a.count) {
+    stf(coeffs + i, ldf(coeffs + i) - a.b[i]);
+    stf(coeffs + n + i, a.b[i]);
+  }
+}
+
+// quotient split blinding (prover.rs:547-574): t (8n coeffs) -> t_low, t_mid, t_high copied out
+// with stride np (+ b_k X^n, - b_{k-1}); t_fourth stays in place at t + 3n with t[3n] -= b14.
+__global__ void split_t_kernel(Fr* __restrict__ t, uint64_t n, uint64_t np, Fr* __restrict__ out, SplitArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int part = blockIdx.y;   // 0..2
+  if (i >= np) return;
+  Fr v = Fr::zero();
+  if (i < n) v = ldf(t + (uint64_t)part * n + i);
+  else if (i == n) v = a.b[part];                   // t_low += b12 X^n, t_mid += b13 X^n, t_high += b14 X^n
+  if (part >= 1 && i == 0) v = v - a.b[part - 1];   // t_mid -= b12, t_high -= b13
+  stf(out + (uint64_t)part * np + i, v);
+  if (part == 0 && i == n + 1) stf(t + 3 * n, ldf(t + 3 * n) - a.b[2]);   // t_fourth -= b14 (nobody reads t[3n])
+}
+
+// highest index with a non-zero coefficient + 1 (Polynomial::from_coefficients_vec trim, polynomial.rs:79)
+__global__ void trimmed_len_kernel(const Fr* __restrict__ p, uint64_t n, unsigned long long* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (!ldf(p + i).is_zero()) atomicMax(out, (unsigned long long)(i + 1));
+}
+
+__global__ void scatter_pi_kernel(Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) stf(dense + idx[i], ldf(val + i));
+}
+
+// ---------------------------------------------------------------------------
+// batch inversion: chunks of 16 per lane, one Fermat inversion per chunk
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) batch_inverse_kernel(Fr* __restrict__ v, uint64_t n) {
+  constexpr int CH = 16;
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * CH;
+  if (base >= n) return;
+  Fr pre[CH];
+  Fr acc = Fr::one();
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    pre[k] = acc;
+    if (base + k < n) {
+      Fr x = ldf(v + base + k);
+      if (!x.is_zero()) acc = acc * x;
+    }
+  }
+  Fr inv = acc.inv();
+#pragma unroll
+  for (int k = CH - 1; k >= 0; --k) {
+    if (base + k < n) {
+      Fr x = ldf(v + base + k);
+      if (!x.is_zero()) {
+        stf(v + base + k, inv * pre[k]);
+        inv = inv * x;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// scans over Fr with op = mul (prefix products) or add (suffix sums), 3 phases
+// ---------------------------------------------------------------------------
+static constexpr int SCAN_T = 256;
+static constexpr int SCAN_E = 8;
+static constexpr int SCAN_BLOCK = SCAN_T * SCAN_E;
+
+template <bool MUL>
+__device__ __forceinline__ Fr sop(const Fr& a, const Fr& b) {
+  if constexpr (MUL) return a * b; else return a + b;
+}
+template <bool MUL>
+__device__ __forceinline__ Fr sid() {
+  if constexpr (MUL) return Fr::one(); else return Fr::zero();
+}
+
+// inclusive scan within blocks of 2048; REV scans from the high index down.
+template <bool MUL, bool REV>
+__global__ void __launch_bounds__(SCAN_T) scan_block_kernel(Fr* __restrict__ data, uint64_t n, Fr* __restrict__ totals) {
+  __shared__ Fr sh[SCAN_T];
+  const int t = threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)t * SCAN_E;
+  Fr v[SCAN_E];
+  Fr acc = sid<MUL>();
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k) {
+    const uint64_t li = base + k;
+    if (li < n) {
+      const uint64_t gi = REV ? (n - 1 - li) : li;
+      acc = sop<MUL>(acc, ldf(data + gi));
+    }
+    v[k] = acc;
+  }
+  sh[t] = acc;
+  __syncthreads();
+  for (int d = 1; d < SCAN_T; d <<= 1) {
+    Fr x = sid<MUL>();
+    const bool take = t >= d;
+    if (take) x = sh[t - d];
+    __syncthreads();
+    if (take) sh[t] = sop<MUL>(x, sh[t]);
+    __syncthreads();
+  }
+  const Fr excl = t ? sh[t - 1] : sid<MUL>();
+  if (t == SCAN_T - 1) stf(totals + blockIdx.x, sh[t]);
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k) {
+    const uint64_t li = base + k;
+    if (li < n) {
+      const uint64_t gi = REV ? (n - 1 - li) : li;
+      stf(data + gi, sop<MUL>(excl, v[k]));
+    }
+  }
+}
+
+// single-block inclusive scan of up to 2048 * 2048 / ... block totals (nb <= SCAN_BLOCK)
+template <bool MUL>
+__global__ void __launch_bounds__(SCAN_T) scan_totals_kernel(Fr* __restrict__ totals, uint32_t nb) {
+  __shared__ Fr sh[SCAN_T];
+  const int t = threadIdx.x;
+  Fr v[SCAN_E];
+  Fr acc = sid<MUL>();
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k) {
+    const uint32_t i = t * SCAN_E + k;
+    if (i < nb) acc = sop<MUL>(acc, ldf(totals + i));
+    v[k] = acc;
+  }
+  sh[t] = acc;
+  __syncthreads();
+  for (int d = 1; d < SCAN_T; d <<= 1) {
+    Fr x = sid<MUL>();
+    const bool take = t >= d;
+    if (take) x = sh[t - d];
+    __syncthreads();
+    if (take) sh[t] = sop<MUL>(x, sh[t]);
+    __syncthreads();
+  }
+  const Fr excl = t ? sh[t - 1] : sid<MUL>();
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k) {
+    const uint32_t i = t * SCAN_E + k;
+    if (i < nb) stf(totals + i, sop<MUL>(excl, v[k]));
+  }
+}
+
+template <bool MUL, bool REV>
+__global__ void __launch_bounds__(SCAN_T) scan_apply_kernel(Fr* __restrict__ data, uint64_t n, const Fr* __restrict__ totals) {
+  if (blockIdx.x == 0) return;
+  const Fr off = ldf(totals + blockIdx.x - 1);
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_E;
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k) {
+    const uint64_t li = base + k;
+    if (li < n) {
+      const uint64_t gi = REV ? (n - 1 - li) : li;
+      stf(data + gi, sop<MUL>(off, ldf(data + gi)));
+    }
+  }
+}
+
+template <bool MUL, bool REV>
+static int scan_inplace(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
+  const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  if (nb > SCAN_BLOCK) return PLONK_ERR_ARG;   // n <= 2^22 * ... (2048 * 2048 elements)
+  hipLaunchKernelGGL((scan_block_kernel<MUL, REV>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals);
+  if (nb > 1) {
+    hipLaunchKernelGGL((scan_totals_kernel<MUL>), dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb);
+    hipLaunchKernelGGL((scan_apply_kernel<MUL, REV>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals);
+  }
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals) { return scan_inplace<true, false>(c, data, n, totals); }
+int scan_suffix_sum(Ctx* c, Fr* data, uint64_t n, Fr* totals) { return scan_inplace<false, true>(c, data, n, totals); }
+
+// ---------------------------------------------------------------------------
+// permutation grand product inputs (permutation.rs:251-294)
+//   s[0] = 1 ; s[i] = num[i-1] (numerators) ; den[i] = denominators[i-1] (inverted later)
+// ---------------------------------------------------------------------------
+__global__ void perm_terms_kernel(PermArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  if (i == 0) {
+    stf(a.num, Fr::one());
+    stf(a.den, Fr::one());
+    return;
+  }
+  const uint64_t r = i - 1;
+  Fr root = ldf(a.tw_lo + (r & ((1ull << a.lobits) - 1)));
+  if (a.use_hi) root = root * ldf(a.tw_hi + (r >> a.lobits));
+  const Fr beta_root = a.beta * root;
+  Fr num = Fr::one(), den = Fr::one();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Fr w = ldf(a.wires[k] + r) + a.gamma;
+    num = num * (w + beta_root * a.ks[k]);
+    den = den * (w + a.beta * ldf(a.sigma[k] + r));
+  }
+  stf(a.num + i, num);
+  stf(a.den + i, den);
+}
+__global__ void mul_arrays_kernel(Fr* __restrict__ a, const Fr* __restrict__ b, uint64_t n, int* zero_flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Fr y = ldf(b + i);
+  if (zero_flag && y.is_zero()) *zero_flag = 1;
+  stf(a + i, ldf(a + i) * y);
+}
+
+// ---------------------------------------------------------------------------
+// quotient numerator / Z_H on the 8n coset (quotient_poly.rs:96-101,160-310)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ Fr delta4(const Fr& f, const Fr& one) {   // f (f-1)(f-2)(f-3)
+  const Fr two = one.dbl();
+  return f * (f - one) * (f - two) * (f - two - one);
+}
+
+__global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q.n8) return;
+  const uint64_t iw = (i + 8) & (q.n8 - 1);           // extended arrays wrap (quotient_poly.rs:61-67)
+  const Fr one = Fr::one();
+  const Fr a = ldf(q.a + i), b = ldf(q.b + i), c = ldf(q.c + i), d = ldf(q.d + i);
+  const Fr z = ldf(q.z + i), z_w = ldf(q.z + iw);
+  Fr t = ldf(q.pi + i);
+  // arithmetic (arithmetic/proverkey.rs:44-71)
+  {
+    Fr s = ldf(q.q_c + i);
+    if (q.has[QS_M]) s = s + a * b * ldf(q.q_m + i);
+    if (q.has[QS_L]) s = s + a * ldf(q.q_l + i);
+    if (q.has[QS_R]) s = s + b * ldf(q.q_r + i);
+    if (q.has[QS_O]) s = s + c * ldf(q.q_o + i);
+    if (q.has[QS_F]) s = s + d * ldf(q.q_f + i);
+    t = t + s * ldf(q.q_arith + i);
+  }
+  const bool need_w = q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR];
+  Fr a_w, b_w, d_w;
+  if (need_w) { a_w = ldf(q.a + iw); b_w = ldf(q.b + iw); d_w = ldf(q.d + iw); }
+  const Fr four = one.dbl().dbl();
+  if (q.has[QS_RANGE]) {   // range/proverkey.rs:32-58
+    const Fr k1 = q.range_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
+    Fr s = delta4(c - four * d, one) + delta4(b - four * c, one) * k1 + delta4(a - four * b, one) * k2 +
+           delta4(d_w - four * a, one) * k3;
+    t = t + s * ldf(q.q_range + i) * q.range_ch;
+  }
+  if (q.has[QS_LOGIC]) {   // logic/proverkey.rs:34-70,108-144
+    const Fr k1 = q.logic_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1, k4 = k3 * k1;
+    const Fr la = a_w - four * a, lb = b_w - four * b, ld = d_w - four * d, w = c;
+    const Fr q_c = ldf(q.q_c + i);
+    const Fr n3 = small(3, one), n9 = small(9, one), n18 = small(18, one), n81 = small(81, one), n83 = small(83, one);
+    const Fr ab = la + lb;
+    const Fr F = w * (w * (four * w - n18 * ab + n81) + n18 * (la.sqr() + lb.sqr()) - n81 * ab + n83);
+    const Fr Ee = n3 * (ab + ld) - F.dbl();
+    const Fr Bb = q_c * (n9 * ld - n3 * ab);
+    Fr s = (w - la * lb) * k3 + delta4(la, one) + delta4(lb, one) * k1 + delta4(ld, one) * k2 + (Bb + Ee) * k4;
+    t = t + ldf(q.q_logic + i) * s * q.logic_ch;
+  }
+  if (q.has[QS_FIXED]) {   // ecc/scalar_mul/fixed_base/proverkey.rs:39-101
+    const Fr k1 = q.fixed_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
+    const Fr x_beta = ldf(q.q_l + i), y_beta = ldf(q.q_r + i), q_c = ldf(q.q_c + i);
+    const Fr bit = d_w - d - d;
+    const Fr bit_cons = bit * (bit - one) * (bit + one);
+    const Fr y_alpha = bit.sqr() * (y_beta - one) + one;
+    const Fr x_alpha = bit * x_beta;
+    const Fr xy_cons = (bit * q_c - c) * k1;
+    const Fr cab_d = c * a * b * q.edwards_d;
+    const Fr x_acc = ((a_w + a_w * cab_d) - (a * y_alpha + b * x_alpha)) * k2;
+    const Fr y_acc = ((b_w - b_w * cab_d) - (b * y_alpha + a * x_alpha)) * k3;
+    t = t + (bit_cons + x_acc + y_acc + xy_cons) * ldf(q.q_fixed + i) * q.fixed_ch;
+  }
+  if (q.has[QS_VAR]) {     // ecc/curve_addition/proverkey.rs:33-77
+    const Fr k1 = q.var_ch.sqr();
+    const Fr x1y2 = d_w;
+    const Fr y1x2 = b * c, y1y2 = b * d, x1x2 = a * c;
+    const Fr xy_cons = a * d - x1y2;
+    const Fr dxy = q.edwards_d * x1y2 * y1x2;
+    const Fr x3c = ((x1y2 + y1x2) - (a_w + a_w * dxy)) * k1;
+    const Fr y3c = ((y1y2 + x1x2) - (b_w - b_w * dxy)) * k1.sqr();
+    t = t + (xy_cons + x3c + y3c) * ldf(q.q_var + i) * q.var_ch;
+  }
+  // permutation (permutation/proverkey.rs:40-125)
+  {
+    const Fr x = ldf(q.linear + i);
+    const Fr bx = q.beta * x;
+    const Fr ag = a + q.gamma, bg = b + q.gamma, cg = c + q.gamma, dg = d + q.gamma;
+    const Fr ident = (ag + bx) * (bg + bx * q.k1) * (cg + bx * q.k2) * (dg + bx * q.k3) * z * q.alpha;
+    const Fr copy = (ag + q.beta * ldf(q.s1 + i)) * (bg + q.beta * ldf(q.s2 + i)) * (cg + q.beta * ldf(q.s3 + i)) *
+                    (dg + q.beta * ldf(q.s4 + i)) * z_w * q.alpha;
+    const Fr l1 = (z - one) * (ldf(q.l1 + i) * q.alpha_sq);
+    t = t + ident - copy + l1;
+  }
+  stf(q.out + i, t * q.vinv[i & 7]);
+}
+
+// L1 numerators on the coset: out[i] = v_h[i & 7] * n_inv  (to be multiplied by 1/(linear[i]-1))
+__global__ void l1_prepare_kernel(const Fr* __restrict__ linear, Fr* __restrict__ out, uint64_t n8) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n8) stf(out + i, ldf(linear + i) - Fr::one());
+}
+__global__ void l1_finish_kernel(Fr* __restrict__ l1, uint64_t n8, L1Args a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n8) stf(l1 + i, ldf(l1 + i) * a.vh[i & 7] * a.n_inv);
+}
+
+// ---------------------------------------------------------------------------
+// polynomial evaluation: partial[b] = sum over the block's coefficients of c_i x^i
+// ---------------------------------------------------------------------------
+static constexpr int EV_T = 256;
+static constexpr int EV_E = 16;
+__global__ void __launch_bounds__(EV_T) eval_kernel(EvalArgs a) {
+  __shared__ Fr sh[EV_T];
+  const EvalItem it = a.items[blockIdx.y];
+  const uint64_t base = ((uint64_t)blockIdx.x * EV_T + threadIdx.x) * EV_E;
+  Fr acc = Fr::zero();
+  if (base < it.len) {
+#pragma unroll
+    for (int k = EV_E - 1; k >= 0; --k) {
+      acc = acc * it.x;
+      if (base + k < it.len) acc = acc + ldf(it.poly + base + k);
+    }
+    acc = acc * it.x.pow_u64(base);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = EV_T / 2; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) stf(a.partial + (uint64_t)blockIdx.y * a.max_blocks + blockIdx.x, sh[0]);
+}
+__global__ void __launch_bounds__(EV_T) eval_final_kernel(const Fr* __restrict__ partial, uint32_t max_blocks, uint32_t nblocks,
+                                                          Fr* __restrict__ out) {
+  __shared__ Fr sh[EV_T];
+  Fr acc = Fr::zero();
+  for (uint32_t k = threadIdx.x; k < nblocks; k += EV_T) acc = acc + ldf(partial + (uint64_t)blockIdx.x * max_blocks + k);
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = EV_T / 2; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) stf(out + blockIdx.x, sh[0]);
+}
+
+// out[i] = sum_k s_k * P_k[i]  (+ constant at i == 0)
+__global__ void lincomb_kernel(LinCombArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.len) return;
+  Fr acc = (i == 0) ? a.constant : Fr::zero();
+  for (int k = 0; k < a.count; ++k)
+    if (i < a.t[k].len) acc = acc + a.t[k].s * ldf(a.t[k].p + i);
+  stf(a.out + i, acc);
+}
+
+// ruffini: q_i = z^-(i+1) * sum_{j > i} c_j z^j
+//   step 1: d_j = c_j z^j ; step 2: suffix sums ; step 3: q_i = S_{i+1} * zinv^(i+1)
+__global__ void mul_powers_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n, Fr x, uint64_t src_off,
+                                  uint64_t exp_off) {
+  constexpr int CH = 8;
+  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * CH;
+  if (base >= n) return;
+  Fr p = x.pow_u64(base + exp_off);
+#pragma unroll
+  for (int k = 0; k < CH; ++k) {
+    if (base + k < n) {
+      stf(dst + base + k, ldf(src + base + k + src_off) * p);
+      p = p * x;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+static inline dim3 grid1(uint64_t n, int t) { return dim3((uint32_t)((n + t - 1) / t)); }
+
+int poly_fill_zero(Ctx* c, Fr* p, uint64_t n) {
+  if (!n) return PLONK_OK;
+  hipLaunchKernelGGL(fill_zero_kernel, grid1(n, 256), dim3(256), 0, c->stream, p, n);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_blind(Ctx* c, Fr* coeffs, uint64_t n, const BlindArgs& a) {
+  hipLaunchKernelGGL(blind_kernel, dim3(1), dim3(64), 0, c->stream, coeffs, n, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_split_t(Ctx* c, Fr* t, uint64_t n, uint64_t np, Fr* out, const SplitArgs& a) {
+  hipLaunchKernelGGL(split_t_kernel, dim3((uint32_t)((np + 255) / 256), 3), dim3(256), 0, c->stream, t, n, np, out, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_trimmed_len(Ctx* c, const Fr* p, uint64_t n, unsigned long long* out_dev) {
+  HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(trimmed_len_kernel, grid1(n, 256), dim3(256), 0, c->stream, p, n, out_dev);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_scatter_pi(Ctx* c, Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count) {
+  if (!count) return PLONK_OK;
+  hipLaunchKernelGGL(scatter_pi_kernel, grid1(count, 256), dim3(256), 0, c->stream, dense, idx, val, count);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n) {
+  hipLaunchKernelGGL(batch_inverse_kernel, grid1((n + 15) / 16, 128), dim3(128), 0, c->stream, v, n);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_perm_terms(Ctx* c, const PermArgs& a) {
+  hipLaunchKernelGGL(perm_terms_kernel, grid1(a.n, 128), dim3(128), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag) {
+  hipLaunchKernelGGL(mul_arrays_kernel, grid1(n, 256), dim3(256), 0, c->stream, a, b, n, zero_flag);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_quotient(Ctx* c, const QuotientArgs& q) {
+  prof_begin(c, 3);
+  hipLaunchKernelGGL(quotient_kernel, grid1(q.n8, 128), dim3(128), 0, c->stream, q);
+  prof_end(c, 3);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a) {
+  hipLaunchKernelGGL(l1_prepare_kernel, grid1(n8, 256), dim3(256), 0, c->stream, linear, l1, n8);
+  int rc = poly_batch_inverse(c, l1, n8);
+  if (rc) return rc;
+  hipLaunchKernelGGL(l1_finish_kernel, grid1(n8, 256), dim3(256), 0, c->stream, l1, n8, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev) {
+  const uint32_t nb = (uint32_t)((max_len + (uint64_t)EV_T * EV_E - 1) / ((uint64_t)EV_T * EV_E));
+  if (nb > a.max_blocks) return PLONK_ERR_ARG;
+  hipLaunchKernelGGL(eval_kernel, dim3(nb, count), dim3(EV_T), 0, c->stream, a);
+  hipLaunchKernelGGL(eval_final_kernel, dim3(count), dim3(EV_T), 0, c->stream, a.partial, a.max_blocks, nb, out_dev);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_lincomb(Ctx* c, const LinCombArgs& a) {
+  hipLaunchKernelGGL(lincomb_kernel, grid1(a.len, 256), dim3(256), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+// quotient of src[0..len) by (X - z) -> dst[0..len-1); dst[len-1] = 0.  scratch: len Fr + totals.
+int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, const Fr& zinv, Fr* scratch, Fr* totals) {
+  hipLaunchKernelGGL(mul_powers_kernel, grid1((len + 7) / 8, 128), dim3(128), 0, c->stream, src, scratch, len, z, 0, 0);
+  int rc = scan_suffix_sum(c, scratch, len, totals);
+  if (rc) return rc;
+  // q_i = S_{i+1} * zinv^(i+1), i < len - 1
+  hipLaunchKernelGGL(mul_powers_kernel, grid1((len - 1 + 7) / 8, 128), dim3(128), 0, c->stream, scratch, dst, len - 1, zinv,
+                     1, 1);
+  rc = poly_fill_zero(c, dst + (len - 1), 1);
+  HIP_TRY(hipGetLastError());
+  return rc;
+}
+
+}  // namespace plonk

@@ -1,0 +1,87 @@
+// Argument blocks + launchers of poly.hip (device-resident polynomial kernels).
+#pragma once
+#include "plonk_internal.hpp"
+
+namespace plonk {
+
+enum { QS_M = 0, QS_L, QS_R, QS_O, QS_F, QS_C, QS_ARITH, QS_RANGE, QS_LOGIC, QS_FIXED, QS_VAR, QS_COUNT };
+
+struct BlindArgs {
+  int count;
+  Fr b[3];
+};
+struct SplitArgs {
+  Fr b[3];          // b12, b13, b14 (prover.rs:553-555)
+  uint64_t len4;    // coefficients of t beyond 3n that belong to t_fourth
+};
+struct PermArgs {
+  uint64_t n;
+  const Fr* wires[4];
+  const Fr* sigma[4];   // sigma_evaluations over the n-domain (prover.rs:95-100)
+  Fr beta, gamma;
+  Fr ks[4];             // 1, K1, K2, K3
+  const Fr* tw_lo;      // w_n^i two-level table (forward NTT tables of log n)
+  const Fr* tw_hi;
+  uint32_t lobits;
+  int use_hi;
+  Fr* num;
+  Fr* den;
+};
+struct QuotientArgs {
+  uint64_t n8;
+  const Fr *a, *b, *c, *d, *z, *pi;
+  const Fr *q_m, *q_l, *q_r, *q_o, *q_f, *q_c, *q_arith, *q_range, *q_logic, *q_fixed, *q_var;
+  const Fr *s1, *s2, *s3, *s4, *linear, *l1;
+  bool has[QS_COUNT];   // selector polynomial is not identically zero
+  Fr alpha, alpha_sq, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch;
+  Fr k1, k2, k3, edwards_d;
+  Fr vinv[8];           // vanishing_coset_inverses (prover.rs:78-91)
+  Fr* out;
+};
+struct L1Args {
+  Fr vh[8];
+  Fr n_inv;
+};
+struct EvalItem {
+  const Fr* poly;
+  uint64_t len;
+  Fr x;
+};
+struct EvalArgs {
+  EvalItem items[16];
+  Fr* partial;
+  uint32_t max_blocks;
+};
+struct LinTerm {
+  const Fr* p;
+  uint64_t len;
+  Fr s;
+};
+struct LinCombArgs {
+  LinTerm t[24];
+  int count;
+  uint64_t len;
+  Fr constant;
+  Fr* out;
+};
+
+void prof_begin(Ctx* c, int slot);
+void prof_end(Ctx* c, int slot);
+
+int poly_fill_zero(Ctx* c, Fr* p, uint64_t n);
+int poly_blind(Ctx* c, Fr* coeffs, uint64_t n, const BlindArgs& a);
+int poly_split_t(Ctx* c, Fr* t, uint64_t n, uint64_t np, Fr* out, const SplitArgs& a);
+int poly_trimmed_len(Ctx* c, const Fr* p, uint64_t n, unsigned long long* out_dev);
+int poly_scatter_pi(Ctx* c, Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count);
+int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n);
+int poly_perm_terms(Ctx* c, const PermArgs& a);
+int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag);
+int poly_quotient(Ctx* c, const QuotientArgs& q);
+int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a);
+int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev);
+int poly_lincomb(Ctx* c, const LinCombArgs& a);
+int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, const Fr& zinv, Fr* scratch, Fr* totals);
+int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals);
+int scan_suffix_sum(Ctx* c, Fr* data, uint64_t n, Fr* totals);
+
+}  // namespace plonk

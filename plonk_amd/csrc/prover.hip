@@ -1,0 +1,633 @@
+// Device-resident Prover::prove (V3) around the NTT / MSM kernels.
+//
+// Host driver restating reference src/compiler/prover.rs:415-761 (prove_inner),
+// Prover::new (:53-115) and the parts of Compiler::preprocess that derive cached
+// proving state from the ProverKey polynomials (src/compiler.rs:310-425).  The host
+// only runs the Fiat-Shamir transcript and O(1) scalar algebra; every O(n) step is a
+// kernel on arrays that stay in HBM (ntt.hip, msm.hip, poly.hip).  Witness generation
+// (Composer::prove, composer.rs:442) and the RNG stay with the caller: the prover takes
+// the padded wire columns and the 11 blinding scalars in the reference's draw order.
+#include <cstring>
+#include <string>
+
+#include "poly.hpp"
+#include "transcript.hpp"
+
+namespace plonk {
+
+enum PolyId {
+  P_QM = 0, P_QL, P_QR, P_QO, P_QF, P_QC, P_QARITH, P_QRANGE, P_QLOGIC, P_QFIXED, P_QVAR,
+  P_S1, P_S2, P_S3, P_S4, P_COUNT
+};
+// transcript labels in VerifierKey::seed_transcript order (widget.rs:229-254)
+static const int VK_ORDER[15] = {P_QM, P_QL, P_QR, P_QO, P_QC, P_QF, P_QARITH, P_QRANGE, P_QLOGIC,
+                                 P_QVAR, P_QFIXED, P_S1, P_S2, P_S3, P_S4};
+static const char* VK_LABEL[15] = {"q_m", "q_l", "q_r", "q_o", "q_c", "q_f", "q_arith", "q_range", "q_logic",
+                                   "q_variable_group_add", "q_fixed_group_add",
+                                   "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"};
+
+struct Prover {
+  Ctx* c = nullptr;
+  uint64_t n = 0, n8 = 0, np = 0, constraints = 0;
+  uint32_t logn = 0;
+  std::string label;
+  uint8_t vk[15][48];              // compressed commitments in PolyId order
+  Fr* polys = nullptr;             // [P_COUNT][np] coefficient form
+  uint64_t poly_len[P_COUNT] = {0};
+  Fr* evals8 = nullptr;            // [P_COUNT + 2][n8]: coset evals of the 15 polys, linear, l1
+  Fr* sigma_n = nullptr;           // [4][n] sigma evaluations over the proving domain
+  Fr vinv[8];
+  bool has[QS_COUNT];
+  // per-proof work buffers
+  Fr* wires = nullptr;             // [4][n] evaluations (device copy)
+  Fr* wpoly = nullptr;             // [4][np] blinded coefficient polys a, b, c, d
+  Fr* zpoly = nullptr;             // [np]
+  Fr* pipoly = nullptr;            // [np]
+  Fr* cos = nullptr;               // [6][n8] coset evals of z, a, b, c, d, pi
+  Fr* tbuf = nullptr;              // [n8] quotient evals -> coefficients
+  Fr* tmp8 = nullptr;              // [n8] NTT scratch
+  Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
+  Fr* agg = nullptr;               // [np] linear combination
+  Fr* wit = nullptr;               // [np] opening witness polynomial
+  Fr* scratch = nullptr;           // [2 * np] (perm num / den, ruffini scratch)
+  Fr* totals = nullptr;            // scan block totals
+  Fr* evpart = nullptr;            // eval partials
+  Fr* evout = nullptr;             // 16 evaluations
+  uint8_t* res = nullptr;          // 16 x 128 B MSM results (device)
+  uint8_t* res_host = nullptr;     // pinned mirror
+  Fr* ev_host = nullptr;           // pinned 16 Fr
+  unsigned long long* len_dev = nullptr;
+  unsigned long long* len_host = nullptr;
+  int* flag_dev = nullptr;
+  int* flag_host = nullptr;
+  uint64_t* pi_idx_dev = nullptr;
+  Fr* pi_val_dev = nullptr;
+  uint64_t pi_cap = 0;
+  uint32_t ev_max_blocks = 0;
+};
+
+// ---- host helpers -------------------------------------------------------------------
+static Fr omega_of(uint32_t L) {
+  Fr g = fr_root_of_unity();
+  for (uint32_t i = L; i < 32; ++i) g = g.sqr();
+  return g;
+}
+static Fr fr_small(uint64_t v) { return Fr::from_u64(v); }
+
+// G1Affine::to_bytes: 48-byte BE x, flags 0x80 | 0x40 inf | 0x20 y > -y  (commitment.rs:46-57)
+static void g1_compress97(const uint8_t in[97], uint8_t out[48]) {
+  if (in[96]) {
+    memset(out, 0, 48);
+    out[0] = 0xC0;
+    return;
+  }
+  Fp x, y;
+  memcpy(x.l, in, 48);
+  memcpy(y.l, in + 48, 48);
+  const Fp xc = x.from_mont(), yc = y.from_mont(), nyc = y.neg().from_mont();
+  for (int i = 0; i < 12; ++i) {
+    const uint32_t w = xc.l[11 - i];
+    out[4 * i] = (uint8_t)(w >> 24); out[4 * i + 1] = (uint8_t)(w >> 16);
+    out[4 * i + 2] = (uint8_t)(w >> 8); out[4 * i + 3] = (uint8_t)w;
+  }
+  bool greater = false;   // y > -y lexicographically (as integers)
+  for (int i = 11; i >= 0; --i) {
+    if (yc.l[i] != nyc.l[i]) { greater = yc.l[i] > nyc.l[i]; break; }
+  }
+  out[0] |= 0x80;
+  if (greater) out[0] |= 0x20;
+}
+
+static Fr delta_h(const Fr& f) {   // f (f-1)(f-2)(f-3)
+  const Fr one = Fr::one();
+  return f * (f - one) * (f - fr_small(2)) * (f - fr_small(3));
+}
+
+struct Evals {
+  Fr a, b, c, d, a_w, b_w, d_w, q_arith, q_c, q_l, q_r, s1, s2, s3, z;
+};
+
+// widget identities at the evaluation point (the scalar factors of compute_linearization)
+static Fr range_identity(const Fr& ch, const Evals& e) {            // range/proverkey.rs:60-85
+  const Fr four = fr_small(4);
+  const Fr k1 = ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
+  return delta_h(e.c - four * e.d) + delta_h(e.b - four * e.c) * k1 + delta_h(e.a - four * e.b) * k2 +
+         delta_h(e.d_w - four * e.a) * k3;
+}
+static Fr logic_identity(const Fr& ch, const Evals& e) {            // logic/proverkey.rs:72-144
+  const Fr four = fr_small(4);
+  const Fr k1 = ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1, k4 = k3 * k1;
+  const Fr a = e.a_w - four * e.a, b = e.b_w - four * e.b, d = e.d_w - four * e.d, w = e.c;
+  const Fr ab = a + b;
+  const Fr F = w * (w * (four * w - fr_small(18) * ab + fr_small(81)) + fr_small(18) * (a.sqr() + b.sqr()) -
+                    fr_small(81) * ab + fr_small(83));
+  const Fr Ee = fr_small(3) * (ab + d) - F.dbl();
+  const Fr Bb = e.q_c * (fr_small(9) * d - fr_small(3) * ab);
+  return delta_h(a) + delta_h(b) * k1 + delta_h(d) * k2 + (w - a * b) * k3 + (Bb + Ee) * k4;
+}
+static Fr fixed_identity(const Fr& ch, const Evals& e, const Fr& ed) {   // fixed_base/proverkey.rs:103-159
+  const Fr one = Fr::one();
+  const Fr k1 = ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
+  const Fr bit = e.d_w - e.d - e.d;
+  const Fr bit_cons = bit * (bit - one) * (bit + one);
+  const Fr y_alpha = bit.sqr() * (e.q_r - one) + one;
+  const Fr x_alpha = e.q_l * bit;
+  const Fr xy_cons = (bit * e.q_c - e.c) * k1;
+  const Fr cab = e.c * e.a * e.b * ed;
+  const Fr x_acc = ((e.a_w + e.a_w * cab) - (x_alpha * e.b + y_alpha * e.a)) * k2;
+  const Fr y_acc = ((e.b_w - e.b_w * cab) - (x_alpha * e.a + y_alpha * e.b)) * k3;
+  return bit_cons + x_acc + y_acc + xy_cons;
+}
+static Fr var_identity(const Fr& ch, const Evals& e, const Fr& ed) {     // curve_addition/proverkey.rs:79-120
+  const Fr k1 = ch.sqr();
+  const Fr x1y2 = e.d_w, y1x2 = e.b * e.c, y1y2 = e.b * e.d, x1x2 = e.a * e.c;
+  const Fr dxy = ed * x1y2 * y1x2;
+  return (e.a * e.d - x1y2) + ((x1y2 + y1x2) - (e.a_w + e.a_w * dxy)) * k1 +
+         ((y1y2 + x1x2) - (e.b_w - e.b_w * dxy)) * k1.sqr();
+}
+
+#define PTRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) {
+  if (m > p->c->srs_n) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
+  return msm_device(p->c, scalars, m, p->res + 128 * slot);
+}
+static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48]) {
+  Ctx* c = p->c;
+  HIP_TRY(hipMemcpyAsync(p->res_host + 128 * first, p->res + 128 * first, 128 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < count; ++i) g1_compress97(p->res_host + 128 * (first + i), out48[i]);
+  return PLONK_OK;
+}
+
+static void prover_free(Prover* p) {
+  if (!p) return;
+  void* bufs[] = {p->polys, p->evals8, p->sigma_n, p->wires, p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tmp8,
+                  p->tparts, p->agg, p->wit, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
+                  p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (p->res_host) (void)hipHostFree(p->res_host);
+  if (p->ev_host) (void)hipHostFree(p->ev_host);
+  if (p->len_host) (void)hipHostFree(p->len_host);
+  if (p->flag_host) (void)hipHostFree(p->flag_host);
+  delete p;
+}
+
+static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
+  if (!d || d->constraints == 0) return PLONK_ERR_ARG;
+  Prover* p = new Prover();
+  p->c = c;
+  p->constraints = d->constraints;
+  uint64_t n = 1;
+  uint32_t L = 0;
+  while (n < d->constraints) { n <<= 1; ++L; }   // constraints.next_power_of_two() (compiler.rs:141)
+  if (L + 3 >= 28) { delete p; return PLONK_ERR_ARG; }
+  p->n = n; p->logn = L; p->n8 = 8 * n; p->np = n + 8;
+  p->label.assign((const char*)d->label, d->label_len);
+  const uint64_t np = p->np, n8 = p->n8;
+#define ALLOC(ptr, count) do { hipError_t _e = hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)); \
+    if (_e != hipSuccess) { set_last_error("hipMalloc " #ptr, hipGetErrorString(_e), __FILE__, __LINE__); prover_free(p); return PLONK_ERR_HIP; } } while (0)
+  ALLOC(p->polys, P_COUNT * np);
+  ALLOC(p->evals8, (P_COUNT + 2) * n8);
+  ALLOC(p->sigma_n, 4 * n);
+  ALLOC(p->wires, 4 * n);
+  ALLOC(p->wpoly, 4 * np);
+  ALLOC(p->zpoly, np);
+  ALLOC(p->pipoly, np);
+  ALLOC(p->cos, 6 * n8);
+  ALLOC(p->tbuf, n8);
+  ALLOC(p->tmp8, n8);
+  ALLOC(p->tparts, 3 * np);
+  ALLOC(p->agg, np);
+  ALLOC(p->wit, np);
+  ALLOC(p->scratch, 2 * np);
+  ALLOC(p->totals, 4096);
+  p->ev_max_blocks = (uint32_t)((np + 4095) / 4096);
+  ALLOC(p->evpart, 16 * (uint64_t)p->ev_max_blocks);
+  ALLOC(p->evout, 16);
+  ALLOC(p->res, 16 * 128);
+  ALLOC(p->len_dev, 1);
+  ALLOC(p->flag_dev, 1);
+#undef ALLOC
+  HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * 128, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&p->ev_host, 16 * sizeof(Fr), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&p->len_host, sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&p->flag_host, sizeof(int), hipHostMallocDefault));
+
+  // ---- ProverKey polynomials (coefficient form, trailing zeros ignored)
+  PTRY(poly_fill_zero(c, p->polys, P_COUNT * np));
+  for (int k = 0; k < P_COUNT; ++k) {
+    uint64_t len = d->poly_len[k];
+    if (len > n) { prover_free(p); return PLONK_ERR_ARG; }
+    if (len) HIP_TRY(hipMemcpyAsync(p->polys + k * np, d->polys[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c->stream));
+    // Polynomial::from_coefficients_vec trim (polynomial.rs:79): highest non-zero coefficient
+    const Fr* hp = (const Fr*)d->polys[k];
+    while (len && hp[len - 1].is_zero()) --len;
+    p->poly_len[k] = len;
+  }
+  for (int s = 0; s < QS_COUNT; ++s) p->has[s] = p->poly_len[s] != 0;   // PolyId 0..10 == QS_*
+
+  // ---- cached evaluations: 16 coset FFTs on 8n (compiler.rs:312-377) ...
+  for (int k = 0; k < P_COUNT; ++k)
+    PTRY(ntt_device(c, p->polys + k * np, p->evals8 + k * n8, p->tmp8, L + 3, false, true, p->poly_len[k]));
+  {
+    const Fr lin[2] = {Fr::zero(), Fr::one()};
+    HIP_TRY(hipMemcpyAsync(p->scratch, lin, sizeof lin, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    PTRY(ntt_device(c, p->scratch, p->evals8 + P_COUNT * n8, p->tmp8, L + 3, false, true, 2));
+  }
+  // ... 4 sigma FFTs on n (prover.rs:95-100)
+  for (int k = 0; k < 4; ++k)
+    PTRY(ntt_device(c, p->polys + (P_S1 + k) * np, p->sigma_n + k * n, p->tmp8, L, false, false, p->poly_len[P_S1 + k]));
+  // ... vanishing polynomial over the coset: 8 distinct values g^n * w8^i - 1 (domain.rs:338-351) and
+  // their inverses (prover.rs:78-91); L1 over the coset (quotient_poly.rs:266-284)
+  L1Args l1a;
+  {
+    Fr point = fr_generator().pow_u64(n);
+    const Fr step = omega_of(L + 3).pow_u64(n);
+    for (int i = 0; i < 8; ++i) {
+      l1a.vh[i] = point - Fr::one();
+      p->vinv[i] = l1a.vh[i].inv();
+      point = point * step;
+    }
+    l1a.n_inv = Fr::from_u64(n).inv();
+  }
+  PTRY(poly_l1(c, p->evals8 + P_COUNT * n8, p->evals8 + (P_COUNT + 1) * n8, n8, l1a));
+
+  // ---- verifier-key commitments for transcript seeding
+  if (d->vk_commitments) {
+    memcpy(p->vk, d->vk_commitments, 15 * 48);
+  } else {   // Compiler::preprocess commits (compiler.rs:213-232); zero polynomial -> identity
+    for (int k = 0; k < P_COUNT; ++k) PTRY(msm_to(p, p->polys + k * np, p->poly_len[k], k));
+    PTRY(fetch_commitments(p, 0, 15, p->vk));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = p;
+  return PLONK_OK;
+}
+
+static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
+                        const Fr* bl, uint8_t proof[1008]) {
+  Ctx* c = p->c;
+  const uint64_t n = p->n, n8 = p->n8, np = p->np;
+  const uint32_t L = p->logn;
+  NttTables* tbn;
+  PTRY(ntt_tables(c, L, false, &tbn));
+  const Fr omega = omega_of(L);
+
+  // transcript_for_version(V3) = Transcript::base_v3 (transcript.rs:131-145, widget.rs:218-258)
+  Transcript tr((const uint8_t*)p->label.data(), p->label.size());
+  tr.circuit_domain_sep(p->constraints);
+  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[VK_ORDER[k]]);
+  tr.circuit_domain_sep(p->constraints);   // vk.n == constraints (compiler.rs:279)
+  for (uint64_t i = 0; i < pi_count; ++i) tr.append_scalar("pi", pi_val[i]);   // prover.rs:440-442
+
+  uint8_t comm[11][48];
+  // ---- round 1 (prover.rs:444-479)
+  for (int k = 0; k < 4; ++k) {
+    Fr* wp = p->wpoly + k * np;
+    PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
+    BlindArgs ba;
+    ba.count = 2;
+    ba.b[0] = bl[2 * k];
+    ba.b[1] = bl[2 * k + 1];
+    PTRY(poly_fill_zero(c, wp + n, np - n));
+    PTRY(poly_blind(c, wp, n, ba));
+  }
+  for (int k = 0; k < 4; ++k) PTRY(msm_to(p, p->wpoly + k * np, n + 2, k));
+  PTRY(fetch_commitments(p, 0, 4, comm));
+  tr.append_commitment("a_comm", comm[0]);
+  tr.append_commitment("b_comm", comm[1]);
+  tr.append_commitment("c_comm", comm[2]);
+  tr.append_commitment("d_comm", comm[3]);
+
+  // ---- round 2 (prover.rs:481-505)
+  const Fr beta = tr.challenge_scalar("beta");
+  tr.append_scalar("beta", beta);
+  const Fr gamma = tr.challenge_scalar("gamma");
+  {
+    PermArgs pa;
+    pa.n = n;
+    for (int k = 0; k < 4; ++k) { pa.wires[k] = wires_dev + k * n; pa.sigma[k] = p->sigma_n + k * n; }
+    pa.beta = beta; pa.gamma = gamma;
+    pa.ks[0] = Fr::one(); pa.ks[1] = fr_small(7); pa.ks[2] = fr_small(13); pa.ks[3] = fr_small(17);
+    pa.tw_lo = tbn->tw_lo; pa.tw_hi = tbn->tw_hi; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
+    pa.num = p->scratch; pa.den = p->scratch + np;
+    HIP_TRY(hipMemsetAsync(p->flag_dev, 0, sizeof(int), c->stream));
+    PTRY(poly_perm_terms(c, pa));
+    PTRY(poly_batch_inverse(c, pa.den, n));
+    PTRY(poly_mul_arrays(c, pa.num, pa.den, n, p->flag_dev));
+    PTRY(scan_prefix_product(c, pa.num, n, p->totals));
+    PTRY(ntt_device(c, pa.num, p->zpoly, p->tmp8, L, true, false, n));
+    BlindArgs ba;
+    ba.count = 3;
+    ba.b[0] = bl[8]; ba.b[1] = bl[9]; ba.b[2] = bl[10];
+    PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
+    PTRY(poly_blind(c, p->zpoly, n, ba));
+  }
+  PTRY(msm_to(p, p->zpoly, n + 3, 4));
+  PTRY(fetch_commitments(p, 4, 1, comm + 4));
+  tr.append_commitment("z_comm", comm[4]);
+
+  // ---- round 3 (prover.rs:507-589)
+  const Fr alpha = tr.challenge_scalar("alpha");
+  const Fr range_ch = tr.challenge_scalar("range separation challenge");
+  const Fr logic_ch = tr.challenge_scalar("logic separation challenge");
+  const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
+  const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
+  const Fr edwards_d = (fr_small(10240) * fr_small(10241).inv()).neg();   // dusk_jubjub::EDWARDS_D
+  // public-input polynomial (prover.rs:520-521)
+  PTRY(poly_fill_zero(c, p->pipoly, np));
+  uint64_t pi_len = 0;
+  if (pi_count) {
+    if (pi_count > p->pi_cap) {
+      if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); }
+      HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
+      HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
+      p->pi_cap = pi_count;
+    }
+    for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return PLONK_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
+    PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
+    PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8, L, true, false, n));
+    pi_len = n;
+  }
+  // quotient (quotient_poly.rs:20-137): 6 coset FFTs on 8n, point-wise pass, coset iFFT
+  {
+    const Fr* srcs[6] = {p->zpoly, p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np, p->pipoly};
+    const uint64_t lens[6] = {n + 3, n + 2, n + 2, n + 2, n + 2, pi_len};
+    for (int k = 0; k < 6; ++k) PTRY(ntt_device(c, srcs[k], p->cos + k * n8, p->tmp8, L + 3, false, true, lens[k]));
+    QuotientArgs q;
+    q.n8 = n8;
+    q.z = p->cos; q.a = p->cos + n8; q.b = p->cos + 2 * n8; q.c = p->cos + 3 * n8; q.d = p->cos + 4 * n8; q.pi = p->cos + 5 * n8;
+    const Fr* e = p->evals8;
+    q.q_m = e + P_QM * n8; q.q_l = e + P_QL * n8; q.q_r = e + P_QR * n8; q.q_o = e + P_QO * n8; q.q_f = e + P_QF * n8;
+    q.q_c = e + P_QC * n8; q.q_arith = e + P_QARITH * n8; q.q_range = e + P_QRANGE * n8; q.q_logic = e + P_QLOGIC * n8;
+    q.q_fixed = e + P_QFIXED * n8; q.q_var = e + P_QVAR * n8;
+    q.s1 = e + P_S1 * n8; q.s2 = e + P_S2 * n8; q.s3 = e + P_S3 * n8; q.s4 = e + P_S4 * n8;
+    q.linear = e + P_COUNT * n8; q.l1 = e + (P_COUNT + 1) * n8;
+    for (int s = 0; s < QS_COUNT; ++s) q.has[s] = p->has[s];
+    q.alpha = alpha; q.alpha_sq = alpha.sqr(); q.beta = beta; q.gamma = gamma;
+    q.range_ch = range_ch; q.logic_ch = logic_ch; q.fixed_ch = fixed_ch; q.var_ch = var_ch;
+    q.k1 = fr_small(7); q.k2 = fr_small(13); q.k3 = fr_small(17); q.edwards_d = edwards_d;
+    for (int i = 0; i < 8; ++i) q.vinv[i] = p->vinv[i];
+    q.out = p->tbuf;
+    PTRY(poly_quotient(c, q));
+    PTRY(ntt_device(c, p->tbuf, p->tbuf, p->tmp8, L + 3, true, true, n8));
+  }
+  PTRY(poly_trimmed_len(c, p->tbuf, n8, p->len_dev));
+  HIP_TRY(hipMemcpyAsync(p->len_host, p->len_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (*p->flag_host) return PLONK_ERR_ARG;                 // "permutation denominator must be nonzero" (permutation.rs:231-234)
+  const uint64_t tlen = *p->len_host;
+  if (tlen > 7 * n) return PLONK_ERR_UNSAT;                // quotient_poly.rs:132
+  const uint64_t len4 = tlen > 3 * n ? tlen - 3 * n : 0;
+  // honest quotient: degree <= 4n + 6 (quotient_poly.rs:106-111) => t_fourth has <= n + 7 coefficients;
+  // anything longer cannot be committed with the trimmed key (key.rs:362-370)
+  if (len4 > n + 7 || len4 > c->srs_n) return PLONK_ERR_DEGREE;
+  {
+    SplitArgs sa;
+    sa.b[0] = bl[11]; sa.b[1] = bl[12]; sa.b[2] = bl[13];
+    sa.len4 = len4;
+    PTRY(poly_split_t(c, p->tbuf, n, np, p->tparts, sa));
+  }
+  Fr* t4 = p->tbuf + 3 * n;
+  const uint64_t t4_len = len4 ? len4 : 1;                 // t_fourth[0] -= b14 even when the tail is empty
+  PTRY(msm_to(p, p->tparts, n + 1, 5));
+  PTRY(msm_to(p, p->tparts + np, n + 1, 6));
+  PTRY(msm_to(p, p->tparts + 2 * np, n + 1, 7));
+  PTRY(msm_to(p, t4, t4_len, 8));
+  PTRY(fetch_commitments(p, 5, 4, comm + 5));
+  tr.append_commitment("t_low_comm", comm[5]);
+  tr.append_commitment("t_mid_comm", comm[6]);
+  tr.append_commitment("t_high_comm", comm[7]);
+  tr.append_commitment("t_fourth_comm", comm[8]);
+
+  // ---- round 4 (prover.rs:591-676): 15 evaluations
+  const Fr z_ch = tr.challenge_scalar("z_challenge");
+  const Fr zw = z_ch * omega;
+  Evals ev;
+  {
+    EvalArgs ea;
+    ea.partial = p->evpart;
+    ea.max_blocks = p->ev_max_blocks;
+    const Fr* P = p->polys;
+    const Fr* pol[15] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np,
+                         p->wpoly, p->wpoly + np, p->wpoly + 3 * np,
+                         P + P_QARITH * np, P + P_QC * np, P + P_QL * np, P + P_QR * np,
+                         P + P_S1 * np, P + P_S2 * np, P + P_S3 * np, p->zpoly};
+    const uint64_t len[15] = {n + 2, n + 2, n + 2, n + 2, n + 2, n + 2, n + 2,
+                              p->poly_len[P_QARITH], p->poly_len[P_QC], p->poly_len[P_QL], p->poly_len[P_QR],
+                              p->poly_len[P_S1], p->poly_len[P_S2], p->poly_len[P_S3], n + 3};
+    for (int k = 0; k < 15; ++k) {
+      ea.items[k].poly = pol[k];
+      ea.items[k].len = len[k];
+      ea.items[k].x = (k >= 4 && k <= 6) || k == 14 ? zw : z_ch;
+    }
+    PTRY(poly_eval(c, ea, 15, n + 3, p->evout));
+    HIP_TRY(hipMemcpyAsync(p->ev_host, p->evout, 15 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const Fr* h = p->ev_host;
+    ev.a = h[0]; ev.b = h[1]; ev.c = h[2]; ev.d = h[3]; ev.a_w = h[4]; ev.b_w = h[5]; ev.d_w = h[6];
+    ev.q_arith = h[7]; ev.q_c = h[8]; ev.q_l = h[9]; ev.q_r = h[10]; ev.s1 = h[11]; ev.s2 = h[12]; ev.s3 = h[13]; ev.z = h[14];
+  }
+  tr.append_scalar("a_eval", ev.a);
+  tr.append_scalar("b_eval", ev.b);
+  tr.append_scalar("c_eval", ev.c);
+  tr.append_scalar("d_eval", ev.d);
+  tr.append_scalar("s_sigma_1_eval", ev.s1);
+  tr.append_scalar("s_sigma_2_eval", ev.s2);
+  tr.append_scalar("s_sigma_3_eval", ev.s3);
+  tr.append_scalar("z_eval", ev.z);
+  tr.append_scalar("a_w_eval", ev.a_w);
+  tr.append_scalar("b_w_eval", ev.b_w);
+  tr.append_scalar("d_w_eval", ev.d_w);
+  tr.append_scalar("q_arith_eval", ev.q_arith);
+  tr.append_scalar("q_c_eval", ev.q_c);
+  tr.append_scalar("q_l_eval", ev.q_l);
+  tr.append_scalar("q_r_eval", ev.q_r);
+
+  // ---- round 5 (prover.rs:678-739)
+  const Fr v = tr.challenge_scalar("v_challenge");
+  const Fr one = Fr::one();
+  const Fr z_n = z_ch.pow_u64(n);
+  const Fr zh = z_n - one;                                           // evaluate_vanishing_polynomial
+  const Fr n_inv = Fr::from_u64(n).inv();
+  // public-input evaluation (compute_barycentric_eval, proof.rs:1041-1088)
+  Fr pi_eval = Fr::zero();
+  if (pi_count) {
+    const Fr omega_inv = omega.inv();
+    Fr acc = Fr::zero();
+    for (uint64_t i = 0; i < pi_count; ++i) {
+      if (pi_val[i].is_zero()) continue;
+      const Fr den = omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
+      acc = acc + den.inv() * pi_val[i];
+    }
+    pi_eval = acc * (zh * n_inv);
+  }
+  // permutation linearisation scalars (permutation/proverkey.rs:127-269)
+  const Fr bz = beta * z_ch;
+  const Fr lin_a = (ev.a + bz + gamma) * (ev.b + fr_small(7) * bz + gamma) * (ev.c + fr_small(13) * bz + gamma) *
+                   (ev.d + fr_small(17) * bz + gamma) * alpha;
+  const Fr lin_b = (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) * (ev.c + beta * ev.s3 + gamma) *
+                   (beta * ev.z) * alpha;
+  Fr l1_z;                                                            // evaluate_all_lagrange_coefficients(z)[0]
+  if (z_n == one) l1_z = (z_ch == one) ? one : Fr::zero();
+  else l1_z = zh * n_inv * (z_ch - one).inv();
+  const Fr c_range = range_identity(range_ch, ev) * range_ch;
+  const Fr c_logic = logic_identity(logic_ch, ev) * logic_ch;
+  const Fr c_fixed = fixed_identity(fixed_ch, ev, edwards_d) * fixed_ch;
+  const Fr c_var = var_identity(var_ch, ev, edwards_d) * var_ch;
+  const Fr nzh = zh.neg();                                            // z_h_eval = -(z^n - 1)
+  Fr vp[12];
+  vp[0] = one;
+  for (int k = 1; k < 12; ++k) vp[k] = vp[k - 1] * v;
+  // W_z numerator = r + v a + v^2 b + v^3 c + v^4 d + v^5 s1 + v^6 s2 + v^7 s3 + v^8 q_arith + v^9 q_c
+  //                 + v^10 q_l + v^11 q_r  (prover.rs:706-726) with r expanded into its terms
+  {
+    LinCombArgs la;
+    int k = 0;
+    const Fr* P = p->polys;
+    auto term = [&](const Fr* ptr, uint64_t len, const Fr& s) { la.t[k].p = ptr; la.t[k].len = len; la.t[k].s = s; ++k; };
+    term(P + P_QM * np, p->poly_len[P_QM], ev.q_arith * ev.a * ev.b);
+    term(P + P_QL * np, p->poly_len[P_QL], ev.q_arith * ev.a + vp[10]);
+    term(P + P_QR * np, p->poly_len[P_QR], ev.q_arith * ev.b + vp[11]);
+    term(P + P_QO * np, p->poly_len[P_QO], ev.q_arith * ev.c);
+    term(P + P_QF * np, p->poly_len[P_QF], ev.q_arith * ev.d);
+    term(P + P_QC * np, p->poly_len[P_QC], ev.q_arith + vp[9]);
+    term(P + P_QARITH * np, p->poly_len[P_QARITH], vp[8]);
+    term(P + P_QRANGE * np, p->poly_len[P_QRANGE], c_range);
+    term(P + P_QLOGIC * np, p->poly_len[P_QLOGIC], c_logic);
+    term(P + P_QFIXED * np, p->poly_len[P_QFIXED], c_fixed);
+    term(P + P_QVAR * np, p->poly_len[P_QVAR], c_var);
+    term(P + P_S1 * np, p->poly_len[P_S1], vp[5]);
+    term(P + P_S2 * np, p->poly_len[P_S2], vp[6]);
+    term(P + P_S3 * np, p->poly_len[P_S3], vp[7]);
+    term(P + P_S4 * np, p->poly_len[P_S4], lin_b.neg());
+    term(p->zpoly, n + 3, lin_a + l1_z * alpha.sqr());
+    term(p->wpoly, n + 2, vp[1]);
+    term(p->wpoly + np, n + 2, vp[2]);
+    term(p->wpoly + 2 * np, n + 2, vp[3]);
+    term(p->wpoly + 3 * np, n + 2, vp[4]);
+    term(p->tparts, n + 1, nzh);
+    term(p->tparts + np, n + 1, nzh * z_n);
+    term(p->tparts + 2 * np, n + 1, nzh * z_n.sqr());
+    term(t4, t4_len, nzh * z_n.sqr() * z_n);
+    la.count = k;
+    la.len = np - 1;
+    la.constant = pi_eval;
+    la.out = p->agg;
+    PTRY(poly_lincomb(c, la));
+  }
+  const bool z_zero = z_ch.is_zero();
+  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : z_ch.inv(), p->scratch, p->totals));
+  if (z_zero) return PLONK_ERR_STATE;   // probability 2^-255; (X - 0) division is a shift — not worth a code path
+  PTRY(msm_to(p, p->wit, np - 2, 9));
+  const Fr v_w = tr.challenge_scalar("v_w_challenge");
+  {
+    LinCombArgs la;
+    la.t[0].p = p->zpoly; la.t[0].len = n + 3; la.t[0].s = one;
+    la.t[1].p = p->wpoly; la.t[1].len = n + 2; la.t[1].s = v_w;
+    la.t[2].p = p->wpoly + np; la.t[2].len = n + 2; la.t[2].s = v_w.sqr();
+    la.t[3].p = p->wpoly + 3 * np; la.t[3].len = n + 2; la.t[3].s = v_w.sqr() * v_w;
+    la.count = 4;
+    la.len = np - 1;
+    la.constant = Fr::zero();
+    la.out = p->agg;
+    PTRY(poly_lincomb(c, la));
+  }
+  if (zw.is_zero()) return PLONK_ERR_STATE;
+  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, zw, zw.inv(), p->scratch, p->totals));
+  PTRY(msm_to(p, p->wit, np - 2, 10));
+  PTRY(fetch_commitments(p, 9, 2, comm + 9));
+
+  // ---- Proof::to_bytes (proof.rs:137-162, linearization_poly.rs:98-124)
+  memcpy(proof, comm, 11 * 48);
+  const Fr* order[15] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.a_w, &ev.b_w, &ev.d_w, &ev.q_arith, &ev.q_c, &ev.q_l,
+                         &ev.q_r, &ev.s1, &ev.s2, &ev.s3, &ev.z};
+  for (int k = 0; k < 15; ++k) fr_to_bytes(*order[k], proof + 11 * 48 + 32 * k);
+  return PLONK_OK;
+}
+
+}  // namespace plonk
+
+using namespace plonk;
+
+struct plonk_prover {
+  plonk::Prover* p;
+  plonk_ctx* ctx;
+};
+
+extern "C" {
+
+int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out) {
+  if (!ctx || !desc || !out) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  if (!ctx->c.srs_table) return PLONK_ERR_NO_SRS;
+  plonk::Prover* p = nullptr;
+  int rc = prover_build(&ctx->c, desc, &p);
+  if (rc) return rc;
+  *out = new plonk_prover{p, ctx};
+  return PLONK_OK;
+}
+
+void plonk_prover_destroy(plonk_prover* pr) {
+  if (!pr) return;
+  {
+    std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+    (void)hipSetDevice(pr->ctx->c.device);
+    (void)hipStreamSynchronize(pr->ctx->c.stream);
+    prover_free(pr->p);
+  }
+  delete pr;
+}
+
+int plonk_prover_vk(plonk_prover* pr, uint8_t out[15 * 48]) {
+  if (!pr || !out) return PLONK_ERR_ARG;
+  memcpy(out, pr->p->vk, 15 * 48);
+  return PLONK_OK;
+}
+
+uint64_t plonk_prover_size(plonk_prover* pr) { return pr ? pr->p->n : 0; }
+
+// Test/diagnostic hook: copy `count` Fr starting at `offset` of an internal device array.
+int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t count, uint64_t* out) {
+  if (!pr || !out) return PLONK_ERR_ARG;
+  plonk::Prover* p = pr->p;
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  const Fr* base[] = {p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tparts, p->agg, p->wit,
+                      p->evals8, p->sigma_n, p->scratch, p->evout, p->polys};
+  const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->n8, p->n8, 3 * p->np, p->np, p->np,
+                          (uint64_t)(P_COUNT + 2) * p->n8, 4 * p->n, 2 * p->np, 16, (uint64_t)P_COUNT * p->np};
+  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return PLONK_ERR_ARG;
+  HIP_TRY(hipSetDevice(pr->ctx->c.device));
+  HIP_TRY(hipMemcpyAsync(out, base[which] + offset, sizeof(Fr) * count, hipMemcpyDeviceToHost, p->c->stream));
+  HIP_TRY(hipStreamSynchronize(p->c->stream));
+  return PLONK_OK;
+}
+
+int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64_t* pi_idx, const uint64_t* pi_val,
+                           uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
+  if (!pr || !wires_dev || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  HIP_TRY(hipSetDevice(pr->ctx->c.device));
+  return prover_prove(pr->p, (const Fr*)wires_dev, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+}
+
+int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const uint64_t* pi_idx, const uint64_t* pi_val,
+                       uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
+  if (!pr || !wires || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  HIP_TRY(hipSetDevice(pr->ctx->c.device));
+  plonk::Prover* p = pr->p;
+  for (int k = 0; k < 4; ++k) {
+    if (!wires[k]) return PLONK_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(p->wires + k * p->n, wires[k], sizeof(Fr) * p->n, hipMemcpyHostToDevice, p->c->stream));
+  }
+  return prover_prove(p, p->wires, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+}
+
+}  // extern "C"

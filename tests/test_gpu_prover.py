@@ -1,0 +1,168 @@
+"""GPU parity: device-resident Prover::prove (plonk_prover_prove through the C-ABI) vs the
+oracle restatement of reference src/compiler/prover.rs:415-761 — bit-identical 1008-byte
+Proof on the same SRS, witness and blinders; and against the reference's own KAT digest."""
+import hashlib
+import random
+
+import pytest
+
+from oracle import bls12_381 as E
+from oracle import plonk as O
+from oracle.rng import StdRng
+from tests.test_oracle_kat import KAT_DIGEST
+
+pytestmark = pytest.mark.gpu
+Q = E.Q
+
+
+class FixedBlinders:
+    """RNG stand-in that records / replays BlsScalar::random draws."""
+
+    def __init__(self, rng):
+        self.rng, self.drawn = rng, []
+
+    def random_scalar(self):
+        s = self.rng.random_scalar()
+        self.drawn.append(s)
+        return s
+
+
+def gpu_prover(ctx, oprover, vk=False):
+    import plonk_amd
+    ctx.srs_load(oprover.ck)
+    vkb = None
+    if vk:
+        vkb = b"".join(E.g1_compress(oprover.vk[name]) for name in plonk_amd.POLY_ORDER)
+    return plonk_amd.Prover(ctx, oprover.constraints, oprover.label, oprover.pk.polys, vkb)
+
+
+def wires_of(composer, size):
+    W = composer.witnesses
+    cols = [[0] * size for _ in range(4)]
+    for i, g in enumerate(composer.constraints):
+        cols[0][i], cols[1][i], cols[2][i], cols[3][i] = W[g.a], W[g.b], W[g.c], W[g.d]
+    return cols
+
+
+def both_prove(ctx, pp, label, build_circuit, seed):
+    oprover = O.compile_circuit(pp, label, build_circuit(), msm=E.msm_pippenger)
+    rec = FixedBlinders(StdRng.seed_from_u64(seed))
+    comp = build_circuit()
+    expected, pis = O.prove(oprover, rec, comp, msm=E.msm_pippenger)
+    assert len(rec.drawn) == 14
+    gp = gpu_prover(ctx, oprover)
+    got = gp.prove(wires_of(comp, oprover.size), dict(comp.public_inputs), rec.drawn)
+    gp.close()
+    return got, expected, oprover
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonk_amd
+    c = plonk_amd.Context(0)
+    yield c
+    c.close()
+
+
+def test_deterministic_v3_proof_matches_base_digest(ctx, kat_setup):
+    """reference prover.rs:1132-1162 through the HIP prover: SRS seed 0x9235e700, proving
+    RNG seed 0x9235e701, MinimalCircuit -> blake2b(proof bytes) == literal at :1151-1158."""
+    import plonk_amd
+    _, oprover, circuit = kat_setup
+    gp = gpu_prover(ctx, oprover)
+    # Compiler::preprocess commitments computed by the GPU MSM (compiler.rs:213-232)
+    assert gp.vk_commitments() == b"".join(E.g1_compress(oprover.vk[n]) for n in plonk_amd.POLY_ORDER)
+    rng = StdRng.seed_from_u64(0x9235E701)
+    blinders = [rng.random_scalar() for _ in range(14)]
+    comp = circuit()
+    proof = gp.prove(wires_of(comp, oprover.size), {}, blinders)
+    assert len(proof) == 1008
+    assert hashlib.blake2b(proof).digest() == KAT_DIGEST
+    # and with the verifier key passed in instead of recomputed
+    gp2 = gpu_prover(ctx, oprover, vk=True)
+    assert gp2.prove(wires_of(comp, oprover.size), {}, blinders) == proof
+    gp.close()
+    gp2.close()
+
+
+def arithmetic_circuit(ngates, seed, with_pi=True):
+    def build():
+        r = random.Random(seed)
+        c = O.Composer()
+        ws = [c.append_witness(r.randrange(Q)) for _ in range(8)]
+        while len(c.constraints) < ngates - (2 if with_pi else 0):
+            a, b, d = r.choice(ws), r.choice(ws), r.choice(ws)
+            if r.random() < 0.5:
+                ws.append(c.gate_add(a, b, d, q_l=r.randrange(Q), q_r=r.randrange(1, 50), q_f=r.randrange(3),
+                                     q_c=r.randrange(Q)))
+            else:
+                ws.append(c.gate_mul(a, b, d, q_m=r.randrange(1, Q), q_f=r.randrange(2), q_c=r.randrange(100)))
+        if with_pi:
+            # append_public (composer.rs:377-389): -w + PI = 0
+            for _ in range(2):
+                v = r.randrange(Q)
+                w = c.append_witness(v)
+                c.append_gate(O.Gate(a=w, q_l=Q - 1, pi=v))
+        return c
+    return build
+
+
+@pytest.mark.parametrize("ngates,seed", [(16, 1), (50, 2), (64, 3), (200, 4)])
+def test_random_arithmetic_circuits_bit_exact(ctx, ngates, seed):
+    pp = O.srs_setup(300, StdRng.seed_from_u64(77), keep=300)
+    got, expected, _ = both_prove(ctx, pp, b"gpu-parity", arithmetic_circuit(ngates, seed), 1000 + seed)
+    assert got == expected
+
+
+def widget_circuit():
+    """Rows activating every selector family on satisfying assignments: all-zero rows satisfy
+    the range/logic/fixed-base/variable-base identities; one non-trivial range row (quads)."""
+    c = O.Composer()
+    z = 0
+    one = 1
+    # non-trivial range gate: d=1, c=4d+2, b=4c+3, a=4b+0, next d = 4a+1
+    d0 = c.append_witness(1)
+    c0 = c.append_witness(6)
+    b0 = c.append_witness(27)
+    a0 = c.append_witness(108)
+    dn = c.append_witness(433)
+    c.append_custom_gate(O.Gate(a=a0, b=b0, c=c0, d=d0, q_range=1))
+    c.append_gate(O.Gate(a=z, b=z, c=z, d=dn))                       # next row carries d_next (0 = 0 gate)
+    for sel in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        g = O.Gate(a=z, b=z, c=z, d=z)
+        setattr(g, sel, 1 if sel != "q_logic" else Q - 1)
+        if sel == "q_logic":
+            g.q_c = Q - 1                                            # Constraint::logic_xor (constraint.rs:213-217)
+        if sel == "q_fixed_group_add":
+            g.q_l, g.q_r, g.q_c = 5, 9, 45                           # x_beta, y_beta, xy_beta
+        c.append_custom_gate(g)
+        c.append_gate(O.Gate(a=z, b=z, c=z, d=z))
+    w = c.append_witness(11)
+    c.assert_equal_constant(w, 11)
+    _ = one
+    return c
+
+
+def test_all_widget_selectors_bit_exact(ctx):
+    pp = O.srs_setup(64, StdRng.seed_from_u64(5), keep=64)
+    got, expected, oprover = both_prove(ctx, pp, b"widgets", widget_circuit, 4242)
+    assert all(oprover.pk.polys[k] for k in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"))
+    assert got == expected
+
+
+def test_unsatisfied_circuit_is_rejected(ctx):
+    """reference tests/common/mod.rs:60-80: forged witnesses -> Error::CircuitUnsatisfied."""
+    import plonk_amd
+    pp = O.srs_setup(64, StdRng.seed_from_u64(6), keep=64)
+    build = arithmetic_circuit(20, 9, with_pi=False)
+    oprover = O.compile_circuit(pp, b"unsat", build(), msm=E.msm_pippenger)
+    comp = build()
+    cols = wires_of(comp, oprover.size)
+    cols[2][7] = (cols[2][7] + 1) % Q            # break one output wire
+    gp = gpu_prover(ctx, oprover)
+    with pytest.raises((plonk_amd.CircuitUnsatisfied, plonk_amd.PolynomialDegreeTooLarge)):
+        gp.prove(cols, {}, list(range(1, 15)))
+    gp.close()
+    comp.witnesses[comp.constraints[7].c] = cols[2][7]
+    with pytest.raises((ValueError, AssertionError)):
+        O.prove(oprover, FixedBlinders(StdRng.seed_from_u64(1)), comp, msm=E.msm_pippenger)
