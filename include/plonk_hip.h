@@ -113,6 +113,13 @@ void* plonk_ctx_stream(plonk_ctx* ctx); /* hipStream_t the library launches on *
  * The 8n coset evaluations, sigma evaluations and vanishing inverses (compiler.rs:310-425,
  * prover.rs:78-100) are rebuilt on the device. */
 typedef struct plonk_prover plonk_prover;
+/* Multi-GPU (one process per GPU): every MSM is sharded by contiguous SRS point range; rank r
+ * loads only points [r*S, (r+1)*S), S = ceil(srs_total / world), into its context and the
+ * per-rank partial sums (192-byte XYZZ points) are exchanged through this callback — an
+ * all-gather (EC addition is not an RCCL reduce op), `recv` laid out rank-major.  bench.py
+ * backs it with torch.distributed (RCCL over xGMI); a Rust shim would call ncclAllGather.
+ * Return 0 on success. */
+typedef int (*plonk_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes_per_rank);
 typedef struct {
   uint64_t constraints;          /* gate count; domain size = next power of two        */
   const uint8_t* label;          /* transcript label (Compiler::compile `label`)        */
@@ -120,6 +127,11 @@ typedef struct {
   const uint64_t* polys[15];
   uint64_t poly_len[15];         /* coefficients per polynomial, <= size                */
   const uint8_t* vk_commitments; /* 15 x 48 bytes or NULL                               */
+  int shard_rank;                /* 0 when shard_world <= 1                             */
+  int shard_world;               /* <= 1: single GPU, the context holds the whole SRS   */
+  uint64_t srs_total;            /* global SRS length (only read when shard_world > 1)  */
+  plonk_allgather_fn allgather;
+  void* allgather_user;
 } plonk_prover_desc;
 int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out);
 void plonk_prover_destroy(plonk_prover* p);

@@ -53,7 +53,18 @@ POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q
 class _ProverDesc(ctypes.Structure):
     _fields_ = [("constraints", ctypes.c_uint64), ("label", ctypes.c_char_p), ("label_len", ctypes.c_uint64),
                 ("polys", ctypes.c_void_p * 15), ("poly_len", ctypes.c_uint64 * 15),
-                ("vk_commitments", ctypes.c_char_p)]
+                ("vk_commitments", ctypes.c_char_p), ("shard_rank", ctypes.c_int), ("shard_world", ctypes.c_int),
+                ("srs_total", ctypes.c_uint64), ("allgather", ctypes.c_void_p), ("allgather_user", ctypes.c_void_p)]
+
+
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous SRS point range owned by `rank` (same rule as prover.hip)."""
+    per = (total + world - 1) // world
+    lo = min(per * rank, total)
+    return lo, min(lo + per, total)
 
 
 class CircuitUnsatisfied(Exception):
@@ -291,9 +302,26 @@ class Prover:
     padded wire columns, sparse public inputs and the 14 blinders drawn by the caller's RNG
     (prover.rs:154-161,133-135,553-555) and returns Proof::to_bytes (1008 bytes)."""
 
-    def __init__(self, ctx: Context, constraints: int, label: bytes, polys: dict, vk_commitments: bytes | None = None):
+    def __init__(self, ctx: Context, constraints: int, label: bytes, polys: dict, vk_commitments: bytes | None = None,
+                 rank: int = 0, world: int = 1, srs_total: int = 0, allgather=None):
+        """allgather(send: bytes) -> bytes (rank-major concatenation) when world > 1."""
         self.ctx = ctx
         desc = _ProverDesc()
+        self._cb = None
+        if world > 1:
+            def _cb(user, send, recv, nbytes):
+                try:
+                    out = allgather(ctypes.string_at(send, nbytes))
+                    assert len(out) == nbytes * world
+                    ctypes.memmove(recv, out, len(out))
+                    return 0
+                except Exception:   # never unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = ALLGATHER_FN(_cb)
+            desc.shard_rank, desc.shard_world, desc.srs_total = rank, world, srs_total
+            desc.allgather = ctypes.cast(self._cb, ctypes.c_void_p)
         desc.constraints = constraints
         desc.label = label
         desc.label_len = len(label)

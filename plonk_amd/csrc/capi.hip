@@ -18,6 +18,14 @@ void set_last_error(const char* what, const char* detail, const char* file, int 
 
 int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G1Affine* out_dev);
 
+void xyzz_to_affine97_host(const G1& p, uint8_t out[97]) {
+  G1Affine a;
+  const bool finite = p.to_affine(&a);
+  memcpy(out, a.x.l, 48);
+  memcpy(out + 48, a.y.l, 48);
+  out[96] = finite ? 0 : 1;
+}
+
 // ---- hipEvent instrumentation ------------------------------------------------
 struct ProfRec { int slot; hipEvent_t a, b; };
 struct ProfState {
@@ -255,7 +263,11 @@ int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_d
   if (!ctx || (!scalars && m) || !out97_dev) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
-  return msm_device(&ctx->c, (const Fr*)scalars, m, (uint8_t*)out97_dev);
+  int rc = msm_reserve(&ctx->c, m ? m : 1);
+  if (rc) return rc;
+  rc = msm_device(&ctx->c, (const Fr*)scalars, m, (G1*)ctx->c.msm.result);
+  if (rc) return rc;
+  return xyzz_to_affine97_device(&ctx->c, (const G1*)ctx->c.msm.result, (uint8_t*)out97_dev);
 }
 
 int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_xy_inf[97]) {
@@ -270,11 +282,13 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
   rc = ensure_scalar_staging(&c, m ? m : 1);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c.msm.scalars_stage, scalars, sizeof(Fr) * m, hipMemcpyHostToDevice, c.stream));
-  rc = msm_device(&c, c.msm.scalars_stage, m, c.msm.result);
+  rc = msm_device(&c, c.msm.scalars_stage, m, (G1*)c.msm.result);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, 97, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, sizeof(G1), hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
-  memcpy(out_xy_inf, c.msm.result_host, 97);
+  G1 r;
+  memcpy(&r, c.msm.result_host, sizeof(G1));
+  xyzz_to_affine97_host(r, out_xy_inf);   // one Fp inversion on the host instead of a serial GPU lane
   return PLONK_OK;
 }
 

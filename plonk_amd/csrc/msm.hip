@@ -260,8 +260,10 @@ __global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1* __restri
   st_g1(chunk + j, acc);
 }
 
-// sum of NB/CHUNK = 2048 chunk results -> affine (x || y || inf flag)
-__global__ void __launch_bounds__(256) msm_final_kernel(const G1* __restrict__ chunk, uint8_t* __restrict__ out97) {
+// sum of NB/CHUNK = 2048 chunk results -> one XYZZ point (192 B).  Affine normalisation
+// (one Fp inversion) is left to the host / to xyzz_to_affine97_kernel: a single-lane
+// Fermat inversion would add ~0.6 ms of serial latency to every MSM.
+__global__ void __launch_bounds__(256) msm_final_kernel(const G1* __restrict__ chunk, G1* __restrict__ out) {
   __shared__ G1 sh[256];
   const uint32_t t = threadIdx.x;
   constexpr uint32_t PER = (MSM_NB / MSM_CHUNK) / 256;
@@ -273,19 +275,21 @@ __global__ void __launch_bounds__(256) msm_final_kernel(const G1* __restrict__ c
     if (t < d) sh[t] = sh[t].add(sh[t + d]);
     __syncthreads();
   }
-  if (t == 0) {
-    G1Affine a;
-    const bool finite = sh[0].to_affine(&a);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out97);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) { o[k] = a.x.l[k]; o[12 + k] = a.y.l[k]; }
-    out97[96] = finite ? 0 : 1;
-  }
+  if (t == 0) st_g1(out, sh[0]);
 }
 
-__global__ void msm_identity_kernel(uint8_t* out97) {
-  if (threadIdx.x < 96) out97[threadIdx.x] = 0;
-  if (threadIdx.x == 96) out97[96] = 1;
+__global__ void xyzz_to_affine97_kernel(const G1* __restrict__ in, uint8_t* __restrict__ out97) {
+  if (threadIdx.x != 0) return;
+  G1Affine a;
+  const bool finite = ld_g1(in).to_affine(&a);
+  uint32_t* o = reinterpret_cast<uint32_t*>(out97);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { o[k] = a.x.l[k]; o[12 + k] = a.y.l[k]; }
+  out97[96] = finite ? 0 : 1;
+}
+
+__global__ void msm_identity_kernel(G1* out) {
+  if (threadIdx.x == 0) st_g1(out, G1::identity());
 }
 
 // ---------------------------------------------------------------------------
@@ -319,8 +323,8 @@ int msm_reserve(Ctx* c, uint64_t m) {
     HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1)));
     HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1) * MSM_NB));
     HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1) * (MSM_NB / MSM_CHUNK)));
-    HIP_TRY(hipMalloc((void**)&w.result, 128));
-    HIP_TRY(hipHostMalloc((void**)&w.result_host, 128, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&w.result, 256));
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, 256, hipHostMallocDefault));
   }
   if (m > w.cap_m) {
     if (w.digits) { HIP_TRY(hipFree(w.digits)); HIP_TRY(hipFree(w.entries)); HIP_TRY(hipFree(w.partial)); }
@@ -337,9 +341,9 @@ int msm_reserve(Ctx* c, uint64_t m) {
 void prof_begin(Ctx* c, int slot);
 void prof_end(Ctx* c, int slot);
 
-int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, uint8_t* out97_dev) {
+int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {
   if (m == 0) {
-    hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(128), 0, c->stream, out97_dev);
+    hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, c->stream, out_dev);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
   }
@@ -365,8 +369,14 @@ int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, uint8_t* out97_dev) {
   prof_begin(c, 2);
   hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB / 128), dim3(128), 0, st, w.partial, w.slice_off, w.buckets);
   hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64), dim3(64), 0, st, w.buckets, w.chunk);
-  hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, w.chunk, out97_dev);
+  hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, w.chunk, out_dev);
   prof_end(c, 2);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
+int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev) {
+  hipLaunchKernelGGL(xyzz_to_affine97_kernel, dim3(1), dim3(64), 0, c->stream, in_dev, out97_dev);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

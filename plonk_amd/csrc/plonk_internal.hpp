@@ -84,7 +84,10 @@ void ntt_plan(uint32_t L, int r[3], int* npass);
 
 // msm.hip
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
-int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, uint8_t* out97_dev);
+int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
+int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
+// host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
+void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);
 int msm_reserve(Ctx* c, uint64_t m);
 
 }  // namespace plonk

@@ -53,8 +53,14 @@ struct Prover {
   Fr* totals = nullptr;            // scan block totals
   Fr* evpart = nullptr;            // eval partials
   Fr* evout = nullptr;             // 16 evaluations
-  uint8_t* res = nullptr;          // 16 x 128 B MSM results (device)
+  uint8_t* res = nullptr;          // 16 x 256 B MSM results, XYZZ (device)
   uint8_t* res_host = nullptr;     // pinned mirror
+  uint8_t* gather_host = nullptr;  // world x 16 x 192 B all-gathered partial sums
+  // multi-GPU: this rank owns SRS points [shard_lo, shard_lo + c->srs_n) of srs_total
+  int rank = 0, world = 1;
+  uint64_t srs_total = 0, shard_lo = 0;
+  plonk_allgather_fn allgather = nullptr;
+  void* allgather_user = nullptr;
   Fr* ev_host = nullptr;           // pinned 16 Fr
   unsigned long long* len_dev = nullptr;
   unsigned long long* len_host = nullptr;
@@ -148,15 +154,48 @@ static Fr var_identity(const Fr& ch, const Evals& e, const Fr& ed) {     // curv
 
 #define PTRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+static constexpr int RES_STRIDE = 256;
+
+// CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
+// [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
+// fetch_commitments.  With world == 1 this is the whole MSM.
 static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) {
-  if (m > p->c->srs_n) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
-  return msm_device(p->c, scalars, m, p->res + 128 * slot);
+  if (m > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
+  const uint64_t lo = p->shard_lo;
+  uint64_t hi = lo + p->c->srs_n;
+  if (hi > m) hi = m;
+  const uint64_t cnt = hi > lo ? hi - lo : 0;
+  return msm_device(p->c, scalars + (cnt ? lo : 0), cnt, (G1*)(p->res + RES_STRIDE * slot));
 }
+// Bring `count` results to the host, all-gather the per-rank partial sums (EC addition is not
+// an RCCL reduction, so the "bucket-sum all-reduce" is an all-gather + local add), normalise
+// to affine on the host (one Fp inversion each) and compress.
 static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48]) {
   Ctx* c = p->c;
-  HIP_TRY(hipMemcpyAsync(p->res_host + 128 * first, p->res + 128 * first, 128 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(p->res_host + RES_STRIDE * first, p->res + RES_STRIDE * first, RES_STRIDE * (size_t)count,
+                         hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < count; ++i) g1_compress97(p->res_host + 128 * (first + i), out48[i]);
+  std::vector<G1> sums(count);
+  for (int i = 0; i < count; ++i) memcpy(&sums[i], p->res_host + RES_STRIDE * (first + i), sizeof(G1));
+  if (p->world > 1) {
+    if (!p->allgather) return PLONK_ERR_STATE;
+    const size_t bytes = sizeof(G1) * (size_t)count;
+    if (p->allgather(p->allgather_user, sums.data(), p->gather_host, bytes) != 0) return PLONK_ERR_STATE;
+    for (int i = 0; i < count; ++i) {
+      G1 acc = G1::identity();
+      for (int r = 0; r < p->world; ++r) {
+        G1 part;
+        memcpy(&part, p->gather_host + (size_t)r * bytes + sizeof(G1) * i, sizeof(G1));
+        acc = acc.add(part);
+      }
+      sums[i] = acc;
+    }
+  }
+  for (int i = 0; i < count; ++i) {
+    uint8_t aff[97];
+    xyzz_to_affine97_host(sums[i], aff);
+    g1_compress97(aff, out48[i]);
+  }
   return PLONK_OK;
 }
 
@@ -167,6 +206,7 @@ static void prover_free(Prover* p) {
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (p->res_host) (void)hipHostFree(p->res_host);
+  if (p->gather_host) free(p->gather_host);
   if (p->ev_host) (void)hipHostFree(p->ev_host);
   if (p->len_host) (void)hipHostFree(p->len_host);
   if (p->flag_host) (void)hipHostFree(p->flag_host);
@@ -184,6 +224,20 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   if (L + 3 >= 28) { delete p; return PLONK_ERR_ARG; }
   p->n = n; p->logn = L; p->n8 = 8 * n; p->np = n + 8;
   p->label.assign((const char*)d->label, d->label_len);
+  p->world = d->shard_world > 1 ? d->shard_world : 1;
+  p->rank = p->world > 1 ? d->shard_rank : 0;
+  if (p->rank < 0 || p->rank >= p->world) { delete p; return PLONK_ERR_ARG; }
+  p->srs_total = p->world > 1 ? d->srs_total : c->srs_n;
+  {
+    const uint64_t per = (p->srs_total + p->world - 1) / p->world;   // contiguous point ranges
+    p->shard_lo = per * (uint64_t)p->rank;
+    const uint64_t hi = p->shard_lo + per < p->srs_total ? p->shard_lo + per : p->srs_total;
+    const uint64_t want = hi > p->shard_lo ? hi - p->shard_lo : 0;
+    if (p->world > 1 && c->srs_n != want) { delete p; return PLONK_ERR_ARG; }   // ctx must hold exactly this rank's slice
+  }
+  p->allgather = d->allgather;
+  p->allgather_user = d->allgather_user;
+  if (p->world > 1) p->gather_host = (uint8_t*)malloc((size_t)p->world * 16 * sizeof(G1));
   const uint64_t np = p->np, n8 = p->n8;
 #define ALLOC(ptr, count) do { hipError_t _e = hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)); \
     if (_e != hipSuccess) { set_last_error("hipMalloc " #ptr, hipGetErrorString(_e), __FILE__, __LINE__); prover_free(p); return PLONK_ERR_HIP; } } while (0)
@@ -205,11 +259,11 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   p->ev_max_blocks = (uint32_t)((np + 4095) / 4096);
   ALLOC(p->evpart, 16 * (uint64_t)p->ev_max_blocks);
   ALLOC(p->evout, 16);
-  ALLOC(p->res, 16 * 128);
+  ALLOC(p->res, 16 * RES_STRIDE);
   ALLOC(p->len_dev, 1);
   ALLOC(p->flag_dev, 1);
 #undef ALLOC
-  HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * 128, hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * RES_STRIDE, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->ev_host, 16 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->len_host, sizeof(unsigned long long), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->flag_host, sizeof(int), hipHostMallocDefault));
@@ -566,7 +620,7 @@ int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_pro
   if (!ctx || !desc || !out) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
-  if (!ctx->c.srs_table) return PLONK_ERR_NO_SRS;
+  if (!ctx->c.srs_table && desc->shard_world <= 1) return PLONK_ERR_NO_SRS;
   plonk::Prover* p = nullptr;
   int rc = prover_build(&ctx->c, desc, &p);
   if (rc) return rc;
