@@ -1,0 +1,178 @@
+// G1 in XYZZ coordinates over the reduced-radix field Fp28 (fp28.cuh), lazily reduced.
+//
+// Same group law as curve.cuh (EFD xyzz madd-2008-s / add-2008-s / dbl-2008-s-1); the
+// difference is bookkeeping: no conditional subtractions — every coordinate carries a static
+// bound (in multiples of p) that is closed under the three operations:
+//        X < 16p,  Y < 8p,  ZZ < 2p,  ZZZ < 2p        (table points: x, y < 2p)
+// Subtractions add the smallest pad K*p with K >= 2 * bound(subtrahend); every product's
+// operand bounds multiply to < 2528 (= R'/p), so products come out < 2p.  The bounds are
+// annotated on each line.  ZZ == 0 (all limbs) marks the identity.
+#pragma once
+#include "curve.cuh"
+#include "fp28.cuh"
+
+namespace plonk {
+
+struct alignas(16) Fp28Slot {   // 14 limbs + 2 pad words = 64 B so coordinates stay 16-B aligned
+  uint32_t w[16];
+};
+struct alignas(16) G1AffineR {  // 128 B table entry: one cache line per gather
+  Fp28Slot x, y;
+};
+
+struct G1R {
+  Fp28 X, Y, ZZ, ZZZ;
+
+  HD static G1R identity() {
+    G1R r;
+    r.X = Fp28::one();
+    r.Y = Fp28::one();
+    r.ZZ = Fp28::zero();
+    r.ZZZ = Fp28::zero();
+    return r;
+  }
+  HD bool is_identity() const { return ZZ.is_zero_limbs(); }
+
+  HD static G1R from_affine(const Fp28& x, const Fp28& y) {
+    G1R r;
+    r.X = x;
+    r.Y = y;
+    r.ZZ = Fp28::one();
+    r.ZZZ = Fp28::one();
+    return r;
+  }
+
+  // cheap necessary condition for v == 0 (mod p) when value(v) < 64p: v = k p with k < 64,
+  // so (v mod 2^28) * p^-1 mod 2^28 = k < 64.  False positives 2^-22 -> exact test.
+  HD static bool maybe_zero(const Fp28& v) {
+    const uint32_t pinv = (0u - Fp28::INV) & Fp28::MASK;   // p^-1 mod 2^28
+    return ((v.l[0] * pinv) & Fp28::MASK) < 64u;
+  }
+  HD static bool zero_mod(const Fp28& v) { return maybe_zero(v) && v.is_zero_mod(); }
+
+  // 2 * this.  In: X<16p Y<8p ZZ,ZZZ<2p.  Out: X<10p Y<6p ZZ,ZZZ<2p.
+  HD G1R dbl() const {
+    if (is_identity()) return identity();   // (Y == 0 cannot happen in the prime-order group)
+    const Fp28 U = Y.dbl();                                   // < 16p
+    const Fp28 V = U.sqr();                                   // 16*16            -> < 2p
+    const Fp28 W = Fp28::mul(U, V);                           // 16*2             -> < 2p
+    const Fp28 S = Fp28::mul(X, V);                           // 16*2             -> < 2p
+    const Fp28 XX = X.sqr();                                  // 16*16            -> < 2p
+    const Fp28 M = Fp28::add(XX.dbl(), XX);                   // < 6p
+    G1R r;
+    r.X = Fp28::sub<8>(M.sqr(), S.dbl());                     // 2p - (<4p) + 8p   -> < 10p
+    r.Y = Fp28::sub<4>(Fp28::mul(M, Fp28::sub<32>(S, r.X)),   // 6 * (2+32=34)     -> < 2p
+                       Fp28::mul(W, Y));                      // 2*8 ; 2p - 2p + 4p -> < 6p
+    r.ZZ = Fp28::mul(V, ZZ);                                  // < 2p
+    r.ZZZ = Fp28::mul(W, ZZZ);                                // < 2p
+    return r;
+  }
+  HD static G1R dbl_affine(const Fp28& x, const Fp28& y) { return from_affine(x, y).dbl(); }
+
+  // this + (x2, y2), affine operand never the identity; x2 < 2p, y2 < 4p (after negation).
+  HD G1R add_affine(const Fp28& x2, const Fp28& y2) const {
+    if (is_identity()) return from_affine(x2, y2);
+    const Fp28 U2 = Fp28::mul(x2, ZZ);                        // 2*2               -> < 2p
+    const Fp28 S2 = Fp28::mul(y2, ZZZ);                       // 4*2               -> < 2p
+    const Fp28 P_ = Fp28::sub<32>(U2, X);                     // X<16p             -> < 34p
+    const Fp28 R_ = Fp28::sub<16>(S2, Y);                     // Y<8p              -> < 18p
+    if (maybe_zero(P_) && P_.is_zero_mod()) {
+      if (R_.is_zero_mod()) return dbl_affine(x2, y2);
+      return identity();
+    }
+    const Fp28 PP = P_.sqr();                                 // 34*34 = 1156      -> < 2p
+    const Fp28 PPP = Fp28::mul(P_, PP);                       // 34*2              -> < 2p
+    const Fp28 Q_ = Fp28::mul(X, PP);                         // 16*2              -> < 2p
+    G1R r;
+    r.X = Fp28::sub<8>(Fp28::sub<4>(R_.sqr(), PPP), Q_.dbl()); // 18*18=324; 2p+4p+8p -> < 14p
+    r.Y = Fp28::sub<4>(Fp28::mul(R_, Fp28::sub<32>(Q_, r.X)),  // 18 * 34 = 612     -> < 2p
+                       Fp28::mul(Y, PPP));                     // 8*2 ; +4p         -> < 6p
+    r.ZZ = Fp28::mul(ZZ, PP);                                 // < 2p
+    r.ZZZ = Fp28::mul(ZZZ, PPP);                              // < 2p
+    return r;
+  }
+
+  // full addition (same bounds in and out)
+  HD G1R add(const G1R& b) const {
+    if (is_identity()) return b;
+    if (b.is_identity()) return *this;
+    const Fp28 U1 = Fp28::mul(X, b.ZZ);                       // 16*2 -> < 2p
+    const Fp28 U2 = Fp28::mul(b.X, ZZ);
+    const Fp28 S1 = Fp28::mul(Y, b.ZZZ);                      // 8*2  -> < 2p
+    const Fp28 S2 = Fp28::mul(b.Y, ZZZ);
+    const Fp28 P_ = Fp28::sub<4>(U2, U1);                     // < 6p
+    const Fp28 R_ = Fp28::sub<4>(S2, S1);                     // < 6p
+    if (maybe_zero(P_) && P_.is_zero_mod()) {
+      if (R_.is_zero_mod()) return dbl();
+      return identity();
+    }
+    const Fp28 PP = P_.sqr();
+    const Fp28 PPP = Fp28::mul(P_, PP);
+    const Fp28 Q_ = Fp28::mul(U1, PP);
+    G1R r;
+    r.X = Fp28::sub<8>(Fp28::sub<4>(R_.sqr(), PPP), Q_.dbl()); // < 14p
+    r.Y = Fp28::sub<4>(Fp28::mul(R_, Fp28::sub<32>(Q_, r.X)), Fp28::mul(S1, PPP));   // < 6p
+    r.ZZ = Fp28::mul(Fp28::mul(ZZ, b.ZZ), PP);
+    r.ZZZ = Fp28::mul(Fp28::mul(ZZZ, b.ZZZ), PPP);
+    return r;
+  }
+
+  HD G1R mul_u32(uint32_t k) const {
+    G1R acc = identity();
+    bool started = false;
+    for (int b = 31; b >= 0; --b) {
+      if (started) acc = acc.dbl();
+      if ((k >> b) & 1) {
+        acc = started ? acc.add(*this) : *this;
+        started = true;
+      }
+    }
+    return acc;
+  }
+
+  // back to the 12 x 32-bit form (canonical coordinates) for the host / ABI
+  HD G1 to_g1() const {
+    G1 r;
+    if (is_identity()) return G1::identity();
+    r.X = X.to_fp();
+    r.Y = Y.to_fp();
+    r.ZZ = ZZ.to_fp();
+    r.ZZZ = ZZZ.to_fp();
+    return r;
+  }
+};
+
+// Fermat inverse in Fp28 (value < 2p in, < 2p out)
+HD Fp28 fp28_inv(const Fp28& a) {
+  // exponent p - 2 as 32-bit words
+  uint32_t e[12];
+  uint64_t borrow = 2;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    uint64_t t = (uint64_t)FpP::MOD[i] - borrow;
+    e[i] = (uint32_t)t;
+    borrow = (t >> 63) & 1;
+  }
+  Fp28 acc = Fp28::one();
+  bool started = false;
+  for (int w = 11; w >= 0; --w)
+    for (int b = 31; b >= 0; --b) {
+      if (started) acc = acc.sqr();
+      if ((e[w] >> b) & 1) {
+        acc = started ? Fp28::mul(acc, a) : a;
+        started = true;
+      }
+    }
+  return acc;
+}
+
+// affine coordinates (x, y) < 2p of a finite point
+HD void g1r_to_affine(const G1R& p, Fp28* x, Fp28* y) {
+  const Fp28 inv = fp28_inv(Fp28::mul(p.ZZ, p.ZZZ));
+  const Fp28 izz = Fp28::mul(inv, p.ZZZ);
+  const Fp28 izzz = Fp28::mul(inv, p.ZZ);
+  *x = Fp28::mul(p.X, izz);
+  *y = Fp28::mul(p.Y, izzz);
+}
+
+}  // namespace plonk

@@ -15,13 +15,16 @@
 //                    (a slice = at most MSM_KSL entries of one bucket).
 //   * msm_scatter  : counting-sort scatter of (table index | sign) by bucket.
 //   * msm_accumulate (dominant): one lane per slice; gathers affine table points
-//                    and folds them into an XYZZ accumulator (mixed addition,
-//                    384-bit Montgomery arithmetic on the VALU).
+//                    (128-byte entries, one cache line each) and folds them into an
+//                    XYZZ accumulator.  Field arithmetic is the reduced-radix, lazily
+//                    reduced Fp28 of fp28.cuh / curve28.cuh: a mixed addition is ten
+//                    Montgomery products of 2*14*14 v_mad_u64_u32 each and no carry chains.
 //   * msm_bucket_sum, msm_chunk_reduce, msm_final: slice partials -> buckets ->
 //                    sum_b b * B_b -> affine.
 //
 // Algorithmic HBM bytes per MSM of m terms: 128 * m (32 B scalar + 96 B base).
 #include "plonk_internal.hpp"
+#include "curve28.cuh"
 
 namespace plonk {
 
@@ -70,21 +73,55 @@ __device__ __forceinline__ void st_g1(G1* p, const G1& v) {
   st_fp(&p->X, v.X); st_fp(&p->Y, v.Y); st_fp(&p->ZZ, v.ZZ); st_fp(&p->ZZZ, v.ZZZ);
 }
 
+// ---- Fp28 / G1R in memory: each coordinate padded to 16 words (64 B) ------------------
+struct alignas(16) G1RSlot {
+  Fp28Slot X, Y, ZZ, ZZZ;
+};
+__device__ __forceinline__ Fp28 ld_f28(const Fp28Slot* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  Fp28 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+  r.l[12] = d.x; r.l[13] = d.y;
+  return r;
+}
+__device__ __forceinline__ void st_f28(Fp28Slot* p, const Fp28& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+  q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
+}
+__device__ __forceinline__ G1R ld_g1r(const G1RSlot* p) {
+  G1R r;
+  r.X = ld_f28(&p->X); r.Y = ld_f28(&p->Y); r.ZZ = ld_f28(&p->ZZ); r.ZZZ = ld_f28(&p->ZZZ);
+  return r;
+}
+__device__ __forceinline__ void st_g1r(G1RSlot* p, const G1R& v) {
+  st_f28(&p->X, v.X); st_f28(&p->Y, v.Y); st_f28(&p->ZZ, v.ZZ); st_f28(&p->ZZZ, v.ZZZ);
+}
+
 // ---------------------------------------------------------------------------
 // SRS tables
 // ---------------------------------------------------------------------------
-// T[w * n + i] = 2^(16 w) * P_i, affine.  One lane per point; 16 doublings and one
-// Fp inversion per window (one-off per Prover, outside every timed region).
-__global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1Affine* __restrict__ table, uint64_t n) {
+// T[w * n + i] = 2^(16 w) * P_i, affine, in the reduced-radix form (x, y < 2p).  One lane per
+// point; 16 doublings and one Fp inversion per window (one-off per Prover, outside every
+// timed region).
+__global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __restrict__ table, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  G1Affine a = ld_aff(pts + i);
-  st_aff(table + i, a);
+  const G1Affine a = ld_aff(pts + i);
+  Fp28 x = Fp28::from_fp(a.x), y = Fp28::from_fp(a.y);
+  st_f28(&table[i].x, x);
+  st_f28(&table[i].y, y);
   for (int w = 1; w < MSM_W; ++w) {
-    G1 p = G1::dbl_affine(a);
+    G1R p = G1R::dbl_affine(x, y);
     for (int k = 1; k < MSM_C; ++k) p = p.dbl();
-    p.to_affine(&a);   // order of P_i is the (prime) group order: never the identity
-    st_aff(table + (uint64_t)w * n + i, a);
+    g1r_to_affine(p, &x, &y);   // P_i has prime order: never the identity
+    st_f28(&table[(uint64_t)w * n + i].x, x);
+    st_f28(&table[(uint64_t)w * n + i].y, y);
   }
 }
 
@@ -206,11 +243,11 @@ __global__ void msm_scatter_kernel(const uint32_t* __restrict__ digits, uint64_t
 // ---------------------------------------------------------------------------
 // accumulation
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine* __restrict__ table,
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __restrict__ table,
                                                              const uint32_t* __restrict__ entries,
                                                              const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ slice_off,
-                                                             G1* __restrict__ partial) {
+                                                             G1RSlot* __restrict__ partial) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nslices = slice_off[MSM_NB];
   if (s >= nslices) return;
@@ -226,56 +263,71 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1Affine* __r
   uint32_t end = beg + MSM_KSL;
   const uint32_t bend = offsets[b + 1];
   if (end > bend) end = bend;
-  G1 acc = G1::identity();
+  G1R acc = G1R::identity();
   for (uint32_t k = beg; k < end; ++k) {
     const uint32_t ent = entries[k];
-    G1Affine a = ld_aff(table + (ent & 0x7fffffffu));
-    if (ent & 0x80000000u) a.y = a.y.neg();
-    acc = acc.add_affine(a);
+    const G1AffineR* e = table + (ent & 0x7fffffffu);
+    const Fp28 x = ld_f28(&e->x);
+    Fp28 y = ld_f28(&e->y);
+    if (ent & 0x80000000u) y = Fp28::sub<4>(Fp28::zero(), y);   // -y : 4p - y < 4p
+    acc = acc.add_affine(x, y);
   }
-  st_g1(partial + s, acc);
+  st_g1r(partial + s, acc);
 }
 
-__global__ void __launch_bounds__(128) msm_bucket_sum_kernel(const G1* __restrict__ partial,
+// bucket[b] = sum of its slice partials.  Eight lanes cooperate on one bucket (strided
+// partial sums, then a 3-step LDS tree), so a bucket that attracted most of the scalars
+// (equal coefficients => equal digits) costs n/8 serial additions instead of n.
+static constexpr int BS_G = 8;
+__global__ void __launch_bounds__(128) msm_bucket_sum_kernel(const G1RSlot* __restrict__ partial,
                                                              const uint32_t* __restrict__ slice_off,
-                                                             G1* __restrict__ buckets) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= MSM_NB) return;
-  const uint32_t beg = slice_off[b], end = slice_off[b + 1];
-  G1 acc = G1::identity();
-  for (uint32_t k = beg; k < end; ++k) acc = acc.add(ld_g1(partial + k));
-  st_g1(buckets + b, acc);
+                                                             G1RSlot* __restrict__ buckets) {
+  __shared__ G1R sh[128];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t b = t / BS_G, g = t % BS_G;
+  G1R acc = G1R::identity();
+  if (b < MSM_NB) {
+    const uint32_t beg = slice_off[b], end = slice_off[b + 1];
+    for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
+  }
+  for (int d = BS_G / 2; d >= 1; d >>= 1) {
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)g < d) acc = acc.add(sh[threadIdx.x + d]);
+    __syncthreads();
+  }
+  if (g == 0 && b < MSM_NB) st_g1r(buckets + b, acc);
 }
 
 // V_j = sum_{i < CHUNK} (CHUNK*j + i + 1) * B[CHUNK*j + i]
-__global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1* __restrict__ buckets, G1* __restrict__ chunk) {
+__global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1RSlot* __restrict__ buckets, G1RSlot* __restrict__ chunk) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= MSM_NB / MSM_CHUNK) return;
-  G1 run = G1::identity(), acc = G1::identity();
+  G1R run = G1R::identity(), acc = G1R::identity();
   for (int i = MSM_CHUNK - 1; i >= 0; --i) {
-    run = run.add(ld_g1(buckets + j * MSM_CHUNK + i));
+    run = run.add(ld_g1r(buckets + j * MSM_CHUNK + i));
     acc = acc.add(run);
   }
   if (j) acc = acc.add(run.mul_u32(j * MSM_CHUNK));
-  st_g1(chunk + j, acc);
+  st_g1r(chunk + j, acc);
 }
 
-// sum of NB/CHUNK = 2048 chunk results -> one XYZZ point (192 B).  Affine normalisation
-// (one Fp inversion) is left to the host / to xyzz_to_affine97_kernel: a single-lane
-// Fermat inversion would add ~0.6 ms of serial latency to every MSM.
-__global__ void __launch_bounds__(256) msm_final_kernel(const G1* __restrict__ chunk, G1* __restrict__ out) {
-  __shared__ G1 sh[256];
+// sum of NB/CHUNK = 2048 chunk results -> one XYZZ point in the 12 x 32-bit form (192 B).
+// Affine normalisation (one Fp inversion) is left to the host / xyzz_to_affine97_kernel: a
+// single-lane Fermat inversion would add ~0.6 ms of serial latency to every MSM.
+__global__ void __launch_bounds__(256) msm_final_kernel(const G1RSlot* __restrict__ chunk, G1* __restrict__ out) {
+  __shared__ G1R sh[256];
   const uint32_t t = threadIdx.x;
   constexpr uint32_t PER = (MSM_NB / MSM_CHUNK) / 256;
-  G1 acc = G1::identity();
-  for (uint32_t k = 0; k < PER; ++k) acc = acc.add(ld_g1(chunk + t * PER + k));
-  sh[t] = acc;
-  __syncthreads();
+  G1R acc = G1R::identity();
+  for (uint32_t k = 0; k < PER; ++k) acc = acc.add(ld_g1r(chunk + t * PER + k));
   for (uint32_t d = 128; d >= 1; d >>= 1) {
-    if (t < d) sh[t] = sh[t].add(sh[t + d]);
+    sh[t] = acc;
+    __syncthreads();
+    if (t < d) acc = acc.add(sh[t + d]);
     __syncthreads();
   }
-  if (t == 0) st_g1(out, sh[0]);
+  if (t == 0) st_g1(out, acc.to_g1());
 }
 
 __global__ void xyzz_to_affine97_kernel(const G1* __restrict__ in, uint8_t* __restrict__ out97) {
@@ -299,8 +351,8 @@ int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
   if (c->srs_table) { HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
   if (n == 0) return PLONK_OK;
   if ((uint64_t)MSM_W * n >= (1ull << 31)) return PLONK_ERR_ARG;   // entry word: 31-bit table index
-  HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1Affine) * (size_t)MSM_W * n));
-  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, c->srs_table, n);
+  HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)MSM_W * n));
+  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, (G1AffineR*)c->srs_table, n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->srs_n = n;
@@ -321,8 +373,8 @@ int msm_reserve(Ctx* c, uint64_t m) {
     HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1)));
     HIP_TRY(hipMalloc((void**)&w.cursors, sizeof(uint32_t) * MSM_NB));
     HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1)));
-    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1) * MSM_NB));
-    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1) * (MSM_NB / MSM_CHUNK)));
+    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB));
+    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK)));
     HIP_TRY(hipMalloc((void**)&w.result, 256));
     HIP_TRY(hipHostMalloc((void**)&w.result_host, 256, hipHostMallocDefault));
   }
@@ -332,7 +384,7 @@ int msm_reserve(Ctx* c, uint64_t m) {
     HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap));
     HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap));
     w.cap_slices = (MSM_W * cap) / MSM_KSL + MSM_NB + 1;
-    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1) * w.cap_slices));
+    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices));
     w.cap_m = cap;
   }
   return PLONK_OK;
@@ -364,12 +416,14 @@ int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {
   const uint64_t max_slices = (MSM_W * m) / MSM_KSL + MSM_NB + 1;
   prof_begin(c, 1);
   hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128)), dim3(128), 0, st,
-                     c->srs_table, w.entries, w.offsets, w.slice_off, w.partial);
+                     (const G1AffineR*)c->srs_table, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
   prof_begin(c, 2);
-  hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB / 128), dim3(128), 0, st, w.partial, w.slice_off, w.buckets);
-  hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64), dim3(64), 0, st, w.buckets, w.chunk);
-  hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, w.chunk, out_dev);
+  hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB * BS_G / 128), dim3(128), 0, st, (const G1RSlot*)w.partial,
+                     w.slice_off, (G1RSlot*)w.buckets);
+  hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64), dim3(64), 0, st, (const G1RSlot*)w.buckets,
+                     (G1RSlot*)w.chunk);
+  hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, (const G1RSlot*)w.chunk, out_dev);
   prof_end(c, 2);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;

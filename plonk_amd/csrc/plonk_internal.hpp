@@ -47,9 +47,9 @@ struct MsmWork {   // per-stream scratch, grown on demand
   uint32_t* cursors = nullptr;     // NB
   uint32_t* slice_off = nullptr;   // NB + 1
   uint64_t cap_slices = 0;
-  G1* partial = nullptr;           // slices
-  G1* buckets = nullptr;           // NB
-  G1* chunk = nullptr;             // NB / 16
+  void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
+  void* buckets = nullptr;         // NB
+  void* chunk = nullptr;           // NB / 16
   uint8_t* result = nullptr;       // 97 B device
   uint8_t* result_host = nullptr;  // pinned
   Fr* scalars_stage = nullptr;     // H2D staging for host-pointer API
@@ -67,7 +67,7 @@ struct Ctx {
   Fr* ntt_tmp = nullptr;
   uint64_t ntt_cap = 0;
   // SRS
-  G1Affine* srs_table = nullptr;   // [MSM_W][npoints] affine, 2^(16 w) * P_i
+  void* srs_table = nullptr;       // [MSM_W][npoints] 128-B affine entries (Fp28), 2^(16 w) * P_i
   uint64_t srs_n = 0;
   MsmWork msm;
   // instrumentation: hipEvent pairs around the dominant kernels

@@ -28,3 +28,56 @@ int h_g1_add_full(const uint8_t* a, const uint8_t* b, uint8_t* o) {
 int h_g1_mul_u32(const uint8_t* a, uint32_t k, uint8_t* o) { G1Affine x; memcpy(&x, a, 96); return out_aff(G1::from_affine(x).mul_u32(k), o); }
 int h_g1_neg_add(const uint8_t* a, uint8_t* o) { G1Affine x; memcpy(&x, a, 96); G1Affine n = x; n.y = x.y.neg(); return out_aff(G1::from_affine(x).add_affine(n), o); }
 }
+// ---- reduced-radix Fp (fp28.cuh) ----
+#include "../../plonk_amd/csrc/fp28.cuh"
+extern "C" {
+// inputs/outputs in the 12 x 32-bit R = 2^384 form; computation done in Fp28
+void h_fp28_mul(const uint32_t* a, const uint32_t* b, uint32_t* o) { Fp x, y; memcpy(&x, a, 48); memcpy(&y, b, 48); Fp r = Fp28::mul(Fp28::from_fp(x), Fp28::from_fp(y)).to_fp(); memcpy(o, &r, 48); }
+void h_fp28_chain(const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  // exercises lazy add/sub bounds: ((a + b) * (a - b + 4p)) - (a*a) + (b*b) ... = 0 ; returns a*b + that
+  Fp x, y; memcpy(&x, a, 48); memcpy(&y, b, 48);
+  Fp28 A = Fp28::from_fp(x), Bv = Fp28::from_fp(y);
+  Fp28 s = Fp28::add(A, Bv), d = Fp28::sub<4>(A, Bv);
+  Fp28 t = Fp28::mul(s, d);                         // a^2 - b^2
+  Fp28 u = Fp28::sub<4>(t, A.sqr());                // -b^2 (+4p)
+  Fp28 v = Fp28::add(u, Bv.sqr());                  // 0 mod p, value < 8p
+  Fp28 w = Fp28::add(Fp28::mul(A, Bv), v);
+  Fp r = w.to_fp(); memcpy(o, &r, 48);
+}
+int h_fp28_zero_test(const uint32_t* a) { Fp x; memcpy(&x, a, 48); Fp28 A = Fp28::from_fp(x); Fp28 z = Fp28::sub<4>(A, A); Fp28 z2 = Fp28::sub<32>(Fp28::add(Fp28::add(A, A), A.dbl().dbl()), Fp28::add(A.dbl(), A.dbl().dbl())); return (z.is_zero_mod() ? 1 : 0) | (z2.is_zero_mod() ? 2 : 0) | (A.is_zero_mod() ? 4 : 0); }
+void h_fp28_roundtrip(const uint32_t* a, uint32_t* o) { Fp x; memcpy(&x, a, 48); Fp r = Fp28::from_fp(x).to_fp(); memcpy(o, &r, 48); }
+}
+// ---- XYZZ over Fp28 (curve28.cuh) ----
+#include "../../plonk_amd/csrc/curve28.cuh"
+extern "C" {
+static int out_aff_r(const G1R& p, uint8_t* o) { return out_aff(p.to_g1(), o); }
+// sum_{i<n} (neg[i] ? -P_i : P_i) with mixed additions, points 96 B each in the 32-bit form
+int h_g1r_accumulate(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* o) {
+  G1R acc = G1R::identity();
+  for (int i = 0; i < n; ++i) {
+    G1Affine a; memcpy(&a, pts + 96 * i, 96);
+    Fp28 x = Fp28::from_fp(a.x), y = Fp28::from_fp(a.y);
+    if (neg[i]) y = Fp28::sub<4>(Fp28::zero(), y);
+    acc = acc.add_affine(x, y);
+  }
+  return out_aff_r(acc, o);
+}
+// (sum of first half) + (sum of second half) via the full addition; then * k
+int h_g1r_tree(const uint8_t* pts, int n, uint32_t k, uint8_t* o) {
+  G1R a = G1R::identity(), b = G1R::identity();
+  for (int i = 0; i < n; ++i) {
+    G1Affine p; memcpy(&p, pts + 96 * i, 96);
+    Fp28 x = Fp28::from_fp(p.x), y = Fp28::from_fp(p.y);
+    if (i < n / 2) a = a.add_affine(x, y); else b = b.add_affine(x, y);
+  }
+  G1R s = a.add(b);
+  s = s.add(s);            // doubling through add()
+  return out_aff_r(s.mul_u32(k), o);
+}
+int h_g1r_affine_roundtrip(const uint8_t* pt, uint8_t* o) {
+  G1Affine p; memcpy(&p, pt, 96);
+  G1R q = G1R::from_affine(Fp28::from_fp(p.x), Fp28::from_fp(p.y)).dbl().dbl();
+  Fp28 x, y; g1r_to_affine(q, &x, &y);
+  G1Affine r; r.x = x.to_fp(); r.y = y.to_fp(); memcpy(o, &r, 96); return 1;
+}
+}

@@ -18,7 +18,7 @@ Q, P = E.Q, E.P
 def lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
-    hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h) for h in ("field.cuh", "curve.cuh")]
+    hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h) for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -116,3 +116,55 @@ def test_g1_group_law_matches_oracle(lib):
             ok = lib.h_g1_mul_u32(E.g1_to_raw96(a), k, out)
             assert ok == 1 and E.g1_from_raw96(bytes(out)) == E.g1_mul(a, k)
         assert lib.h_g1_mul_u32(E.g1_to_raw96(a), 0, out) == 0
+
+
+def test_fp28_reduced_radix_matches_oracle(lib):
+    """fp28.cuh (14 x 28-bit limbs, lazy reduction) against big ints, through the 32-bit form."""
+    rnd = random.Random(9)
+    vals = edge_values(P, rnd, 60)
+    out = (ctypes.c_uint32 * 12)()
+    for a in vals:
+        lib.h_fp28_roundtrip(fp_limbs(a), out)
+        assert fp_val(out) == a
+        for b in vals[:9] + [rnd.randrange(P), rnd.randrange(P)]:
+            lib.h_fp28_mul(fp_limbs(a), fp_limbs(b), out)
+            assert fp_val(out) == a * b % P
+            lib.h_fp28_chain(fp_limbs(a), fp_limbs(b), out)
+            assert fp_val(out) == a * b % P
+        flags = lib.h_fp28_zero_test(fp_limbs(a))
+        assert flags & 3 == 3 and bool(flags & 4) == (a == 0)
+
+
+def test_g1_xyzz_over_fp28_matches_oracle(lib):
+    """curve28.cuh: lazily-reduced XYZZ formulas — long accumulation chains (bounds must stay
+    closed), negated operands, P + P and P + (-P) through the mixed and the full addition."""
+    rnd = random.Random(12)
+    G = E.G1_GEN
+    pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(40)]
+    raw = b"".join(E.g1_to_raw96(p) for p in pts)
+    out = (ctypes.c_uint8 * 96)()
+    for n in (1, 2, 3, 17, 40):
+        neg = bytes(rnd.randrange(2) for _ in range(n))
+        ok = lib.h_g1r_accumulate(raw, neg, n, out)
+        exp = None
+        for p, s in zip(pts[:n], neg):
+            exp = E.g1_add(exp, (p[0], (E.P - p[1]) % E.P) if s else p)
+        assert (ok == 1) == (exp is not None)
+        if exp is not None:
+            assert E.g1_from_raw96(bytes(out)) == exp
+    # same point repeatedly: first mixed add hits the doubling branch, then generic adds
+    rep = E.g1_to_raw96(pts[0]) * 9
+    assert lib.h_g1r_accumulate(rep, bytes(9), 9, out) == 1
+    assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[0], 9)
+    # P + (-P) + P
+    assert lib.h_g1r_accumulate(rep, bytes([0, 1, 0]), 3, out) == 1
+    assert E.g1_from_raw96(bytes(out)) == pts[0]
+    assert lib.h_g1r_accumulate(rep, bytes([0, 1]), 2, out) == 0
+    for k in (1, 2, 16 * 2047, 0xFFFF):
+        ok = lib.h_g1r_tree(raw, 20, k, out)
+        s = None
+        for p in pts[:20]:
+            s = E.g1_add(s, p)
+        assert ok == 1 and E.g1_from_raw96(bytes(out)) == E.g1_mul(s, 2 * k)
+    lib.h_g1r_affine_roundtrip(E.g1_to_raw96(pts[3]), out)
+    assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[3], 4)
