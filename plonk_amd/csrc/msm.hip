@@ -28,6 +28,14 @@
 
 namespace plonk {
 
+struct MsmBatch {
+  const Fr* scalars[MSM_MAX_BATCH];
+  uint64_t m[MSM_MAX_BATCH];
+  G1* out[MSM_MAX_BATCH];
+  int count;
+  uint64_t cap_m, cap_slices;
+};
+
 static constexpr uint32_t MSM_KSL = 32;   // entries per slice
 static constexpr uint32_t MSM_CHUNK = 16; // buckets per chunk in the weighted reduction
 
@@ -157,8 +165,12 @@ __global__ void srs_generate_kernel(Fr tau, Fr g_scalar, uint64_t n, G1Affine* _
 // digits, histogram, scatter
 // ---------------------------------------------------------------------------
 // digit word: 0 = skip; else (bucket_index + 1) | sign << 31, bucket_index = |d| - 1
-__global__ void msm_digits_kernel(const Fr* __restrict__ scalars, uint64_t m, uint32_t* __restrict__ digits,
-                                  uint32_t* __restrict__ counts) {
+__global__ void msm_digits_kernel(MsmBatch bt, uint32_t* __restrict__ digits_all, uint32_t* __restrict__ counts_all) {
+  const int kb = blockIdx.y;
+  const uint64_t m = bt.m[kb];
+  const Fr* __restrict__ scalars = bt.scalars[kb];
+  uint32_t* __restrict__ digits = digits_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint32_t* __restrict__ counts = counts_all + (uint64_t)kb * MSM_NB;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const Fr s = ld_fr_g(scalars + i).from_mont();
@@ -184,10 +196,14 @@ __global__ void msm_digits_kernel(const Fr* __restrict__ scalars, uint64_t m, ui
 // exclusive scans over NB entries, single workgroup of 1024 threads:
 //   offsets[b]   = sum_{b' < b} counts[b']
 //   slice_off[b] = sum_{b' < b} ceil(counts[b'] / KSL)
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts,
-                                                        uint32_t* __restrict__ offsets,
-                                                        uint32_t* __restrict__ slice_off,
-                                                        uint32_t* __restrict__ cursors) {
+__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts_all,
+                                                        uint32_t* __restrict__ offsets_all,
+                                                        uint32_t* __restrict__ slice_off_all,
+                                                        uint32_t* __restrict__ cursors_all) {
+  const uint32_t* __restrict__ counts = counts_all + (uint64_t)blockIdx.x * MSM_NB;
+  uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  uint32_t* __restrict__ cursors = cursors_all + (uint64_t)blockIdx.x * MSM_NB;
   __shared__ uint32_t sa[1024], sb[1024];
   constexpr uint32_t PER = MSM_NB / 1024;
   const uint32_t t = threadIdx.x;
@@ -225,9 +241,15 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restri
 }
 
 // entries[offsets[b] + k] = (w * srs_n + i) | sign
-__global__ void msm_scatter_kernel(const uint32_t* __restrict__ digits, uint64_t m, uint64_t srs_n,
-                                   const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursors,
-                                   uint32_t* __restrict__ entries) {
+__global__ void msm_scatter_kernel(MsmBatch bt, const uint32_t* __restrict__ digits_all, uint64_t srs_n,
+                                   const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ cursors_all,
+                                   uint32_t* __restrict__ entries_all) {
+  const int kb = blockIdx.y;
+  const uint64_t m = bt.m[kb];
+  const uint32_t* __restrict__ digits = digits_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  uint32_t* __restrict__ cursors = cursors_all + (uint64_t)kb * MSM_NB;
+  uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
 #pragma unroll
@@ -243,11 +265,16 @@ __global__ void msm_scatter_kernel(const uint32_t* __restrict__ digits, uint64_t
 // ---------------------------------------------------------------------------
 // accumulation
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __restrict__ table,
-                                                             const uint32_t* __restrict__ entries,
-                                                             const uint32_t* __restrict__ offsets,
-                                                             const uint32_t* __restrict__ slice_off,
-                                                             G1RSlot* __restrict__ partial) {
+__global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __restrict__ table, MsmBatch bt,
+                                                             const uint32_t* __restrict__ entries_all,
+                                                             const uint32_t* __restrict__ offsets_all,
+                                                             const uint32_t* __restrict__ slice_off_all,
+                                                             G1RSlot* __restrict__ partial_all) {
+  const int kb = blockIdx.y;
+  const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
+  G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nslices = slice_off[MSM_NB];
   if (s >= nslices) return;
@@ -279,9 +306,13 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
 // partial sums, then a 3-step LDS tree), so a bucket that attracted most of the scalars
 // (equal coefficients => equal digits) costs n/8 serial additions instead of n.
 static constexpr int BS_G = 8;
-__global__ void __launch_bounds__(128) msm_bucket_sum_kernel(const G1RSlot* __restrict__ partial,
-                                                             const uint32_t* __restrict__ slice_off,
-                                                             G1RSlot* __restrict__ buckets) {
+__global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
+                                                             const uint32_t* __restrict__ slice_off_all,
+                                                             G1RSlot* __restrict__ buckets_all) {
+  const int kb = blockIdx.y;
+  const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
+  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
+  G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
   __shared__ G1R sh[128];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t b = t / BS_G, g = t % BS_G;
@@ -300,7 +331,10 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(const G1RSlot* __re
 }
 
 // V_j = sum_{i < CHUNK} (CHUNK*j + i + 1) * B[CHUNK*j + i]
-__global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1RSlot* __restrict__ buckets, G1RSlot* __restrict__ chunk) {
+__global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1RSlot* __restrict__ buckets_all,
+                                                              G1RSlot* __restrict__ chunk_all) {
+  const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
+  G1RSlot* __restrict__ chunk = chunk_all + (uint64_t)blockIdx.y * (MSM_NB / MSM_CHUNK);
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= MSM_NB / MSM_CHUNK) return;
   G1R run = G1R::identity(), acc = G1R::identity();
@@ -315,7 +349,9 @@ __global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1RSlot* __r
 // sum of NB/CHUNK = 2048 chunk results -> one XYZZ point in the 12 x 32-bit form (192 B).
 // Affine normalisation (one Fp inversion) is left to the host / xyzz_to_affine97_kernel: a
 // single-lane Fermat inversion would add ~0.6 ms of serial latency to every MSM.
-__global__ void __launch_bounds__(256) msm_final_kernel(const G1RSlot* __restrict__ chunk, G1* __restrict__ out) {
+__global__ void __launch_bounds__(256) msm_final_kernel(MsmBatch bt, const G1RSlot* __restrict__ chunk_all) {
+  const G1RSlot* __restrict__ chunk = chunk_all + (uint64_t)blockIdx.x * (MSM_NB / MSM_CHUNK);
+  G1* __restrict__ out = bt.out[blockIdx.x];
   __shared__ G1R sh[256];
   const uint32_t t = threadIdx.x;
   constexpr uint32_t PER = (MSM_NB / MSM_CHUNK) / 256;
@@ -368,23 +404,24 @@ int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G
 
 int msm_reserve(Ctx* c, uint64_t m) {
   MsmWork& w = c->msm;
+  constexpr int KB = MSM_MAX_BATCH;
   if (!w.counts) {
-    HIP_TRY(hipMalloc((void**)&w.counts, sizeof(uint32_t) * MSM_NB));
-    HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1)));
-    HIP_TRY(hipMalloc((void**)&w.cursors, sizeof(uint32_t) * MSM_NB));
-    HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1)));
-    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB));
-    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK)));
+    HIP_TRY(hipMalloc((void**)&w.counts, sizeof(uint32_t) * MSM_NB * KB));
+    HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1) * KB));
+    HIP_TRY(hipMalloc((void**)&w.cursors, sizeof(uint32_t) * MSM_NB * KB));
+    HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
+    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB * KB));
+    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK) * KB));
     HIP_TRY(hipMalloc((void**)&w.result, 256));
     HIP_TRY(hipHostMalloc((void**)&w.result_host, 256, hipHostMallocDefault));
   }
   if (m > w.cap_m) {
     if (w.digits) { HIP_TRY(hipFree(w.digits)); HIP_TRY(hipFree(w.entries)); HIP_TRY(hipFree(w.partial)); }
     const uint64_t cap = m;
-    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap));
-    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap));
+    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap * KB));
+    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));
     w.cap_slices = (MSM_W * cap) / MSM_KSL + MSM_NB + 1;
-    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices));
+    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
     w.cap_m = cap;
   }
   return PLONK_OK;
@@ -393,40 +430,59 @@ int msm_reserve(Ctx* c, uint64_t m) {
 void prof_begin(Ctx* c, int slot);
 void prof_end(Ctx* c, int slot);
 
-int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {
-  if (m == 0) {
-    hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, c->stream, out_dev);
+// `count` (<= MSM_MAX_BATCH) independent MSMs over the same bases, launched together: the
+// latency-bound reduction kernels run once per group instead of once per commitment
+// (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
+int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev) {
+  if (count <= 0) return PLONK_OK;
+  if (count > MSM_MAX_BATCH) return PLONK_ERR_ARG;
+  uint64_t mmax = 0;
+  for (int k = 0; k < count; ++k) {
+    if (m[k] > c->srs_n) return PLONK_ERR_DEGREE;
+    if (m[k] > mmax) mmax = m[k];
+  }
+  hipStream_t st = c->stream;
+  if (mmax == 0) {
+    for (int k = 0; k < count; ++k) hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, st, out_dev[k]);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
   }
   if (!c->srs_table) return PLONK_ERR_NO_SRS;
-  if (m > c->srs_n) return PLONK_ERR_DEGREE;
-  int rc = msm_reserve(c, m);
+  int rc = msm_reserve(c, mmax);
   if (rc) return rc;
   MsmWork& w = c->msm;
-  hipStream_t st = c->stream;
+  MsmBatch bt{};
+  bt.count = count;
+  bt.cap_m = w.cap_m;
+  bt.cap_slices = w.cap_slices;
+  for (int k = 0; k < count; ++k) { bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k]; }
   prof_begin(c, 2);
-  HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * MSM_NB, st));
-  const uint32_t gb = (uint32_t)((m + 255) / 256);
-  hipLaunchKernelGGL(msm_digits_kernel, dim3(gb), dim3(256), 0, st, scalars_dev, m, w.digits, w.counts);
-  hipLaunchKernelGGL(msm_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb), dim3(256), 0, st, w.digits, m, c->srs_n, w.offsets, w.cursors, w.entries);
+  HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * MSM_NB * count, st));
+  const uint32_t gb = (uint32_t)((mmax + 255) / 256);
+  hipLaunchKernelGGL(msm_digits_kernel, dim3(gb, count), dim3(256), 0, st, bt, w.digits, w.counts);
+  hipLaunchKernelGGL(msm_scan_kernel, dim3(count), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors);
+  hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb, count), dim3(256), 0, st, bt, w.digits, c->srs_n, w.offsets, w.cursors,
+                     w.entries);
   prof_end(c, 2);
   // upper bound on slices known on the host: no device->host sync on the path
-  const uint64_t max_slices = (MSM_W * m) / MSM_KSL + MSM_NB + 1;
+  const uint64_t max_slices = (MSM_W * mmax) / MSM_KSL + MSM_NB + 1;
   prof_begin(c, 1);
-  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128)), dim3(128), 0, st,
-                     (const G1AffineR*)c->srs_table, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
+  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
+                     (const G1AffineR*)c->srs_table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
   prof_begin(c, 2);
-  hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB * BS_G / 128), dim3(128), 0, st, (const G1RSlot*)w.partial,
-                     w.slice_off, (G1RSlot*)w.buckets);
-  hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64), dim3(64), 0, st, (const G1RSlot*)w.buckets,
-                     (G1RSlot*)w.chunk);
-  hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, (const G1RSlot*)w.chunk, out_dev);
+  hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB * BS_G / 128, count), dim3(128), 0, st, bt,
+                     (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
+  hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64, count), dim3(64), 0, st,
+                     (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+  hipLaunchKernelGGL(msm_final_kernel, dim3(count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk);
   prof_end(c, 2);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
+}
+
+int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {
+  return msm_batch_device(c, &scalars_dev, &m, 1, &out_dev);
 }
 
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev) {

@@ -37,6 +37,7 @@ struct NttTables {
 static constexpr int MSM_C = 16;
 static constexpr int MSM_W = 16;
 static constexpr uint32_t MSM_NB = 1u << (MSM_C - 1);   // buckets 1..32768
+static constexpr int MSM_MAX_BATCH = 4;                  // commitments per group launch
 
 struct MsmWork {   // per-stream scratch, grown on demand
   uint64_t cap_m = 0;
@@ -85,6 +86,7 @@ void ntt_plan(uint32_t L, int r[3], int* npass);
 // msm.hip
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
+int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev);
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
 // host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);

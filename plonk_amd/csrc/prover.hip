@@ -48,7 +48,8 @@ struct Prover {
   Fr* tmp8 = nullptr;              // [n8] NTT scratch
   Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
   Fr* agg = nullptr;               // [np] linear combination
-  Fr* wit = nullptr;               // [np] opening witness polynomial
+  Fr* wit = nullptr;               // [np] opening witness polynomial W_z
+  Fr* wit2 = nullptr;              // [np] W_zw
   Fr* scratch = nullptr;           // [2 * np] (perm num / den, ruffini scratch)
   Fr* totals = nullptr;            // scan block totals
   Fr* evpart = nullptr;            // eval partials
@@ -159,14 +160,22 @@ static constexpr int RES_STRIDE = 256;
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
 // [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
 // fetch_commitments.  With world == 1 this is the whole MSM.
-static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) {
-  if (m > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
-  const uint64_t lo = p->shard_lo;
-  uint64_t hi = lo + p->c->srs_n;
-  if (hi > m) hi = m;
-  const uint64_t cnt = hi > lo ? hi - lo : 0;
-  return msm_device(p->c, scalars + (cnt ? lo : 0), cnt, (G1*)(p->res + RES_STRIDE * slot));
+static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int count, int first_slot) {
+  const Fr* sc[MSM_MAX_BATCH];
+  uint64_t cnt[MSM_MAX_BATCH];
+  G1* out[MSM_MAX_BATCH];
+  for (int k = 0; k < count; ++k) {
+    if (m[k] > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
+    const uint64_t lo = p->shard_lo;
+    uint64_t hi = lo + p->c->srs_n;
+    if (hi > m[k]) hi = m[k];
+    cnt[k] = hi > lo ? hi - lo : 0;
+    sc[k] = scalars[k] + (cnt[k] ? lo : 0);
+    out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
+  }
+  return msm_batch_device(p->c, sc, cnt, count, out);
 }
+static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) { return msm_group(p, &scalars, &m, 1, slot); }
 // Bring `count` results to the host, all-gather the per-rank partial sums (EC addition is not
 // an RCCL reduction, so the "bucket-sum all-reduce" is an all-gather + local add), normalise
 // to affine on the host (one Fp inversion each) and compress.
@@ -202,7 +211,7 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
 static void prover_free(Prover* p) {
   if (!p) return;
   void* bufs[] = {p->polys, p->evals8, p->sigma_n, p->wires, p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tmp8,
-                  p->tparts, p->agg, p->wit, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
+                  p->tparts, p->agg, p->wit, p->wit2, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (p->res_host) (void)hipHostFree(p->res_host);
@@ -254,6 +263,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   ALLOC(p->tparts, 3 * np);
   ALLOC(p->agg, np);
   ALLOC(p->wit, np);
+  ALLOC(p->wit2, np);
   ALLOC(p->scratch, 2 * np);
   ALLOC(p->totals, 4096);
   p->ev_max_blocks = (uint32_t)((np + 4095) / 4096);
@@ -312,7 +322,13 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   if (d->vk_commitments) {
     memcpy(p->vk, d->vk_commitments, 15 * 48);
   } else {   // Compiler::preprocess commits (compiler.rs:213-232); zero polynomial -> identity
-    for (int k = 0; k < P_COUNT; ++k) PTRY(msm_to(p, p->polys + k * np, p->poly_len[k], k));
+    for (int k0 = 0; k0 < P_COUNT; k0 += MSM_MAX_BATCH) {
+      const int cnt = P_COUNT - k0 < MSM_MAX_BATCH ? P_COUNT - k0 : MSM_MAX_BATCH;
+      const Fr* sc[MSM_MAX_BATCH];
+      uint64_t ms[MSM_MAX_BATCH];
+      for (int k = 0; k < cnt; ++k) { sc[k] = p->polys + (k0 + k) * np; ms[k] = p->poly_len[k0 + k]; }
+      PTRY(msm_group(p, sc, ms, cnt, k0));
+    }
     PTRY(fetch_commitments(p, 0, 15, p->vk));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -348,7 +364,11 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_fill_zero(c, wp + n, np - n));
     PTRY(poly_blind(c, wp, n, ba));
   }
-  for (int k = 0; k < 4; ++k) PTRY(msm_to(p, p->wpoly + k * np, n + 2, k));
+  {
+    const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
+    const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
+    PTRY(msm_group(p, sc, ms, 4, 0));   // commit_polynomials (prover.rs:187-210) as one group launch
+  }
   PTRY(fetch_commitments(p, 0, 4, comm));
   tr.append_commitment("a_comm", comm[0]);
   tr.append_commitment("b_comm", comm[1]);
@@ -449,10 +469,11 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   }
   Fr* t4 = p->tbuf + 3 * n;
   const uint64_t t4_len = len4 ? len4 : 1;                 // t_fourth[0] -= b14 even when the tail is empty
-  PTRY(msm_to(p, p->tparts, n + 1, 5));
-  PTRY(msm_to(p, p->tparts + np, n + 1, 6));
-  PTRY(msm_to(p, p->tparts + 2 * np, n + 1, 7));
-  PTRY(msm_to(p, t4, t4_len, 8));
+  {
+    const Fr* sc[4] = {p->tparts, p->tparts + np, p->tparts + 2 * np, t4};
+    const uint64_t ms[4] = {n + 1, n + 1, n + 1, t4_len};
+    PTRY(msm_group(p, sc, ms, 4, 5));
+  }
   PTRY(fetch_commitments(p, 5, 4, comm + 5));
   tr.append_commitment("t_low_comm", comm[5]);
   tr.append_commitment("t_mid_comm", comm[6]);
@@ -578,7 +599,8 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const bool z_zero = z_ch.is_zero();
   PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : z_ch.inv(), p->scratch, p->totals));
   if (z_zero) return PLONK_ERR_STATE;   // probability 2^-255; (X - 0) division is a shift — not worth a code path
-  PTRY(msm_to(p, p->wit, np - 2, 9));
+  // W_z's commitment is not absorbed before v_w is drawn (prover.rs:727-730), so both opening
+  // witnesses can be committed as one group.
   const Fr v_w = tr.challenge_scalar("v_w_challenge");
   {
     LinCombArgs la;
@@ -593,8 +615,12 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_lincomb(c, la));
   }
   if (zw.is_zero()) return PLONK_ERR_STATE;
-  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, zw, zw.inv(), p->scratch, p->totals));
-  PTRY(msm_to(p, p->wit, np - 2, 10));
+  PTRY(poly_ruffini(c, p->agg, p->wit2, np - 1, zw, zw.inv(), p->scratch, p->totals));
+  {
+    const Fr* sc[2] = {p->wit, p->wit2};
+    const uint64_t ms[2] = {np - 2, np - 2};
+    PTRY(msm_group(p, sc, ms, 2, 9));
+  }
   PTRY(fetch_commitments(p, 9, 2, comm + 9));
 
   // ---- Proof::to_bytes (proof.rs:137-162, linearization_poly.rs:98-124)
