@@ -141,6 +141,8 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
     NttTables* t = kv.second;
     (void)hipFree(t->tw_lo); (void)hipFree(t->tw_hi); (void)hipFree(t->tw_lo_scaled);
     (void)hipFree(t->w512); (void)hipFree(t->g_lo); (void)hipFree(t->g_hi);
+    (void)hipFree(t->tw_lo29); (void)hipFree(t->tw_hi29); (void)hipFree(t->tw_lo_scaled29);
+    (void)hipFree(t->w512_29); (void)hipFree(t->g_lo29); (void)hipFree(t->g_hi29);
     delete t;
   }
   (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_tmp); (void)hipFree(c.srs_table);

@@ -15,11 +15,15 @@
 //   loads/stores are runs of C (>= 4) consecutive 32-byte elements, the
 //   transposed store writes runs of R1 consecutive elements.
 //
-//   Inside a tile each thread keeps 8 elements (64 VGPRs) and performs radix-8
-//   decimation-in-frequency rounds in registers; rounds exchange data through LDS
-//   kept limb-planar (8 planes of u32) so DS traffic is plain 4-byte accesses.
-//   Small twiddles (w_512^e) sit in LDS; the inter-pass twiddle w_N^e is
-//   TWLO[e & 8191] * TWHI[e >> 13].
+//   Inside a tile each thread keeps 8 elements and performs radix-8 decimation-in-frequency
+//   rounds in registers, in the reduced-radix lazy form of fr29.cuh (9 x 29-bit limbs: a
+//   butterfly is ~290 VALU instructions, 162 of them v_mad_u64_u32, instead of ~890 with
+//   32-bit limbs and carry chains).  Rounds exchange data through LDS kept limb-planar
+//   (9 planes of u32, 72 KiB => two workgroups per CU) so DS traffic is plain 4-byte
+//   accesses.  Small twiddles (w_512^e) come from an L1-resident table; the inter-pass
+//   twiddle w_N^e is TWLO[e & 8191] * TWHI[e >> 13].  Tables hold w * 2^261 (fr29.cuh) so
+//   data stays in the reference's Montgomery domain; elements are converted to canonical
+//   32-bit limbs only when a pass stores to HBM.
 //
 // HBM traffic: 64*N bytes per pass (32 read + 32 written), i.e. 128*N / 192*N
 // for the 2- / 3-pass plans against the algorithmic 64*N.  The kernel is bound by
@@ -28,6 +32,7 @@
 // tests/ntt_model.py mirrors the index arithmetic below (same names) and is
 // checked against the oracle on CPU.
 #include "plonk_internal.hpp"
+#include "fr29.cuh"
 
 namespace plonk {
 
@@ -48,17 +53,17 @@ struct NttPass {
   // inter-pass twiddle: value *= w_N^(k * ((cg >> tw_shr) << tw_shr))
   int tw_mode;
   uint32_t tw_shr;
-  const Fr* tw_lo;
-  const Fr* tw_hi;
+  const Fr29Slot* tw_lo;
+  const Fr29Slot* tw_hi;
   // first pass: zero beyond in_len, optional coset scale g^i
   uint64_t in_len;
   int pre_coset;
   // last pass: 0 none, 1 multiply by `scale`, 2 multiply by GLO[o & 1023] * GHI[o >> 10]
   int post_mode;
-  Fr scale;
-  const Fr* g_lo;
-  const Fr* g_hi;
-  const Fr* w512;   // w_512^e, e < 256 (direction specific)
+  Fr29 scale;
+  const Fr29Slot* g_lo;
+  const Fr29Slot* g_hi;
+  const Fr29Slot* w512;   // w_512^e, e < 256 (direction specific), L1-resident
 };
 
 __device__ __forceinline__ Fr ld_fr(const Fr* p) {
@@ -75,16 +80,32 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-// LDS planes: data[l * 2048 + idx], wtab[l * 256 + e]
-__device__ __forceinline__ Fr lds_get(const uint32_t* base, int stride, int idx) {
-  Fr r;
+// LDS planes: data[l * 2048 + idx]
+__device__ __forceinline__ Fr29 lds_get(const uint32_t* base, int stride, int idx) {
+  Fr29 r;
 #pragma unroll
-  for (int l = 0; l < 8; ++l) r.l[l] = base[l * stride + idx];
+  for (int l = 0; l < Fr29::N; ++l) r.l[l] = base[l * stride + idx];
   return r;
 }
-__device__ __forceinline__ void lds_put(uint32_t* base, int stride, int idx, const Fr& v) {
+__device__ __forceinline__ void lds_put(uint32_t* base, int stride, int idx, const Fr29& v) {
 #pragma unroll
-  for (int l = 0; l < 8; ++l) base[l * stride + idx] = v.l[l];
+  for (int l = 0; l < Fr29::N; ++l) base[l * stride + idx] = v.l[l];
+}
+__device__ __forceinline__ Fr29 ld_tw(const Fr29Slot* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t c = p->w[8];
+  Fr29 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c;
+  return r;
+}
+__device__ __forceinline__ void st_tw(Fr29Slot* p, const Fr29& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+  q[2] = make_uint4(v.l[8], 0u, 0u, 0u);
 }
 
 // tests/ntt_model.py: elem_index
@@ -100,30 +121,30 @@ __device__ __forceinline__ int elem_index(int t, int e) {
 
 // One DIF stage on local bit LB of a register round (global row bit LO + LB).
 template <int RLOG, int LO, int LB>
-__device__ __forceinline__ void dif_stage(Fr (&v)[8], int rlow_thread, const uint32_t* wtab) {
+__device__ __forceinline__ void dif_stage(Fr29 (&v)[8], int rlow_thread, const Fr29Slot* __restrict__ wtab) {
   constexpr int bitpos = LO + LB;
 #pragma unroll
   for (int x = 0; x < (1 << LB); ++x) {
-    Fr w;
+    Fr29 w;
     if constexpr (bitpos > 0) {
       const int rlow = rlow_thread | (x << LO);          // row & (2^bitpos - 1)
-      w = lds_get(wtab, 256, rlow << (8 - bitpos));
+      w = ld_tw(wtab + (rlow << (8 - bitpos)));
     }
 #pragma unroll
     for (int y = 0; y < (8 >> (LB + 1)); ++y) {         // bits above LB (incl. extra groups)
       const int e = (y << (LB + 1)) | x;
       const int e2 = e | (1 << LB);
-      Fr a = v[e], b = v[e2];
-      v[e] = a + b;
-      Fr d = a - b;
-      if constexpr (bitpos > 0) v[e2] = d * w; else v[e2] = d;
+      const Fr29 a = v[e], b = v[e2];
+      v[e] = Fr29::add_csub(a, b);
+      if constexpr (bitpos > 0) v[e2] = Fr29::mul(Fr29::sub_lazy(a, b), w);
+      else v[e2] = Fr29::sub_reduce(a, b);
     }
   }
 }
 
 // One register round: RB DIF stages on the row bits [LO, LO+RB), top bit first.
 template <int RLOG, int LO, int RB>
-__device__ __forceinline__ void dif_round(Fr (&v)[8], int t, const uint32_t* wtab) {
+__device__ __forceinline__ void dif_round(Fr29 (&v)[8], int t, const Fr29Slot* __restrict__ wtab) {
   constexpr int CLOG = TILE_LOG - RLOG;
   const int rlow_thread = (LO > 0) ? ((t >> CLOG) & ((1 << LO) - 1)) : 0;
   if constexpr (RB >= 3) dif_stage<RLOG, LO, 2>(v, rlow_thread, wtab);
@@ -142,7 +163,7 @@ struct RoundGeom {
 template <int RLOG, int R_IDX, int NR>
 struct Rounds {
   // rounds R_IDX .. NR-1; on entry v holds round R_IDX's elements
-  __device__ static __forceinline__ void run(Fr (&v)[8], int t, uint32_t* data, const uint32_t* wtab) {
+  __device__ static __forceinline__ void run(Fr29 (&v)[8], int t, uint32_t* data, const Fr29Slot* __restrict__ wtab) {
     using G = RoundGeom<RLOG, R_IDX>;
     dif_round<RLOG, G::LO, G::RB>(v, t, wtab);
     if constexpr (R_IDX + 1 < NR) {
@@ -157,9 +178,14 @@ struct Rounds {
   }
 };
 
-__device__ __forceinline__ Fr two_level(const Fr* lo, const Fr* hi, uint64_t e, int lobits, bool use_hi) {
+__device__ __forceinline__ Fr two_level_fr(const Fr* lo, const Fr* hi, uint64_t e, int lobits, bool use_hi) {
   Fr w = ld_fr(lo + (e & ((1ull << lobits) - 1)));
   if (use_hi) w = w * ld_fr(hi + (e >> lobits));
+  return w;
+}
+__device__ __forceinline__ Fr29 two_level(const Fr29Slot* lo, const Fr29Slot* hi, uint64_t e, int lobits, bool use_hi) {
+  Fr29 w = ld_tw(lo + (e & ((1ull << lobits) - 1)));
+  if (use_hi) w = Fr29::mul(w, ld_tw(hi + (e >> lobits)));
   return w;
 }
 
@@ -169,19 +195,14 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
   constexpr int C = 1 << CLOG;
   constexpr int NR = (RLOG + 2) / 3;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* data = smem;                       // 8 * 2048 u32
-  uint32_t* wtab = smem + 8 * (1 << TILE_LOG);  // 8 * 256 u32
+  uint32_t* data = smem;                       // 9 * 2048 u32
+  const Fr29Slot* __restrict__ wtab = p.w512;
   const int t = threadIdx.x;
   const uint64_t cg0 = (uint64_t)blockIdx.x * C;
 
-  {  // small twiddles -> LDS (planar)
-    Fr w = ld_fr(p.w512 + t);
-    lds_put(wtab, 256, t, w);
-  }
-
   // ---- load round 0 operands straight from HBM
   using G0 = RoundGeom<RLOG, 0>;
-  Fr v[8];
+  Fr29 v[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int idx = elem_index<G0::POS, G0::RB>(t, e);
@@ -189,14 +210,13 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
     const uint64_t cg = cg0 + (idx & (C - 1));
     const uint64_t gi = row * p.in_rs + (cg >> p.in_hshift) * p.in_hs + (cg & ((1ull << p.in_hshift) - 1));
     if (gi < p.in_len) {
-      Fr x = ld_fr(p.src + gi);
-      if (p.pre_coset) x = x * two_level(p.g_lo, p.g_hi, gi, GLO_BITS, true);
+      Fr29 x = Fr29::from_fr(ld_fr(p.src + gi));
+      if (p.pre_coset) x = Fr29::mul(x, two_level(p.g_lo, p.g_hi, gi, GLO_BITS, true));
       v[e] = x;
     } else {
-      v[e] = Fr::zero();
+      v[e] = Fr29::zero();
     }
   }
-  __syncthreads();   // wtab visible
   Rounds<RLOG, 0, NR>::run(v, t, data, wtab);
 
   // ---- epilogue: inter-pass twiddle / scaling, then store
@@ -210,16 +230,16 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
       const uint32_t prow = idx >> CLOG;
       const uint64_t k = __brev(prow) >> (32 - RLOG);
       const uint64_t cg = cg0 + (idx & (C - 1));
-      Fr x = v[e];
+      Fr29 x = v[e];
       if (p.tw_mode) {
         const uint64_t twcol = (cg >> p.tw_shr) << p.tw_shr;
-        x = x * two_level(p.tw_lo, p.tw_hi, (k * twcol) & nmask, TWLO_BITS, use_hi);
+        x = Fr29::mul(x, two_level(p.tw_lo, p.tw_hi, (k * twcol) & nmask, TWLO_BITS, use_hi));
       }
       const uint64_t o = k * p.out_rs + (cg >> p.out_hshift) * p.out_hs +
                          (cg & ((1ull << p.out_hshift) - 1)) * p.out_ls;
-      if (p.post_mode == 1) x = x * p.scale;
-      else if (p.post_mode == 2) x = x * two_level(p.g_lo, p.g_hi, o, GLO_BITS, true);
-      st_fr(p.dst + o, x);
+      if (p.post_mode == 1) x = Fr29::mul(x, p.scale);
+      else if (p.post_mode == 2) x = Fr29::mul(x, two_level(p.g_lo, p.g_hi, o, GLO_BITS, true));
+      st_fr(p.dst + o, x.to_fr());
     }
   } else {
     constexpr int R = 1 << RLOG;
@@ -231,10 +251,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
       const uint32_t k = __brev(prow) >> (32 - RLOG);
       const int col = idx & (C - 1);
       const uint64_t cg = cg0 + col;
-      Fr x = v[e];
+      Fr29 x = v[e];
       if (p.tw_mode) {
         const uint64_t twcol = (cg >> p.tw_shr) << p.tw_shr;
-        x = x * two_level(p.tw_lo, p.tw_hi, ((uint64_t)k * twcol) & nmask, TWLO_BITS, use_hi);
+        x = Fr29::mul(x, two_level(p.tw_lo, p.tw_hi, ((uint64_t)k * twcol) & nmask, TWLO_BITS, use_hi));
       }
       lds_put(data, 1 << TILE_LOG, col * R + (int)k, x);
     }
@@ -245,10 +265,10 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
       const int col = u >> RLOG;
       const uint64_t k = u & (R - 1);
       const uint64_t cg = cg0 + col;
-      Fr x = lds_get(data, 1 << TILE_LOG, u);
+      const Fr29 x = lds_get(data, 1 << TILE_LOG, u);
       const uint64_t o = k * p.out_rs + (cg >> p.out_hshift) * p.out_hs +
                          (cg & ((1ull << p.out_hshift) - 1)) * p.out_ls;
-      st_fr(p.dst + o, x);
+      st_fr(p.dst + o, x.to_fr());
     }
   }
 }
@@ -275,7 +295,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_small_kernel(NttSmall p) {
     Fr x = Fr::zero();
     if (s < p.in_len) {
       x = ld_fr(p.src + s);
-      if (p.pre_coset) x = x * two_level(p.g_lo, p.g_hi, s, GLO_BITS, true);
+      if (p.pre_coset) x = x * two_level_fr(p.g_lo, p.g_hi, s, GLO_BITS, true);
     }
     buf[i] = x;
   }
@@ -297,7 +317,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_small_kernel(NttSmall p) {
   for (uint32_t i = threadIdx.x; i < N; i += blockDim.x) {
     Fr x = buf[i];
     if (p.post_mode) x = x * p.scale;                                                    // n^-1
-    if (p.post_mode == 2) x = x * two_level(p.g_lo, p.g_hi, i, GLO_BITS, true);          // g^-i
+    if (p.post_mode == 2) x = x * two_level_fr(p.g_lo, p.g_hi, i, GLO_BITS, true);       // g^-i
     st_fr(p.dst + i, x);
   }
 }
@@ -307,6 +327,13 @@ __global__ void pow_table_kernel(Fr* out, Fr base, Fr first, uint32_t count) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   st_fr(out + i, first * base.pow_u64(i));
+}
+
+// same, stored as w * 2^261 in 29-bit limbs (fr29.cuh)
+__global__ void pow_table29_kernel(Fr29Slot* out, Fr base, Fr first, uint32_t count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  st_tw(out + i, Fr29::twiddle_from_fr(first * base.pow_u64(i)));
 }
 
 // ---------------------------------------------------------------------------
@@ -334,6 +361,13 @@ static int build_pow_table(Ctx* c, Fr** out, const Fr& base, const Fr& first, ui
   return PLONK_OK;
 }
 
+static int build_pow_table29(Ctx* c, Fr29Slot** out, const Fr& base, const Fr& first, uint32_t count) {
+  HIP_TRY(hipMalloc((void**)out, sizeof(Fr29Slot) * (size_t)count));
+  hipLaunchKernelGGL(pow_table29_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, *out, base, first, count);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
 int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
   std::lock_guard<std::mutex> lk(c->table_mu);
   const uint32_t key = (L << 1) | (inverse ? 1u : 0u);
@@ -356,6 +390,15 @@ int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
   const uint32_t ghi_n = L > (uint32_t)GLO_BITS ? (1u << (L - GLO_BITS)) : 1u;
   if ((rc = build_pow_table(c, &tb->g_lo, g, Fr::one(), 1u << GLO_BITS))) return rc;
   if ((rc = build_pow_table(c, &tb->g_hi, g.pow_u64(1ull << GLO_BITS), Fr::one(), ghi_n))) return rc;
+  // the same tables as w * 2^261 / 29-bit limbs for the pass kernels
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->tw_lo29, w, Fr::one(), lo_n))) return rc;
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->tw_hi29, w.pow_u64(1ull << TWLO_BITS), Fr::one(), hi_n))) return rc;
+  if (inverse) {
+    if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->tw_lo_scaled29, w, n_inv, lo_n))) return rc;
+  }
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->w512_29, host_omega(9, inverse), Fr::one(), 256))) return rc;
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->g_lo29, g, Fr::one(), 1u << GLO_BITS))) return rc;
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->g_hi29, g.pow_u64(1ull << GLO_BITS), Fr::one(), ghi_n))) return rc;
   tb->n_inv = n_inv;
   c->ntt_tables[key] = tb;
   *out = tb;
@@ -364,7 +407,7 @@ int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
 
 template <int RLOG>
 static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint32_t nblocks) {
-  constexpr size_t smem = (8 * (1 << TILE_LOG) + 8 * 256) * sizeof(uint32_t);
+  constexpr size_t smem = (size_t)Fr29::N * (1 << TILE_LOG) * sizeof(uint32_t);
   if (transpose) {
     static bool attr_t = false;
     if (!attr_t) { (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<RLOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_t = true; }
@@ -421,10 +464,11 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.in_rs = N >> r[0]; p.in_hshift = 63; p.in_hs = 0;
     p.out_rs = 1; p.out_hshift = (uint32_t)rl; p.out_hs = R1; p.out_ls = N >> rl;
     p.tw_mode = 1; p.tw_shr = 0;
-    p.tw_lo = inverse ? tb->tw_lo_scaled : tb->tw_lo;   // n^-1 folded into pass A's twiddles
-    p.tw_hi = tb->tw_hi;
+    p.tw_lo = (const Fr29Slot*)(inverse ? tb->tw_lo_scaled29 : tb->tw_lo29);   // n^-1 folded into pass A's twiddles
+    p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
     p.in_len = in_len; p.pre_coset = (coset && !inverse) ? 1 : 0;
-    p.post_mode = 0; p.g_lo = tb->g_lo; p.g_hi = tb->g_hi; p.w512 = tb->w512;
+    p.post_mode = 0; p.g_lo = (const Fr29Slot*)tb->g_lo29; p.g_hi = (const Fr29Slot*)tb->g_hi29;
+    p.w512 = (const Fr29Slot*)tb->w512_29;
     const uint32_t nb = (uint32_t)((N >> r[0]) >> (TILE_LOG - r[0]));
     if ((rc = launch_pass_rt(c, r[0], p, true, nb))) return rc;
   }
@@ -435,9 +479,9 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.in_rs = R1; p.in_hshift = (uint32_t)r[0]; p.in_hs = R1 << r[1];
     p.out_rs = R1; p.out_hshift = (uint32_t)r[0]; p.out_hs = R1 << r[1]; p.out_ls = 1;
     p.tw_mode = 1; p.tw_shr = (uint32_t)r[0];
-    p.tw_lo = tb->tw_lo; p.tw_hi = tb->tw_hi;
-    p.in_len = N; p.pre_coset = 0; p.post_mode = 0; p.w512 = tb->w512;
-    p.g_lo = tb->g_lo; p.g_hi = tb->g_hi;
+    p.tw_lo = (const Fr29Slot*)tb->tw_lo29; p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
+    p.in_len = N; p.pre_coset = 0; p.post_mode = 0; p.w512 = (const Fr29Slot*)tb->w512_29;
+    p.g_lo = (const Fr29Slot*)tb->g_lo29; p.g_hi = (const Fr29Slot*)tb->g_hi29;
     const uint32_t nb = (uint32_t)((N >> r[1]) >> (TILE_LOG - r[1]));
     if ((rc = launch_pass_rt(c, r[1], p, false, nb))) return rc;
   }
@@ -447,10 +491,11 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.src = tmp; p.dst = dst; p.logN = L;
     p.in_rs = N >> rl; p.in_hshift = 63; p.in_hs = 0;
     p.out_rs = N >> rl; p.out_hshift = 63; p.out_hs = 0; p.out_ls = 1;
-    p.tw_mode = 0; p.tw_shr = 0; p.tw_lo = tb->tw_lo; p.tw_hi = tb->tw_hi;
+    p.tw_mode = 0; p.tw_shr = 0; p.tw_lo = (const Fr29Slot*)tb->tw_lo29; p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
     p.in_len = N; p.pre_coset = 0;
     p.post_mode = (inverse && coset) ? 2 : 0;   // n^-1 already folded in pass A
-    p.scale = tb->n_inv; p.g_lo = tb->g_lo; p.g_hi = tb->g_hi; p.w512 = tb->w512;
+    p.scale = Fr29::zero(); p.g_lo = (const Fr29Slot*)tb->g_lo29; p.g_hi = (const Fr29Slot*)tb->g_hi29;
+    p.w512 = (const Fr29Slot*)tb->w512_29;
     const uint32_t nb = (uint32_t)((N >> rl) >> (TILE_LOG - rl));
     if ((rc = launch_pass_rt(c, rl, p, false, nb))) return rc;
   }

@@ -30,6 +30,13 @@ struct NttTables {
   Fr* w512 = nullptr;          // w_512^e, e < 256
   Fr* g_lo = nullptr;          // g^i (fwd) or g^-i (inv), i < 1024
   Fr* g_hi = nullptr;          // g^(i << 10)
+  // the same as w * 2^261 in 29-bit limbs (48-byte slots, fr29.cuh) for the pass kernels
+  void* tw_lo29 = nullptr;
+  void* tw_hi29 = nullptr;
+  void* tw_lo_scaled29 = nullptr;
+  void* w512_29 = nullptr;
+  void* g_lo29 = nullptr;
+  void* g_hi29 = nullptr;
   Fr n_inv;
 };
 

@@ -81,3 +81,38 @@ int h_g1r_affine_roundtrip(const uint8_t* pt, uint8_t* o) {
   G1Affine r; r.x = x.to_fp(); r.y = y.to_fp(); memcpy(o, &r, 96); return 1;
 }
 }
+// ---- reduced-radix Fr (fr29.cuh) ----
+#include "../../plonk_amd/csrc/fr29.cuh"
+extern "C" {
+// DIF butterfly on Montgomery (R = 2^256) inputs: out0 = a + b, out1 = (a - b) * w
+void h_fr29_butterfly(const uint32_t* a, const uint32_t* b, const uint32_t* w, uint32_t* o0, uint32_t* o1) {
+  Fr x, y, t; memcpy(&x, a, 32); memcpy(&y, b, 32); memcpy(&t, w, 32);
+  Fr29 A = Fr29::from_fr(x), Bv = Fr29::from_fr(y), W = Fr29::twiddle_from_fr(t);
+  Fr r0 = Fr29::add_csub(A, Bv).to_fr();
+  Fr r1 = Fr29::mul(Fr29::sub_lazy(A, Bv), W).to_fr();
+  memcpy(o0, &r0, 32); memcpy(o1, &r1, 32);
+}
+// 9 chained stages on a vector of 2 elements: exercises the lazy ranges (sum path and product path)
+void h_fr29_chain(const uint32_t* a, const uint32_t* b, const uint32_t* w, int stages, uint32_t* o0, uint32_t* o1) {
+  Fr x, y, t; memcpy(&x, a, 32); memcpy(&y, b, 32); memcpy(&t, w, 32);
+  Fr29 A = Fr29::from_fr(x), Bv = Fr29::from_fr(y), W = Fr29::twiddle_from_fr(t);
+  for (int s = 0; s < stages; ++s) {
+    Fr29 n0 = Fr29::add_csub(A, Bv);
+    Fr29 n1 = Fr29::mul(Fr29::sub_lazy(A, Bv), W);
+    A = n0; Bv = n1;
+  }
+  Fr r0 = A.to_fr(), r1 = Bv.to_fr();
+  memcpy(o0, &r0, 32); memcpy(o1, &r1, 32);
+}
+void h_fr29_mul2(const uint32_t* a, const uint32_t* w1, const uint32_t* w2, uint32_t* o) {   // a * (w1 * w2)
+  Fr x, t1, t2; memcpy(&x, a, 32); memcpy(&t1, w1, 32); memcpy(&t2, w2, 32);
+  Fr29 W = Fr29::mul(Fr29::twiddle_from_fr(t1), Fr29::twiddle_from_fr(t2));
+  Fr r = Fr29::mul(Fr29::from_fr(x), W).to_fr(); memcpy(o, &r, 32);
+}
+}
+extern "C" void h_fr29_sub_reduce(const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  Fr x, y; memcpy(&x, a, 32); memcpy(&y, b, 32);
+  // operands first pushed to the top of the lazy range: (x + 0) via add_csub keeps them, so use doubled values
+  Fr29 A = Fr29::from_fr(x), Bv = Fr29::from_fr(y);
+  Fr r = Fr29::sub_reduce(Fr29::add_csub(A, A), Fr29::add_csub(Bv, Bv)).to_fr(); memcpy(o, &r, 32);
+}

@@ -18,7 +18,7 @@ Q, P = E.Q, E.P
 def lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
-    hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h) for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh")]
+    hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h) for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -168,3 +168,34 @@ def test_g1_xyzz_over_fp28_matches_oracle(lib):
         assert ok == 1 and E.g1_from_raw96(bytes(out)) == E.g1_mul(s, 2 * k)
     lib.h_g1r_affine_roundtrip(E.g1_to_raw96(pts[3]), out)
     assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[3], 4)
+
+
+def test_fr29_reduced_radix_butterflies_match_oracle(lib):
+    """fr29.cuh: lazy DIF butterflies (a + b, (a - b) w) incl. 9 chained stages."""
+    rnd = random.Random(29)
+    vals = edge_values(Q, rnd, 40)
+    o0, o1 = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)()
+    for a in vals:
+        for b in vals[:10] + [rnd.randrange(Q)]:
+            w = rnd.choice(vals)
+            lib.h_fr29_butterfly(fr_limbs(a), fr_limbs(b), fr_limbs(w), o0, o1)
+            assert fr_val(o0) == (a + b) % Q and fr_val(o1) == (a - b) * w % Q
+            # outputs must be canonical limbs
+            assert sum(int(v) << (32 * i) for i, v in enumerate(o0)) < Q
+            x, y = a, b
+            for _ in range(9):
+                x, y = (x + y) % Q, (x - y) * w % Q
+            lib.h_fr29_chain(fr_limbs(a), fr_limbs(b), fr_limbs(w), 9, o0, o1)
+            assert fr_val(o0) == x and fr_val(o1) == y
+            lib.h_fr29_mul2(fr_limbs(a), fr_limbs(b), fr_limbs(w), o0)
+            assert fr_val(o0) == a * b * w % Q
+
+
+def test_fr29_sub_reduce(lib):
+    rnd = random.Random(31)
+    vals = edge_values(Q, rnd, 60)
+    o = (ctypes.c_uint32 * 8)()
+    for a in vals:
+        for b in vals[:12] + [rnd.randrange(Q)]:
+            lib.h_fr29_sub_reduce(fr_limbs(a), fr_limbs(b), o)
+            assert fr_val(o) == (2 * a - 2 * b) % Q
