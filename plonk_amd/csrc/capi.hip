@@ -147,7 +147,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   }
   (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_tmp); (void)hipFree(c.srs_table);
   MsmWork& w = c.msm;
-  (void)hipFree(w.digits); (void)hipFree(w.entries); (void)hipFree(w.counts); (void)hipFree(w.offsets);
+  (void)hipFree(w.digits); (void)hipFree(w.entries); (void)hipFree(w.keys_out); (void)hipFree(w.vals_in); (void)hipFree(w.sort_tmp); (void)hipFree(w.counts); (void)hipFree(w.offsets);
   (void)hipFree(w.cursors); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
   (void)hipFree(w.chunk); (void)hipFree(w.result); (void)hipFree(w.scalars_stage);
   if (w.result_host) (void)hipHostFree(w.result_host);

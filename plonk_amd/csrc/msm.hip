@@ -9,11 +9,12 @@
 //     (16 x 96 B per SRS point; 1.5 GiB at 2^20 points).  All windows then share
 //     ONE set of 2^15 signed-digit buckets, so there is no per-window bucket
 //     reduction and no Horner doubling chain at the end.
-//   * msm_digits   : scalars -> canonical form -> 16 signed 16-bit digits,
-//                    bucket histogram (global atomics).
-//   * msm_scan     : exclusive scans -> bucket offsets and slice offsets
-//                    (a slice = at most MSM_KSL entries of one bucket).
-//   * msm_scatter  : counting-sort scatter of (table index | sign) by bucket.
+//   * msm_digits   : scalars -> canonical form -> 16 signed 16-bit digits, emitted as
+//                    (bucket, table index | sign) pairs.
+//   * radix sort   : pairs grouped by bucket (rocPRIM, msm_sort.hip).
+//   * msm_counts / msm_scan : bucket sizes by binary search in the sorted keys, exclusive
+//                    scans -> bucket offsets and slice offsets (a slice = at most MSM_KSL
+//                    entries of one bucket).
 //   * msm_accumulate (dominant): one lane per slice; gathers affine table points
 //                    (128-byte entries, one cache line each) and folds them into an
 //                    XYZZ accumulator.  Field arithmetic is the reduced-radix, lazily
@@ -164,13 +165,16 @@ __global__ void srs_generate_kernel(Fr tau, Fr g_scalar, uint64_t n, G1Affine* _
 // ---------------------------------------------------------------------------
 // digits, histogram, scatter
 // ---------------------------------------------------------------------------
-// digit word: 0 = skip; else (bucket_index + 1) | sign << 31, bucket_index = |d| - 1
-__global__ void msm_digits_kernel(MsmBatch bt, uint32_t* __restrict__ digits_all, uint32_t* __restrict__ counts_all) {
+// Emits one (key, value) pair per window: key = bucket index |d| - 1 (MSM_NB for a zero
+// digit, which sorts behind every real bucket), value = (w * srs_n + i) | sign << 31.
+// Pair index = w * m + i.
+__global__ void msm_digits_kernel(MsmBatch bt, uint64_t srs_n, uint32_t* __restrict__ keys_all,
+                                  uint32_t* __restrict__ vals_all) {
   const int kb = blockIdx.y;
   const uint64_t m = bt.m[kb];
   const Fr* __restrict__ scalars = bt.scalars[kb];
-  uint32_t* __restrict__ digits = digits_all + (uint64_t)kb * MSM_W * bt.cap_m;
-  uint32_t* __restrict__ counts = counts_all + (uint64_t)kb * MSM_NB;
+  uint32_t* __restrict__ keys = keys_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint32_t* __restrict__ vals = vals_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const Fr s = ld_fr_g(scalars + i).from_mont();
@@ -178,19 +182,34 @@ __global__ void msm_digits_kernel(MsmBatch bt, uint32_t* __restrict__ digits_all
 #pragma unroll
   for (int w = 0; w < MSM_W; ++w) {
     const uint32_t raw = (s.l[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-    uint32_t v = raw + carry;
-    uint32_t word = 0;
+    const uint32_t v = raw + carry;
+    uint32_t key = MSM_NB, sign = 0;
     carry = 0;
     if (v > MSM_NB) {          // negative digit d = v - 65536
       carry = 1;
       const uint32_t mag = 65536u - v;
-      if (mag) word = mag | 0x80000000u;
+      if (mag) { key = mag - 1; sign = 0x80000000u; }
     } else if (v) {
-      word = v;
+      key = v - 1;
     }
-    digits[(uint64_t)w * m + i] = word;
-    if (word) atomicAdd(&counts[(word & 0x7fffffffu) - 1], 1u);
+    keys[(uint64_t)w * m + i] = key;
+    vals[(uint64_t)w * m + i] = (uint32_t)((uint64_t)w * srs_n + i) | sign;
   }
+}
+
+// counts[b] = number of sorted keys equal to b (binary searches in the sorted key array)
+__global__ void msm_counts_kernel(MsmBatch bt, const uint32_t* __restrict__ keys_sorted_all,
+                                  uint32_t* __restrict__ counts_all) {
+  const int kb = blockIdx.y;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= MSM_NB) return;
+  const uint32_t* __restrict__ keys = keys_sorted_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint64_t n = (uint64_t)MSM_W * bt.m[kb];
+  uint64_t lo0 = 0, hi0 = n;           // first index with key >= b
+  while (lo0 < hi0) { const uint64_t mid = (lo0 + hi0) >> 1; if (keys[mid] < b) lo0 = mid + 1; else hi0 = mid; }
+  uint64_t lo1 = lo0, hi1 = n;         // first index with key >= b + 1
+  while (lo1 < hi1) { const uint64_t mid = (lo1 + hi1) >> 1; if (keys[mid] < b + 1) lo1 = mid + 1; else hi1 = mid; }
+  counts_all[(uint64_t)kb * MSM_NB + b] = (uint32_t)(lo1 - lo0);
 }
 
 // exclusive scans over NB entries, single workgroup of 1024 threads:
@@ -237,28 +256,6 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restri
   if (t == 1023) {
     offsets[MSM_NB] = ra;
     slice_off[MSM_NB] = rb;
-  }
-}
-
-// entries[offsets[b] + k] = (w * srs_n + i) | sign
-__global__ void msm_scatter_kernel(MsmBatch bt, const uint32_t* __restrict__ digits_all, uint64_t srs_n,
-                                   const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ cursors_all,
-                                   uint32_t* __restrict__ entries_all) {
-  const int kb = blockIdx.y;
-  const uint64_t m = bt.m[kb];
-  const uint32_t* __restrict__ digits = digits_all + (uint64_t)kb * MSM_W * bt.cap_m;
-  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
-  uint32_t* __restrict__ cursors = cursors_all + (uint64_t)kb * MSM_NB;
-  uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-#pragma unroll
-  for (int w = 0; w < MSM_W; ++w) {
-    const uint32_t word = digits[(uint64_t)w * m + i];
-    if (!word) continue;
-    const uint32_t b = (word & 0x7fffffffu) - 1;
-    const uint32_t pos = atomicAdd(&cursors[b], 1u);
-    entries[offsets[b] + pos] = (uint32_t)((uint64_t)w * srs_n + i) | (word & 0x80000000u);
   }
 }
 
@@ -418,8 +415,14 @@ int msm_reserve(Ctx* c, uint64_t m) {
   if (m > w.cap_m) {
     if (w.digits) { HIP_TRY(hipFree(w.digits)); HIP_TRY(hipFree(w.entries)); HIP_TRY(hipFree(w.partial)); }
     const uint64_t cap = m;
-    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap * KB));
-    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));
+    if (w.keys_out) { HIP_TRY(hipFree(w.keys_out)); HIP_TRY(hipFree(w.vals_in)); HIP_TRY(hipFree(w.sort_tmp)); }
+    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap * KB));     // keys, unsorted
+    HIP_TRY(hipMalloc((void**)&w.keys_out, sizeof(uint32_t) * MSM_W * cap * KB));   // keys, sorted
+    HIP_TRY(hipMalloc((void**)&w.vals_in, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, unsorted
+    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, grouped by bucket
+    int rc_t = msm_sort_temp_bytes((size_t)MSM_W * cap, &w.sort_tmp_bytes);
+    if (rc_t) return rc_t;
+    HIP_TRY(hipMalloc((void**)&w.sort_tmp, w.sort_tmp_bytes));
     w.cap_slices = (MSM_W * cap) / MSM_KSL + MSM_NB + 1;
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
     w.cap_m = cap;
@@ -457,12 +460,17 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   bt.cap_slices = w.cap_slices;
   for (int k = 0; k < count; ++k) { bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k]; }
   prof_begin(c, 2);
-  HIP_TRY(hipMemsetAsync(w.counts, 0, sizeof(uint32_t) * MSM_NB * count, st));
   const uint32_t gb = (uint32_t)((mmax + 255) / 256);
-  hipLaunchKernelGGL(msm_digits_kernel, dim3(gb, count), dim3(256), 0, st, bt, w.digits, w.counts);
+  hipLaunchKernelGGL(msm_digits_kernel, dim3(gb, count), dim3(256), 0, st, bt, c->srs_n, w.digits, w.vals_in);
+  for (int k = 0; k < count; ++k) {
+    if (!m[k]) continue;
+    const uint64_t off = (uint64_t)k * MSM_W * w.cap_m;
+    rc = msm_sort_pairs(c, w.sort_tmp, w.sort_tmp_bytes, w.digits + off, w.keys_out + off, w.vals_in + off,
+                        w.entries + off, (size_t)MSM_W * m[k]);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(msm_counts_kernel, dim3(MSM_NB / 256, count), dim3(256), 0, st, bt, w.keys_out, w.counts);
   hipLaunchKernelGGL(msm_scan_kernel, dim3(count), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors);
-  hipLaunchKernelGGL(msm_scatter_kernel, dim3(gb, count), dim3(256), 0, st, bt, w.digits, c->srs_n, w.offsets, w.cursors,
-                     w.entries);
   prof_end(c, 2);
   // upper bound on slices known on the host: no device->host sync on the path
   const uint64_t max_slices = (MSM_W * mmax) / MSM_KSL + MSM_NB + 1;
