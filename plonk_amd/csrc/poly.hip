@@ -13,6 +13,7 @@
 //   ruffini_*              Polynomial::ruffini, src/fft/polynomial.rs:345-367
 // All arithmetic is exact Fr; results are the same field elements as the reference's.
 #include "plonk_internal.hpp"
+#include "fr29.cuh"
 #include "poly.hpp"
 
 namespace plonk {
@@ -71,11 +72,20 @@ __global__ void split_t_kernel(Fr* __restrict__ t, uint64_t n, uint64_t np, Fr* 
   if (part == 0 && i == n + 1) stf(t + 3 * n, ldf(t + 3 * n) - a.b[2]);   // t_fourth -= b14 (nobody reads t[3n])
 }
 
-// highest index with a non-zero coefficient + 1 (Polynomial::from_coefficients_vec trim, polynomial.rs:79)
-__global__ void trimmed_len_kernel(const Fr* __restrict__ p, uint64_t n, unsigned long long* out) {
+// highest index with a non-zero coefficient + 1 (Polynomial::from_coefficients_vec trim, polynomial.rs:79).
+// One atomic per workgroup (a per-element atomicMax serialises ~4n+7 updates on one address).
+__global__ void __launch_bounds__(256) trimmed_len_kernel(const Fr* __restrict__ p, uint64_t n, unsigned long long* out) {
+  __shared__ unsigned long long sh[256];
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (!ldf(p + i).is_zero()) atomicMax(out, (unsigned long long)(i + 1));
+  unsigned long long v = 0;
+  if (i < n && !ldf(p + i).is_zero()) v = i + 1;
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) { const unsigned long long o = sh[threadIdx.x + d]; if (o > sh[threadIdx.x]) sh[threadIdx.x] = o; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && sh[0]) atomicMax(out, sh[0]);
 }
 
 __global__ void scatter_pi_kernel(Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count) {
@@ -271,81 +281,116 @@ __device__ __forceinline__ Fr delta4(const Fr& f, const Fr& one) {   // f (f-1)(
   return f * (f - one) * (f - two) * (f - two - one);
 }
 
+// Hot part (arithmetic + permutation + L1 + Z_H division) in the reduced-radix lazy form of
+// fr29.cuh: 28 Montgomery products per point at ~220 VALU instructions each.  Data stays in the
+// reference's R = 2^256 domain while the reduction is by R'' = 2^261, so every product of two
+// DATA values carries an extra 2^-5; that is pre-compensated once: the selector / L1 evaluation
+// arrays are stored scaled (q_m by 2^10; q_l q_r q_o q_f q_arith l1 by 2^5, prover.hip) and the
+// challenge constants are handed over as c * 2^(5k) * R'' (QuotientConst).  The range / logic /
+// fixed-base / curve-addition widgets — identically zero selectors in most circuits — run on
+// the exact 32-bit path from the same loaded values.
+__device__ __forceinline__ Fr29 ld29(const Fr* p) { return Fr29::from_fr(ldf(p)); }
+__device__ __forceinline__ Fr29 c29(const uint32_t (&v)[9]) {
+  Fr29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = v[i];
+  return r;
+}
+
 __global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= q.n8) return;
   const uint64_t iw = (i + 8) & (q.n8 - 1);           // extended arrays wrap (quotient_poly.rs:61-67)
-  const Fr one = Fr::one();
-  const Fr a = ldf(q.a + i), b = ldf(q.b + i), c = ldf(q.c + i), d = ldf(q.d + i);
-  const Fr z = ldf(q.z + i), z_w = ldf(q.z + iw);
-  Fr t = ldf(q.pi + i);
-  // arithmetic (arithmetic/proverkey.rs:44-71)
+  const Fr29 a = ld29(q.a + i), b = ld29(q.b + i), c = ld29(q.c + i), d = ld29(q.d + i);
+  const Fr29 z = ld29(q.z + i), z_w = ld29(q.z + iw);
+  const Fr29 gamma = c29(q.k.gamma);
+  Fr29 t = ld29(q.pi + i);
+  // arithmetic (arithmetic/proverkey.rs:44-71); selector arrays pre-scaled, see above
   {
-    Fr s = ldf(q.q_c + i);
-    if (q.has[QS_M]) s = s + a * b * ldf(q.q_m + i);
-    if (q.has[QS_L]) s = s + a * ldf(q.q_l + i);
-    if (q.has[QS_R]) s = s + b * ldf(q.q_r + i);
-    if (q.has[QS_O]) s = s + c * ldf(q.q_o + i);
-    if (q.has[QS_F]) s = s + d * ldf(q.q_f + i);
-    t = t + s * ldf(q.q_arith + i);
-  }
-  const bool need_w = q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR];
-  Fr a_w, b_w, d_w;
-  if (need_w) { a_w = ldf(q.a + iw); b_w = ldf(q.b + iw); d_w = ldf(q.d + iw); }
-  const Fr four = one.dbl().dbl();
-  if (q.has[QS_RANGE]) {   // range/proverkey.rs:32-58
-    const Fr k1 = q.range_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
-    Fr s = delta4(c - four * d, one) + delta4(b - four * c, one) * k1 + delta4(a - four * b, one) * k2 +
-           delta4(d_w - four * a, one) * k3;
-    t = t + s * ldf(q.q_range + i) * q.range_ch;
-  }
-  if (q.has[QS_LOGIC]) {   // logic/proverkey.rs:34-70,108-144
-    const Fr k1 = q.logic_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1, k4 = k3 * k1;
-    const Fr la = a_w - four * a, lb = b_w - four * b, ld = d_w - four * d, w = c;
-    const Fr q_c = ldf(q.q_c + i);
-    const Fr n3 = small(3, one), n9 = small(9, one), n18 = small(18, one), n81 = small(81, one), n83 = small(83, one);
-    const Fr ab = la + lb;
-    const Fr F = w * (w * (four * w - n18 * ab + n81) + n18 * (la.sqr() + lb.sqr()) - n81 * ab + n83);
-    const Fr Ee = n3 * (ab + ld) - F.dbl();
-    const Fr Bb = q_c * (n9 * ld - n3 * ab);
-    Fr s = (w - la * lb) * k3 + delta4(la, one) + delta4(lb, one) * k1 + delta4(ld, one) * k2 + (Bb + Ee) * k4;
-    t = t + ldf(q.q_logic + i) * s * q.logic_ch;
-  }
-  if (q.has[QS_FIXED]) {   // ecc/scalar_mul/fixed_base/proverkey.rs:39-101
-    const Fr k1 = q.fixed_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
-    const Fr x_beta = ldf(q.q_l + i), y_beta = ldf(q.q_r + i), q_c = ldf(q.q_c + i);
-    const Fr bit = d_w - d - d;
-    const Fr bit_cons = bit * (bit - one) * (bit + one);
-    const Fr y_alpha = bit.sqr() * (y_beta - one) + one;
-    const Fr x_alpha = bit * x_beta;
-    const Fr xy_cons = (bit * q_c - c) * k1;
-    const Fr cab_d = c * a * b * q.edwards_d;
-    const Fr x_acc = ((a_w + a_w * cab_d) - (a * y_alpha + b * x_alpha)) * k2;
-    const Fr y_acc = ((b_w - b_w * cab_d) - (b * y_alpha + a * x_alpha)) * k3;
-    t = t + (bit_cons + x_acc + y_acc + xy_cons) * ldf(q.q_fixed + i) * q.fixed_ch;
-  }
-  if (q.has[QS_VAR]) {     // ecc/curve_addition/proverkey.rs:33-77
-    const Fr k1 = q.var_ch.sqr();
-    const Fr x1y2 = d_w;
-    const Fr y1x2 = b * c, y1y2 = b * d, x1x2 = a * c;
-    const Fr xy_cons = a * d - x1y2;
-    const Fr dxy = q.edwards_d * x1y2 * y1x2;
-    const Fr x3c = ((x1y2 + y1x2) - (a_w + a_w * dxy)) * k1;
-    const Fr y3c = ((y1y2 + x1x2) - (b_w - b_w * dxy)) * k1.sqr();
-    t = t + (xy_cons + x3c + y3c) * ldf(q.q_var + i) * q.var_ch;
+    Fr29 s = ld29(q.q_c + i);
+    if (q.has[QS_M]) s = Fr29::add_csub(s, Fr29::mul(Fr29::mul(a, b), ld29(q.q_m + i)));
+    if (q.has[QS_L]) s = Fr29::add_csub(s, Fr29::mul(a, ld29(q.q_l + i)));
+    if (q.has[QS_R]) s = Fr29::add_csub(s, Fr29::mul(b, ld29(q.q_r + i)));
+    if (q.has[QS_O]) s = Fr29::add_csub(s, Fr29::mul(c, ld29(q.q_o + i)));
+    if (q.has[QS_F]) s = Fr29::add_csub(s, Fr29::mul(d, ld29(q.q_f + i)));
+    t = Fr29::add_csub(t, Fr29::mul(s, ld29(q.q_arith + i)));
   }
   // permutation (permutation/proverkey.rs:40-125)
   {
-    const Fr x = ldf(q.linear + i);
-    const Fr bx = q.beta * x;
-    const Fr ag = a + q.gamma, bg = b + q.gamma, cg = c + q.gamma, dg = d + q.gamma;
-    const Fr ident = (ag + bx) * (bg + bx * q.k1) * (cg + bx * q.k2) * (dg + bx * q.k3) * z * q.alpha;
-    const Fr copy = (ag + q.beta * ldf(q.s1 + i)) * (bg + q.beta * ldf(q.s2 + i)) * (cg + q.beta * ldf(q.s3 + i)) *
-                    (dg + q.beta * ldf(q.s4 + i)) * z_w * q.alpha;
-    const Fr l1 = (z - one) * (ldf(q.l1 + i) * q.alpha_sq);
-    t = t + ident - copy + l1;
+    const Fr29 x = ld29(q.linear + i);
+    const Fr29 ag = Fr29::add_csub(a, gamma), bg = Fr29::add_csub(b, gamma);
+    const Fr29 cg = Fr29::add_csub(c, gamma), dg = Fr29::add_csub(d, gamma);
+    Fr29 p1 = Fr29::mul(Fr29::add_csub(ag, Fr29::mul(x, c29(q.k.beta_k[0]))),
+                        Fr29::add_csub(bg, Fr29::mul(x, c29(q.k.beta_k[1]))));
+    p1 = Fr29::mul(p1, Fr29::add_csub(cg, Fr29::mul(x, c29(q.k.beta_k[2]))));
+    p1 = Fr29::mul(p1, Fr29::add_csub(dg, Fr29::mul(x, c29(q.k.beta_k[3]))));
+    t = Fr29::add_csub(t, Fr29::mul(Fr29::mul(p1, z), c29(q.k.alpha_pos)));            // identity * z * alpha
+    const Fr29 be = c29(q.k.beta_k[0]);
+    Fr29 p2 = Fr29::mul(Fr29::add_csub(ag, Fr29::mul(ld29(q.s1 + i), be)), Fr29::add_csub(bg, Fr29::mul(ld29(q.s2 + i), be)));
+    p2 = Fr29::mul(p2, Fr29::add_csub(cg, Fr29::mul(ld29(q.s3 + i), be)));
+    p2 = Fr29::mul(p2, Fr29::add_csub(dg, Fr29::mul(ld29(q.s4 + i), be)));
+    t = Fr29::add_csub(t, Fr29::mul(Fr29::mul(p2, z_w), c29(q.k.alpha_neg)));          // - copy * z_w * alpha
+    const Fr29 l1a = Fr29::mul(ld29(q.l1 + i), c29(q.k.alpha_sq));                      // L1 * alpha^2 (* 2^5)
+    t = Fr29::add_csub(t, Fr29::mul(Fr29::sub_lazy(z, c29(q.k.one)), l1a));             // (z - 1) L1 alpha^2
   }
-  stf(q.out + i, t * q.vinv[i & 7]);
+  const bool need_w = q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR];
+  if (need_w) {   // exact 32-bit path for the remaining widgets
+    const Fr one = Fr::one();
+    const Fr a_ = ldf(q.a + i), b_ = ldf(q.b + i), c_ = ldf(q.c + i), d_ = ldf(q.d + i);
+    const Fr a_w = ldf(q.a + iw), b_w = ldf(q.b + iw), d_w = ldf(q.d + iw);
+    const Fr four = one.dbl().dbl();
+    Fr u = Fr::zero();
+    if (q.has[QS_RANGE]) {   // range/proverkey.rs:32-58
+      const Fr k1 = q.range_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
+      Fr s = delta4(c_ - four * d_, one) + delta4(b_ - four * c_, one) * k1 + delta4(a_ - four * b_, one) * k2 +
+             delta4(d_w - four * a_, one) * k3;
+      u = u + s * ldf(q.q_range + i) * q.range_ch;
+    }
+    if (q.has[QS_LOGIC]) {   // logic/proverkey.rs:34-70,108-144
+      const Fr k1 = q.logic_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1, k4 = k3 * k1;
+      const Fr la = a_w - four * a_, lb = b_w - four * b_, ld = d_w - four * d_, w = c_;
+      const Fr q_c = ldf(q.q_c + i);
+      const Fr n3 = small(3, one), n9 = small(9, one), n18 = small(18, one), n81 = small(81, one), n83 = small(83, one);
+      const Fr ab = la + lb;
+      const Fr F = w * (w * (four * w - n18 * ab + n81) + n18 * (la.sqr() + lb.sqr()) - n81 * ab + n83);
+      const Fr Ee = n3 * (ab + ld) - F.dbl();
+      const Fr Bb = q_c * (n9 * ld - n3 * ab);
+      Fr s = (w - la * lb) * k3 + delta4(la, one) + delta4(lb, one) * k1 + delta4(ld, one) * k2 + (Bb + Ee) * k4;
+      u = u + ldf(q.q_logic + i) * s * q.logic_ch;
+    }
+    if (q.has[QS_FIXED]) {   // ecc/scalar_mul/fixed_base/proverkey.rs:39-101
+      const Fr k1 = q.fixed_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
+      // q_l / q_r arrays are stored * 2^5 for the fast path: undo
+      const Fr x_beta = ldf(q.q_l + i) * q.inv32, y_beta = ldf(q.q_r + i) * q.inv32, q_c = ldf(q.q_c + i);
+      const Fr bit = d_w - d_ - d_;
+      const Fr bit_cons = bit * (bit - one) * (bit + one);
+      const Fr y_alpha = bit.sqr() * (y_beta - one) + one;
+      const Fr x_alpha = bit * x_beta;
+      const Fr xy_cons = (bit * q_c - c_) * k1;
+      const Fr cab_d = c_ * a_ * b_ * q.edwards_d;
+      const Fr x_acc = ((a_w + a_w * cab_d) - (a_ * y_alpha + b_ * x_alpha)) * k2;
+      const Fr y_acc = ((b_w - b_w * cab_d) - (b_ * y_alpha + a_ * x_alpha)) * k3;
+      u = u + (bit_cons + x_acc + y_acc + xy_cons) * ldf(q.q_fixed + i) * q.fixed_ch;
+    }
+    if (q.has[QS_VAR]) {     // ecc/curve_addition/proverkey.rs:33-77
+      const Fr k1 = q.var_ch.sqr();
+      const Fr x1y2 = d_w;
+      const Fr y1x2 = b_ * c_, y1y2 = b_ * d_, x1x2 = a_ * c_;
+      const Fr xy_cons = a_ * d_ - x1y2;
+      const Fr dxy = q.edwards_d * x1y2 * y1x2;
+      const Fr x3c = ((x1y2 + y1x2) - (a_w + a_w * dxy)) * k1;
+      const Fr y3c = ((y1y2 + x1x2) - (b_w - b_w * dxy)) * k1.sqr();
+      u = u + (xy_cons + x3c + y3c) * ldf(q.q_var + i) * q.var_ch;
+    }
+    t = Fr29::add_csub(t, Fr29::from_fr(u));
+  }
+  stf(q.out + i, Fr29::mul(t, c29(q.k.vinv[i & 7])).to_fr());
+}
+
+// v[i] *= s  (one-off pre-scaling of key arrays for the kernel above)
+__global__ void scale_array_kernel(Fr* __restrict__ v, uint64_t n, Fr s) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stf(v + i, ldf(v + i) * s);
 }
 
 // L1 numerators on the coset: out[i] = v_h[i & 7] * n_inv  (to be multiplied by 1/(linear[i]-1))
@@ -479,6 +524,22 @@ int poly_quotient(Ctx* c, const QuotientArgs& q) {
   prof_end(c, 3);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
+}
+int poly_scale_array(Ctx* c, Fr* v, uint64_t n, const Fr& s) {
+  hipLaunchKernelGGL(scale_array_kernel, grid1(n, 256), dim3(256), 0, c->stream, v, n, s);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+// host helper: challenge constant c (Fr, R form) * 2^shift  ->  limbs of c * 2^shift * R'' (fr29.cuh)
+void quotient_const(const Fr& c, int shift, uint32_t out[9]) {
+  Fr v = c;
+  for (int k = 0; k < shift; ++k) v = v.dbl();
+  const Fr29 r = Fr29::twiddle_from_fr(v);
+  for (int k = 0; k < 9; ++k) out[k] = r.l[k];
+}
+void quotient_data(const Fr& c, uint32_t out[9]) {   // plain re-slicing (stays in R form)
+  const Fr29 r = Fr29::from_fr(c);
+  for (int k = 0; k < 9; ++k) out[k] = r.l[k];
 }
 int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a) {
   hipLaunchKernelGGL(l1_prepare_kernel, grid1(n8, 256), dim3(256), 0, c->stream, linear, l1, n8);

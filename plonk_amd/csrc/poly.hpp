@@ -27,15 +27,26 @@ struct PermArgs {
   Fr* num;
   Fr* den;
 };
+// challenge-derived constants of the fast quotient path as 9 x 29-bit limbs (fr29.cuh):
+// c * 2^(5k) * R'' for multipliers, plain re-sliced R-form values for addends.
+struct QuotientConst {
+  uint32_t gamma[9];       // gamma (R form, addend)
+  uint32_t one[9];         // 1 (R form, subtrahend of z - 1)
+  uint32_t beta_k[4][9];   // beta * {1, K1, K2, K3} * R''
+  uint32_t alpha_pos[9];   // alpha * 2^20 * R''   (absorbs the 2^-5 of 4 data x data products)
+  uint32_t alpha_neg[9];   // -alpha * 2^20 * R''
+  uint32_t alpha_sq[9];    // alpha^2 * R''
+  uint32_t vinv[8][9];     // vanishing_coset_inverses * R''
+};
 struct QuotientArgs {
   uint64_t n8;
+  QuotientConst k;
+  Fr inv32;                // 2^-5: undoes the pre-scaling of q_l / q_r for the fixed-base widget
   const Fr *a, *b, *c, *d, *z, *pi;
   const Fr *q_m, *q_l, *q_r, *q_o, *q_f, *q_c, *q_arith, *q_range, *q_logic, *q_fixed, *q_var;
   const Fr *s1, *s2, *s3, *s4, *linear, *l1;
   bool has[QS_COUNT];   // selector polynomial is not identically zero
-  Fr alpha, alpha_sq, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch;
-  Fr k1, k2, k3, edwards_d;
-  Fr vinv[8];           // vanishing_coset_inverses (prover.rs:78-91)
+  Fr range_ch, logic_ch, fixed_ch, var_ch, edwards_d;   // exact path (rarely active widgets)
   Fr* out;
 };
 struct L1Args {
@@ -78,6 +89,9 @@ int poly_perm_terms(Ctx* c, const PermArgs& a);
 int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag);
 int poly_quotient(Ctx* c, const QuotientArgs& q);
 int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a);
+int poly_scale_array(Ctx* c, Fr* v, uint64_t n, const Fr& s);
+void quotient_const(const Fr& c, int shift, uint32_t out[9]);
+void quotient_data(const Fr& c, uint32_t out[9]);
 int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev);
 int poly_lincomb(Ctx* c, const LinCombArgs& a);
 int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, const Fr& zinv, Fr* scratch, Fr* totals);

@@ -317,6 +317,13 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
     l1a.n_inv = Fr::from_u64(n).inv();
   }
   PTRY(poly_l1(c, p->evals8 + P_COUNT * n8, p->evals8 + (P_COUNT + 1) * n8, n8, l1a));
+  // pre-scaling for the reduced-radix quotient kernel (poly.hip): q_m * 2^10; q_l q_r q_o q_f q_arith, L1 * 2^5
+  {
+    const Fr s5 = Fr::from_u64(32), s10 = Fr::from_u64(1024);
+    PTRY(poly_scale_array(c, p->evals8 + P_QM * n8, n8, s10));
+    const int five[] = {P_QL, P_QR, P_QO, P_QF, P_QARITH, P_COUNT + 1};
+    for (int id : five) PTRY(poly_scale_array(c, p->evals8 + (uint64_t)id * n8, n8, s5));
+  }
 
   // ---- verifier-key commitments for transcript seeding
   if (d->vk_commitments) {
@@ -442,10 +449,17 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     q.s1 = e + P_S1 * n8; q.s2 = e + P_S2 * n8; q.s3 = e + P_S3 * n8; q.s4 = e + P_S4 * n8;
     q.linear = e + P_COUNT * n8; q.l1 = e + (P_COUNT + 1) * n8;
     for (int s = 0; s < QS_COUNT; ++s) q.has[s] = p->has[s];
-    q.alpha = alpha; q.alpha_sq = alpha.sqr(); q.beta = beta; q.gamma = gamma;
     q.range_ch = range_ch; q.logic_ch = logic_ch; q.fixed_ch = fixed_ch; q.var_ch = var_ch;
-    q.k1 = fr_small(7); q.k2 = fr_small(13); q.k3 = fr_small(17); q.edwards_d = edwards_d;
-    for (int i = 0; i < 8; ++i) q.vinv[i] = p->vinv[i];
+    q.edwards_d = edwards_d;
+    q.inv32 = Fr::from_u64(32).inv();
+    quotient_data(gamma, q.k.gamma);
+    quotient_data(Fr::one(), q.k.one);
+    const Fr ks[4] = {Fr::one(), fr_small(7), fr_small(13), fr_small(17)};
+    for (int k = 0; k < 4; ++k) quotient_const(beta * ks[k], 0, q.k.beta_k[k]);
+    quotient_const(alpha, 20, q.k.alpha_pos);
+    quotient_const(alpha.neg(), 20, q.k.alpha_neg);
+    quotient_const(alpha.sqr(), 0, q.k.alpha_sq);
+    for (int i = 0; i < 8; ++i) quotient_const(p->vinv[i], 0, q.k.vinv[i]);
     q.out = p->tbuf;
     PTRY(poly_quotient(c, q));
     PTRY(ntt_device(c, p->tbuf, p->tbuf, p->tmp8, L + 3, true, true, n8));
