@@ -157,12 +157,18 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # PLONK_BENCH_BACKEND=gloo + PLONK_BENCH_SHARE_GPU=1: several ranks on ONE GPU (functional test of
+        # the sharded path on a 1-GPU box; RCCL itself refuses two ranks per device)
+        backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
+        if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dev = "cuda" if backend == "nccl" else "cpu"
 
-        def allgather(send: bytes) -> bytes:   # RCCL all-gather of the MSM partial sums
-            t = torch.frombuffer(bytearray(send), dtype=torch.uint8).cuda()
-            out = torch.empty(world * t.numel(), dtype=torch.uint8, device="cuda")
+        def allgather(send: bytes) -> bytes:   # all-gather of the MSM partial sums (RCCL over xGMI)
+            t = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
+            out = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
             dist.all_gather_into_tensor(out, t)
             return out.cpu().numpy().tobytes()
 
@@ -198,11 +204,11 @@ def main():
     ctx.profile(False)
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         # all ranks must have produced the identical proof
-        ph = torch.frombuffer(bytearray(proof), dtype=torch.uint8).cuda().to(torch.int32)
+        ph = torch.frombuffer(bytearray(proof), dtype=torch.uint8).to(dev).to(torch.int32)
         ref = ph.clone()
         dist.broadcast(ref, 0)
         assert bool((ref == ph).all()), "ranks disagree on the proof bytes"

@@ -474,7 +474,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const uint64_t len4 = tlen > 3 * n ? tlen - 3 * n : 0;
   // honest quotient: degree <= 4n + 6 (quotient_poly.rs:106-111) => t_fourth has <= n + 7 coefficients;
   // anything longer cannot be committed with the trimmed key (key.rs:362-370)
-  if (len4 > n + 7 || len4 > c->srs_n) return PLONK_ERR_DEGREE;
+  if (len4 > n + 7 || len4 > p->srs_total) return PLONK_ERR_DEGREE;
   {
     SplitArgs sa;
     sa.b[0] = bl[11]; sa.b[1] = bl[12]; sa.b[2] = bl[13];
