@@ -383,7 +383,7 @@ __global__ void msm_identity_kernel(G1* out) {
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
   if (c->srs_table) { HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
   if (n == 0) return PLONK_OK;
-  if ((uint64_t)MSM_W * n >= (1ull << 31)) return PLONK_ERR_ARG;   // entry word: 31-bit table index
+  if ((uint64_t)MSM_W * n >= (1ull << 31)) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // entry word: 31-bit table index
   HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)MSM_W * n));
   hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, (G1AffineR*)c->srs_table, n);
   HIP_TRY(hipGetLastError());
@@ -438,7 +438,7 @@ void prof_end(Ctx* c, int slot);
 // (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev) {
   if (count <= 0) return PLONK_OK;
-  if (count > MSM_MAX_BATCH) return PLONK_ERR_ARG;
+  if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   uint64_t mmax = 0;
   for (int k = 0; k < count; ++k) {
     if (m[k] > c->srs_n) return PLONK_ERR_DEGREE;

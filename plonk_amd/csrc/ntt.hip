@@ -427,7 +427,7 @@ static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, ui
     case 7: launch_pass<7>(c, p, transpose, nblocks); break;
     case 8: launch_pass<8>(c, p, transpose, nblocks); break;
     case 9: launch_pass<9>(c, p, transpose, nblocks); break;
-    default: return PLONK_ERR_ARG;
+    default: return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   }
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
@@ -436,7 +436,7 @@ static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, ui
 // Device-resident transform: src (in_len valid elements) -> dst (N elements).
 // src == dst is allowed.  `tmp` must hold N elements (N > 1024 only).
 int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len) {
-  if (L >= 28) return PLONK_ERR_ARG;   // 3 passes of <= 2^9; reference limit is 2^32 (domain.rs:132)
+  if (L >= 28) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // 3 passes of <= 2^9; reference limit is 2^32 (domain.rs:132)
   const uint64_t N = 1ull << L;
   if (in_len > N) in_len = N;          // Vec::resize truncation, domain.rs:174
   NttTables* tb;

@@ -178,18 +178,17 @@ __global__ void __launch_bounds__(SCAN_T) scan_block_kernel(Fr* __restrict__ dat
   }
 }
 
-// single-block inclusive scan of up to 2048 * 2048 / ... block totals (nb <= SCAN_BLOCK)
+// single-block inclusive scan of the block totals (nb <= SCAN_T * SCAN_MAXPER); each thread owns
+// a contiguous run of `per` totals.
+static constexpr int SCAN_MAXPER = 64;
 template <bool MUL>
-__global__ void __launch_bounds__(SCAN_T) scan_totals_kernel(Fr* __restrict__ totals, uint32_t nb) {
+__global__ void __launch_bounds__(SCAN_T) scan_totals_kernel(Fr* __restrict__ totals, uint32_t nb, uint32_t per) {
   __shared__ Fr sh[SCAN_T];
   const int t = threadIdx.x;
-  Fr v[SCAN_E];
   Fr acc = sid<MUL>();
-#pragma unroll
-  for (int k = 0; k < SCAN_E; ++k) {
-    const uint32_t i = t * SCAN_E + k;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t i = t * per + k;
     if (i < nb) acc = sop<MUL>(acc, ldf(totals + i));
-    v[k] = acc;
   }
   sh[t] = acc;
   __syncthreads();
@@ -201,11 +200,13 @@ __global__ void __launch_bounds__(SCAN_T) scan_totals_kernel(Fr* __restrict__ to
     if (take) sh[t] = sop<MUL>(x, sh[t]);
     __syncthreads();
   }
-  const Fr excl = t ? sh[t - 1] : sid<MUL>();
-#pragma unroll
-  for (int k = 0; k < SCAN_E; ++k) {
-    const uint32_t i = t * SCAN_E + k;
-    if (i < nb) stf(totals + i, sop<MUL>(excl, v[k]));
+  acc = t ? sh[t - 1] : sid<MUL>();
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t i = t * per + k;
+    if (i < nb) {
+      acc = sop<MUL>(acc, ldf(totals + i));
+      stf(totals + i, acc);
+    }
   }
 }
 
@@ -227,10 +228,10 @@ __global__ void __launch_bounds__(SCAN_T) scan_apply_kernel(Fr* __restrict__ dat
 template <bool MUL, bool REV>
 static int scan_inplace(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
   const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-  if (nb > SCAN_BLOCK) return PLONK_ERR_ARG;   // n <= 2^22 * ... (2048 * 2048 elements)
+  if (nb > SCAN_T * SCAN_MAXPER) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // n <= 2^25
   hipLaunchKernelGGL((scan_block_kernel<MUL, REV>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals);
   if (nb > 1) {
-    hipLaunchKernelGGL((scan_totals_kernel<MUL>), dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb);
+    hipLaunchKernelGGL((scan_totals_kernel<MUL>), dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb, (nb + SCAN_T - 1) / SCAN_T);
     hipLaunchKernelGGL((scan_apply_kernel<MUL, REV>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals);
   }
   HIP_TRY(hipGetLastError());
@@ -551,7 +552,7 @@ int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a) {
 }
 int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev) {
   const uint32_t nb = (uint32_t)((max_len + (uint64_t)EV_T * EV_E - 1) / ((uint64_t)EV_T * EV_E));
-  if (nb > a.max_blocks) return PLONK_ERR_ARG;
+  if (nb > a.max_blocks) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   hipLaunchKernelGGL(eval_kernel, dim3(nb, count), dim3(EV_T), 0, c->stream, a);
   hipLaunchKernelGGL(eval_final_kernel, dim3(count), dim3(EV_T), 0, c->stream, a.partial, a.max_blocks, nb, out_dev);
   HIP_TRY(hipGetLastError());

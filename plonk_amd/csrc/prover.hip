@@ -223,26 +223,26 @@ static void prover_free(Prover* p) {
 }
 
 static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
-  if (!d || d->constraints == 0) return PLONK_ERR_ARG;
+  if (!d || d->constraints == 0) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   Prover* p = new Prover();
   p->c = c;
   p->constraints = d->constraints;
   uint64_t n = 1;
   uint32_t L = 0;
   while (n < d->constraints) { n <<= 1; ++L; }   // constraints.next_power_of_two() (compiler.rs:141)
-  if (L + 3 >= 28) { delete p; return PLONK_ERR_ARG; }
+  if (L + 3 >= 28) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
   p->n = n; p->logn = L; p->n8 = 8 * n; p->np = n + 8;
   p->label.assign((const char*)d->label, d->label_len);
   p->world = d->shard_world > 1 ? d->shard_world : 1;
   p->rank = p->world > 1 ? d->shard_rank : 0;
-  if (p->rank < 0 || p->rank >= p->world) { delete p; return PLONK_ERR_ARG; }
+  if (p->rank < 0 || p->rank >= p->world) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
   p->srs_total = p->world > 1 ? d->srs_total : c->srs_n;
   {
     const uint64_t per = (p->srs_total + p->world - 1) / p->world;   // contiguous point ranges
     p->shard_lo = per * (uint64_t)p->rank;
     const uint64_t hi = p->shard_lo + per < p->srs_total ? p->shard_lo + per : p->srs_total;
     const uint64_t want = hi > p->shard_lo ? hi - p->shard_lo : 0;
-    if (p->world > 1 && c->srs_n != want) { delete p; return PLONK_ERR_ARG; }   // ctx must hold exactly this rank's slice
+    if (p->world > 1 && c->srs_n != want) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }   // ctx must hold exactly this rank's slice
   }
   p->allgather = d->allgather;
   p->allgather_user = d->allgather_user;
@@ -265,7 +265,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   ALLOC(p->wit, np);
   ALLOC(p->wit2, np);
   ALLOC(p->scratch, 2 * np);
-  ALLOC(p->totals, 4096);
+  ALLOC(p->totals, 256 * 64 + 1);   // scan block totals (poly.hip: SCAN_T * SCAN_MAXPER)
   p->ev_max_blocks = (uint32_t)((np + 4095) / 4096);
   ALLOC(p->evpart, 16 * (uint64_t)p->ev_max_blocks);
   ALLOC(p->evout, 16);
@@ -282,7 +282,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   PTRY(poly_fill_zero(c, p->polys, P_COUNT * np));
   for (int k = 0; k < P_COUNT; ++k) {
     uint64_t len = d->poly_len[k];
-    if (len > n) { prover_free(p); return PLONK_ERR_ARG; }
+    if (len > n) { prover_free(p); return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
     if (len) HIP_TRY(hipMemcpyAsync(p->polys + k * np, d->polys[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c->stream));
     // Polynomial::from_coefficients_vec trim (polynomial.rs:79): highest non-zero coefficient
     const Fr* hp = (const Fr*)d->polys[k];
@@ -427,7 +427,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
       p->pi_cap = pi_count;
     }
-    for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return PLONK_ERR_ARG;
+    for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
     HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
     PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
@@ -468,7 +468,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   HIP_TRY(hipMemcpyAsync(p->len_host, p->len_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (*p->flag_host) return PLONK_ERR_ARG;                 // "permutation denominator must be nonzero" (permutation.rs:231-234)
+  if (*p->flag_host) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);                 // "permutation denominator must be nonzero" (permutation.rs:231-234)
   const uint64_t tlen = *p->len_host;
   if (tlen > 7 * n) return PLONK_ERR_UNSAT;                // quotient_poly.rs:132
   const uint64_t len4 = tlen > 3 * n ? tlen - 3 * n : 0;
@@ -657,7 +657,7 @@ struct plonk_prover {
 extern "C" {
 
 int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out) {
-  if (!ctx || !desc || !out) return PLONK_ERR_ARG;
+  if (!ctx || !desc || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   if (!ctx->c.srs_table && desc->shard_world <= 1) return PLONK_ERR_NO_SRS;
@@ -680,7 +680,7 @@ void plonk_prover_destroy(plonk_prover* pr) {
 }
 
 int plonk_prover_vk(plonk_prover* pr, uint8_t out[15 * 48]) {
-  if (!pr || !out) return PLONK_ERR_ARG;
+  if (!pr || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   memcpy(out, pr->p->vk, 15 * 48);
   return PLONK_OK;
 }
@@ -689,14 +689,14 @@ uint64_t plonk_prover_size(plonk_prover* pr) { return pr ? pr->p->n : 0; }
 
 // Test/diagnostic hook: copy `count` Fr starting at `offset` of an internal device array.
 int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t count, uint64_t* out) {
-  if (!pr || !out) return PLONK_ERR_ARG;
+  if (!pr || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk::Prover* p = pr->p;
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   const Fr* base[] = {p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tparts, p->agg, p->wit,
                       p->evals8, p->sigma_n, p->scratch, p->evout, p->polys};
   const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->n8, p->n8, 3 * p->np, p->np, p->np,
                           (uint64_t)(P_COUNT + 2) * p->n8, 4 * p->n, 2 * p->np, 16, (uint64_t)P_COUNT * p->np};
-  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return PLONK_ERR_ARG;
+  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   HIP_TRY(hipMemcpyAsync(out, base[which] + offset, sizeof(Fr) * count, hipMemcpyDeviceToHost, p->c->stream));
   HIP_TRY(hipStreamSynchronize(p->c->stream));
@@ -705,7 +705,7 @@ int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t cou
 
 int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64_t* pi_idx, const uint64_t* pi_val,
                            uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
-  if (!pr || !wires_dev || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return PLONK_ERR_ARG;
+  if (!pr || !wires_dev || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   return prover_prove(pr->p, (const Fr*)wires_dev, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
@@ -713,12 +713,12 @@ int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64
 
 int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const uint64_t* pi_idx, const uint64_t* pi_val,
                        uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
-  if (!pr || !wires || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return PLONK_ERR_ARG;
+  if (!pr || !wires || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   for (int k = 0; k < 4; ++k) {
-    if (!wires[k]) return PLONK_ERR_ARG;
+    if (!wires[k]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
     HIP_TRY(hipMemcpyAsync(p->wires + k * p->n, wires[k], sizeof(Fr) * p->n, hipMemcpyHostToDevice, p->c->stream));
   }
   return prover_prove(p, p->wires, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);

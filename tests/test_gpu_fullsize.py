@@ -1,0 +1,38 @@
+"""GPU, BASELINE sizes: proofs produced at 2^16 and 2^20 gates (bench.py's workload) must
+satisfy the verification equation of reference proof.rs:218-507, checked by the known-tau
+verifier of oracle/verifier.py — a size-independent acceptance test where no CPU prover can
+serve as oracle.  Also: proofs are deterministic and change with the blinders."""
+import pytest
+
+import bench
+from oracle import bls12_381 as E
+from oracle.verifier import verify_with_tau
+
+pytestmark = pytest.mark.gpu
+Q = E.Q
+
+
+@pytest.mark.parametrize("log_n", [16, 20])
+def test_bench_proof_verifies(log_n):
+    import plonk_amd
+    ctx = plonk_amd.Context(0)
+    prover, wbuf, srs_total = bench.build_prover(ctx, log_n, 0, 1, None)
+    tau, g = 0x5EED0000 * 0x9E3779B97F4A7C15 % Q, 0xA5A5A5A5DEADBEEF
+    srs_g = E.g1_mul(E.G1_GEN, g)
+    raw = prover.vk_commitments()
+    vk = {name: E.g1_decompress(raw[48 * i:48 * i + 48]) for i, name in enumerate(plonk_amd.POLY_ORDER)}
+    bl1 = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
+    bl2 = plonk_amd.fr_to_bytes_mont([(0xC0FFEE00 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
+    p1 = prover.prove_dev(wbuf.ptr, {}, bl1)
+    p1b = prover.prove_dev(wbuf.ptr, {}, bl1)
+    p2 = prover.prove_dev(wbuf.ptr, {}, bl2)
+    assert p1 == p1b and p1 != p2
+    n = 1 << log_n
+    for p in (p1, p2):
+        assert verify_with_tau(p, vk, b"bench", n, {}, tau, srs_g)
+    bad = bytearray(p1)
+    bad[530] ^= 4
+    assert not verify_with_tau(bytes(bad), vk, b"bench", n, {}, tau, srs_g)
+    prover.close()
+    wbuf.free()
+    ctx.close()
