@@ -224,6 +224,14 @@ def main():
         avg_acc = acc_ms / max(acc_n, 1)
         acc_ms_per_prove = acc_ms / args.steps
         achieved = alg_bytes_per_prove / (acc_ms_per_prove * 1e-3) / 1e9 if acc_ms_per_prove > 0 else 0.0
+        traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, profiles/*/pmc.json)
+        if world == 1 and log_n == 20:
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json"))):
+                try:
+                    traffic = round(json.load(open(f))["traffic_bytes_per_launch"])
+                except Exception:
+                    pass
         out = {
             "metric": "prove() wall-clock (ms) at 2^%d gates" % log_n,
             "value": round(ms_per_step, 3), "unit": "ms", "n_gpus": world, "steps": args.steps,
@@ -238,7 +246,7 @@ def main():
             "proof_blake2b": __import__("hashlib").blake2b(proof).hexdigest()[:32],
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
+                         "traffic": traffic, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
                          "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
                          "launch_groups_per_prove": list(groups),
                          "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; see DESIGN.md"},
