@@ -327,37 +327,62 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   if (g == 0 && b < MSM_NB) st_g1r(buckets + b, acc);
 }
 
-// V_j = sum_{i < CHUNK} (CHUNK*j + i + 1) * B[CHUNK*j + i]
-__global__ void __launch_bounds__(64) msm_chunk_reduce_kernel(const G1RSlot* __restrict__ buckets_all,
-                                                              G1RSlot* __restrict__ chunk_all) {
-  const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
-  G1RSlot* __restrict__ chunk = chunk_all + (uint64_t)blockIdx.y * (MSM_NB / MSM_CHUNK);
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= MSM_NB / MSM_CHUNK) return;
-  G1R run = G1R::identity(), acc = G1R::identity();
-  for (int i = MSM_CHUNK - 1; i >= 0; --i) {
-    run = run.add(ld_g1r(buckets + j * MSM_CHUNK + i));
-    acc = acc.add(run);
-  }
-  if (j) acc = acc.add(run.mul_u32(j * MSM_CHUNK));
-  st_g1r(chunk + j, acc);
-}
+// ---- weighted bucket reduction  W = sum_{b=1..NB} b * B_b  in two shallow kernels -------------
+// Write b = 128 h + l with h in [0,256), l in [1,128]  (bucket array index b-1 = 128 h + (l-1)):
+//     W = sum_l l * C_l + 128 * sum_h h * R_h ,   C_l = sum_h B_{h,l} ,  R_h = sum_l B_{h,l} .
+// msm_rowcol_kernel forms the 256 row sums and 128 column sums with LDS trees (depth 8);
+// msm_final_kernel turns both weighted sums into sums of suffix sums (Hillis-Steele scans in LDS),
+// doubles the row part 7 times and tree-sums everything: ~24 dependent additions instead of the
+// ~70 of a running-sum-per-chunk scheme — these kernels are pure latency (one wave per SIMD).
+static constexpr uint32_t RC_ROWS = 256, RC_COLS = 128;
+static_assert(RC_ROWS * RC_COLS == MSM_NB, "row/column split must cover the bucket range");
 
-// sum of NB/CHUNK = 2048 chunk results -> one XYZZ point in the 12 x 32-bit form (192 B).
-// Affine normalisation (one Fp inversion) is left to the host / xyzz_to_affine97_kernel: a
-// single-lane Fermat inversion would add ~0.6 ms of serial latency to every MSM.
-__global__ void __launch_bounds__(256) msm_final_kernel(MsmBatch bt, const G1RSlot* __restrict__ chunk_all) {
-  const G1RSlot* __restrict__ chunk = chunk_all + (uint64_t)blockIdx.x * (MSM_NB / MSM_CHUNK);
-  G1* __restrict__ out = bt.out[blockIdx.x];
+__global__ void __launch_bounds__(256) msm_rowcol_kernel(const G1RSlot* __restrict__ buckets_all,
+                                                         G1RSlot* __restrict__ rc_all) {
   __shared__ G1R sh[256];
-  const uint32_t t = threadIdx.x;
-  constexpr uint32_t PER = (MSM_NB / MSM_CHUNK) / 256;
+  const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
+  G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * (RC_ROWS + RC_COLS);
+  const uint32_t t = threadIdx.x, blk = blockIdx.x;
   G1R acc = G1R::identity();
-  for (uint32_t k = 0; k < PER; ++k) acc = acc.add(ld_g1r(chunk + t * PER + k));
+  if (blk < RC_ROWS) {               // R_h : 128 buckets of row h
+    if (t < RC_COLS) acc = ld_g1r(buckets + blk * RC_COLS + t);
+  } else {                           // C_l : 256 buckets of column l0 = blk - 256
+    acc = ld_g1r(buckets + t * RC_COLS + (blk - RC_ROWS));
+  }
   for (uint32_t d = 128; d >= 1; d >>= 1) {
     sh[t] = acc;
     __syncthreads();
     if (t < d) acc = acc.add(sh[t + d]);
+    __syncthreads();
+  }
+  if (t == 0) st_g1r(rc + blk, acc);
+}
+
+// one workgroup of 384 lanes per commitment: lanes 0..255 own R_h, lanes 256..383 own C_l
+__global__ void __launch_bounds__(384) msm_final_kernel(MsmBatch bt, const G1RSlot* __restrict__ rc_all) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+  G1R* sh = reinterpret_cast<G1R*>(smem_raw);          // 384 points
+  const G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.x * (RC_ROWS + RC_COLS);
+  G1* __restrict__ out = bt.out[blockIdx.x];
+  const uint32_t t = threadIdx.x;
+  const bool is_row = t < RC_ROWS;
+  const uint32_t seg_end = is_row ? RC_ROWS : (RC_ROWS + RC_COLS);   // suffix scans stay inside the segment
+  G1R acc = ld_g1r(rc + t);
+  for (uint32_t d = 1; d < RC_ROWS; d <<= 1) {          // inclusive suffix scan: acc_t = sum_{j >= t} x_j
+    sh[t] = acc;
+    __syncthreads();
+    if (t + d < seg_end) acc = acc.add(sh[t + d]);
+    __syncthreads();
+  }
+  // rows: sum_h h R_h = sum_{k=1..255} Suf_k  (drop k = 0), times 128 ; cols: sum_l l C_l = sum_{k=0..127} Suf'_k
+  if (is_row) {
+    if (t == 0) acc = G1R::identity();
+    else for (int k = 0; k < 7; ++k) acc = acc.dbl();
+  }
+  for (uint32_t d = 256; d >= 1; d >>= 1) {             // tree over 384 (< 512) entries
+    sh[t] = acc;
+    __syncthreads();
+    if (t < d && t + d < RC_ROWS + RC_COLS) acc = acc.add(sh[t + d]);
     __syncthreads();
   }
   if (t == 0) st_g1(out, acc.to_g1());
@@ -481,9 +506,14 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   prof_begin(c, 2);
   hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB * BS_G / 128, count), dim3(128), 0, st, bt,
                      (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
-  hipLaunchKernelGGL(msm_chunk_reduce_kernel, dim3(MSM_NB / MSM_CHUNK / 64, count), dim3(64), 0, st,
-                     (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
-  hipLaunchKernelGGL(msm_final_kernel, dim3(count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk);
+  hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_ROWS + RC_COLS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
+                     (G1RSlot*)w.chunk);
+  {
+    constexpr size_t smem = sizeof(G1R) * (RC_ROWS + RC_COLS);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)msm_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    hipLaunchKernelGGL(msm_final_kernel, dim3(count), dim3(384), smem, st, bt, (const G1RSlot*)w.chunk);
+  }
   prof_end(c, 2);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
