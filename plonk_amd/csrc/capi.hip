@@ -122,7 +122,11 @@ int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
   HIP_TRY(hipSetDevice(dev));
   auto* ctx = new plonk_ctx();
   ctx->c.device = dev;
-  hipError_t e = hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking);
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  hipError_t e = hipStreamCreateWithPriority(&ctx->c.stream, hipStreamNonBlocking, prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->c.side_stream, hipStreamNonBlocking, prio_least);
+  ctx->c.main_stream = ctx->c.stream;
   if (e != hipSuccess) {
     set_last_error("hipStreamCreate", hipGetErrorString(e), __FILE__, __LINE__);
     delete ctx;
@@ -151,7 +155,8 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   (void)hipFree(w.cursors); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
   (void)hipFree(w.chunk); (void)hipFree(w.result); (void)hipFree(w.scalars_stage);
   if (w.result_host) (void)hipHostFree(w.result_host);
-  (void)hipStreamDestroy(c.stream);
+  (void)hipStreamDestroy(c.main_stream);
+  if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
   delete ctx;
 }
 

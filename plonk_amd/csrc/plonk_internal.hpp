@@ -70,7 +70,9 @@ struct MsmWork {   // per-stream scratch, grown on demand
 
 struct Ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;    // every launch goes to this stream (prover.hip swaps it for side work)
+  hipStream_t main_stream = nullptr;
+  hipStream_t side_stream = nullptr;   // low priority: challenge-independent NTTs overlapped with MSM phases
   std::mutex mu;         // serialises entry points (reference calls concurrently from rayon)
   std::mutex table_mu;
   std::map<uint32_t, NttTables*> ntt_tables;

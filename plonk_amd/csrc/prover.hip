@@ -45,7 +45,9 @@ struct Prover {
   Fr* pipoly = nullptr;            // [np]
   Fr* cos = nullptr;               // [6][n8] coset evals of z, a, b, c, d, pi
   Fr* tbuf = nullptr;              // [n8] quotient evals -> coefficients
-  Fr* tmp8 = nullptr;              // [n8] NTT scratch
+  Fr* tmp8 = nullptr;              // [n8] NTT scratch (main stream)
+  Fr* tmp8b = nullptr;             // [n8] NTT scratch (side stream)
+  hipEvent_t ev_ready = nullptr, ev_side = nullptr;
   Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
   Fr* agg = nullptr;               // [np] linear combination
   Fr* wit = nullptr;               // [np] opening witness polynomial W_z
@@ -155,6 +157,24 @@ static Fr var_identity(const Fr& ch, const Evals& e, const Fr& ed) {     // curv
 
 #define PTRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// Work that does not depend on a Fiat-Shamir challenge (the coset FFTs of the wire, public-input
+// and z polynomials) is issued on the context's low-priority side stream so it fills the
+// bandwidth-/latency-bound stretches of the MSM pipeline.  While a SideScope is alive every
+// launch helper (they all use c->stream) targets the side stream.
+struct SideScope {
+  Ctx* c;
+  explicit SideScope(Ctx* ctx, hipEvent_t wait_for) : c(ctx) {
+    (void)hipEventRecord(wait_for, c->main_stream);
+    (void)hipStreamWaitEvent(c->side_stream, wait_for, 0);
+    c->stream = c->side_stream;
+  }
+  ~SideScope() { c->stream = c->main_stream; }
+};
+struct SideJoin {   // never leave side work in flight when prove() returns (buffers are reused)
+  Ctx* c;
+  ~SideJoin() { (void)hipStreamSynchronize(c->side_stream); }
+};
+
 static constexpr int RES_STRIDE = 256;
 
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
@@ -210,10 +230,12 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
 
 static void prover_free(Prover* p) {
   if (!p) return;
-  void* bufs[] = {p->polys, p->evals8, p->sigma_n, p->wires, p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tmp8,
+  void* bufs[] = {p->polys, p->evals8, p->sigma_n, p->wires, p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tmp8, p->tmp8b,
                   p->tparts, p->agg, p->wit, p->wit2, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
+  if (p->ev_side) (void)hipEventDestroy(p->ev_side);
   if (p->res_host) (void)hipHostFree(p->res_host);
   if (p->gather_host) free(p->gather_host);
   if (p->ev_host) (void)hipHostFree(p->ev_host);
@@ -260,6 +282,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   ALLOC(p->cos, 6 * n8);
   ALLOC(p->tbuf, n8);
   ALLOC(p->tmp8, n8);
+  ALLOC(p->tmp8b, n8);
   ALLOC(p->tparts, 3 * np);
   ALLOC(p->agg, np);
   ALLOC(p->wit, np);
@@ -273,6 +296,8 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   ALLOC(p->len_dev, 1);
   ALLOC(p->flag_dev, 1);
 #undef ALLOC
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * RES_STRIDE, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->ev_host, 16 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->len_host, sizeof(unsigned long long), hipHostMallocDefault));
@@ -371,6 +396,31 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_fill_zero(c, wp + n, np - n));
     PTRY(poly_blind(c, wp, n, ba));
   }
+  SideJoin side_join{c};
+  uint64_t pi_len = 0;
+  {
+    // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
+    // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments below
+    SideScope side(c, p->ev_ready);
+    for (int k = 0; k < 4; ++k)
+      PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + 3, false, true, n + 2));
+    PTRY(poly_fill_zero(c, p->pipoly, np));
+    if (pi_count) {
+      if (pi_count > p->pi_cap) {
+        if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); }
+        HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
+        HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
+        p->pi_cap = pi_count;
+      }
+      for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+      HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
+      PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
+      PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8b, L, true, false, n));
+      pi_len = n;
+    }
+    PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + 3, false, true, pi_len));
+  }
   {
     const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
@@ -406,6 +456,11 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
     PTRY(poly_blind(c, p->zpoly, n, ba));
   }
+  {
+    SideScope side(c, p->ev_ready);   // z's coset FFT only needs z(X): overlap with its commitment
+    PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + 3, false, true, n + 3));
+    HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+  }
   PTRY(msm_to(p, p->zpoly, n + 3, 4));
   PTRY(fetch_commitments(p, 4, 1, comm + 4));
   tr.append_commitment("z_comm", comm[4]);
@@ -417,28 +472,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
   const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
   const Fr edwards_d = (fr_small(10240) * fr_small(10241).inv()).neg();   // dusk_jubjub::EDWARDS_D
-  // public-input polynomial (prover.rs:520-521)
-  PTRY(poly_fill_zero(c, p->pipoly, np));
-  uint64_t pi_len = 0;
-  if (pi_count) {
-    if (pi_count > p->pi_cap) {
-      if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); }
-      HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
-      HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
-      p->pi_cap = pi_count;
-    }
-    for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-    HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
-    PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
-    PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8, L, true, false, n));
-    pi_len = n;
-  }
-  // quotient (quotient_poly.rs:20-137): 6 coset FFTs on 8n, point-wise pass, coset iFFT
+  // quotient (quotient_poly.rs:20-137): the 6 coset FFTs on 8n were issued on the side stream in
+  // rounds 1-2; point-wise pass, then coset iFFT
+  HIP_TRY(hipStreamWaitEvent(c->main_stream, p->ev_side, 0));
   {
-    const Fr* srcs[6] = {p->zpoly, p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np, p->pipoly};
-    const uint64_t lens[6] = {n + 3, n + 2, n + 2, n + 2, n + 2, pi_len};
-    for (int k = 0; k < 6; ++k) PTRY(ntt_device(c, srcs[k], p->cos + k * n8, p->tmp8, L + 3, false, true, lens[k]));
     QuotientArgs q;
     q.n8 = n8;
     q.z = p->cos; q.a = p->cos + n8; q.b = p->cos + 2 * n8; q.c = p->cos + 3 * n8; q.d = p->cos + 4 * n8; q.pi = p->cos + 5 * n8;
