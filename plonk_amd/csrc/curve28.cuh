@@ -50,7 +50,7 @@ struct G1R {
   }
   HD static bool zero_mod(const Fp28& v) { return maybe_zero(v) && v.is_zero_mod(); }
 
-  // 2 * this.  In: X<16p Y<8p ZZ,ZZZ<2p.  Out: X<10p Y<6p ZZ,ZZZ<2p.
+  // 2 * this.  In: X<16p Y<8p ZZ,ZZZ<2p.  Out: X<10p Y<2p ZZ,ZZZ<2p.
   HD G1R dbl() const {
     if (is_identity()) return identity();   // (Y == 0 cannot happen in the prime-order group)
     const Fp28 U = Y.dbl();                                   // < 16p
@@ -60,9 +60,9 @@ struct G1R {
     const Fp28 XX = X.sqr();                                  // 16*16            -> < 2p
     const Fp28 M = Fp28::add(XX.dbl(), XX);                   // < 6p
     G1R r;
-    r.X = Fp28::sub<8>(M.sqr(), S.dbl());                     // 2p - (<4p) + 8p   -> < 10p
-    r.Y = Fp28::sub<4>(Fp28::mul(M, Fp28::sub<32>(S, r.X)),   // 6 * (2+32=34)     -> < 2p
-                       Fp28::mul(W, Y));                      // 2*8 ; 2p - 2p + 4p -> < 6p
+    r.X = Fp28::sub<8>(M.sqr(), Fp28::add_lazy(S, S));        // 2p - (<4p) + 8p   -> < 10p
+    r.Y = Fp28::mul2(M, Fp28::sub_lazy<32>(S, r.X),           // 6 * (2+32=34) = 204
+                     W, Fp28::neg_lazy<16>(Y));               // + 2 * 16 = 236    -> < 2p
     r.ZZ = Fp28::mul(V, ZZ);                                  // < 2p
     r.ZZZ = Fp28::mul(W, ZZZ);                                // < 2p
     return r;
@@ -70,13 +70,15 @@ struct G1R {
   HD static G1R dbl_affine(const Fp28& x, const Fp28& y) { return from_affine(x, y).dbl(); }
 
   // this + (x2, y2), affine operand never the identity; x2 < 2p, y2 < 4p (after negation).
+  // 8 products + 2 squarings, 9 Montgomery reductions (Y3 is one fused two-product reduction).
+  // In: X<16p Y<8p.  Out: X<14p Y<2p.
   HD G1R add_affine(const Fp28& x2, const Fp28& y2) const {
     if (is_identity()) return from_affine(x2, y2);
     const Fp28 U2 = Fp28::mul(x2, ZZ);                        // 2*2               -> < 2p
     const Fp28 S2 = Fp28::mul(y2, ZZZ);                       // 4*2               -> < 2p
-    const Fp28 P_ = Fp28::sub<32>(U2, X);                     // X<16p             -> < 34p
-    const Fp28 R_ = Fp28::sub<16>(S2, Y);                     // Y<8p              -> < 18p
-    if (maybe_zero(P_) && P_.is_zero_mod()) {
+    const Fp28 P_ = Fp28::sub_lazy<32>(U2, X);                // X<16p  -> < 34p, lazy limbs
+    const Fp28 R_ = Fp28::sub<16>(S2, Y);                     // Y<8p   -> < 18p, normalised
+    if (maybe_zero(P_) && P_.normalized().is_zero_mod()) {
       if (R_.is_zero_mod()) return dbl_affine(x2, y2);
       return identity();
     }
@@ -84,9 +86,10 @@ struct G1R {
     const Fp28 PPP = Fp28::mul(P_, PP);                       // 34*2              -> < 2p
     const Fp28 Q_ = Fp28::mul(X, PP);                         // 16*2              -> < 2p
     G1R r;
-    r.X = Fp28::sub<8>(Fp28::sub<4>(R_.sqr(), PPP), Q_.dbl()); // 18*18=324; 2p+4p+8p -> < 14p
-    r.Y = Fp28::sub<4>(Fp28::mul(R_, Fp28::sub<32>(Q_, r.X)),  // 18 * 34 = 612     -> < 2p
-                       Fp28::mul(Y, PPP));                     // 8*2 ; +4p         -> < 6p
+    r.X = Fp28::sub<8>(Fp28::sub_lazy<4>(R_.sqr(), PPP),      // 18*18=324; 2p + 4p
+                       Fp28::add_lazy(Q_, Q_));               // - (<4p) + 8p      -> < 14p
+    r.Y = Fp28::mul2(R_, Fp28::sub_lazy<32>(Q_, r.X),         // 18 * (2+32=34) = 612
+                     PPP, Fp28::neg_lazy<16>(Y));             // + 2 * 16 = 644    -> < 2p
     r.ZZ = Fp28::mul(ZZ, PP);                                 // < 2p
     r.ZZZ = Fp28::mul(ZZZ, PPP);                              // < 2p
     return r;
@@ -100,9 +103,9 @@ struct G1R {
     const Fp28 U2 = Fp28::mul(b.X, ZZ);
     const Fp28 S1 = Fp28::mul(Y, b.ZZZ);                      // 8*2  -> < 2p
     const Fp28 S2 = Fp28::mul(b.Y, ZZZ);
-    const Fp28 P_ = Fp28::sub<4>(U2, U1);                     // < 6p
-    const Fp28 R_ = Fp28::sub<4>(S2, S1);                     // < 6p
-    if (maybe_zero(P_) && P_.is_zero_mod()) {
+    const Fp28 P_ = Fp28::sub_lazy<4>(U2, U1);                // < 6p, lazy limbs
+    const Fp28 R_ = Fp28::sub<4>(S2, S1);                     // < 6p, normalised
+    if (maybe_zero(P_) && P_.normalized().is_zero_mod()) {
       if (R_.is_zero_mod()) return dbl();
       return identity();
     }
@@ -110,8 +113,8 @@ struct G1R {
     const Fp28 PPP = Fp28::mul(P_, PP);
     const Fp28 Q_ = Fp28::mul(U1, PP);
     G1R r;
-    r.X = Fp28::sub<8>(Fp28::sub<4>(R_.sqr(), PPP), Q_.dbl()); // < 14p
-    r.Y = Fp28::sub<4>(Fp28::mul(R_, Fp28::sub<32>(Q_, r.X)), Fp28::mul(S1, PPP));   // < 6p
+    r.X = Fp28::sub<8>(Fp28::sub_lazy<4>(R_.sqr(), PPP), Fp28::add_lazy(Q_, Q_));   // < 14p
+    r.Y = Fp28::mul2(R_, Fp28::sub_lazy<32>(Q_, r.X), PPP, Fp28::neg_lazy<4>(S1));  // 6*34 + 2*4 -> < 2p
     r.ZZ = Fp28::mul(Fp28::mul(ZZ, b.ZZ), PP);
     r.ZZZ = Fp28::mul(Fp28::mul(ZZZ, b.ZZZ), PPP);
     return r;

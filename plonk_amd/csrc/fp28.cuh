@@ -76,8 +76,10 @@ struct Fp28 {
     }
   }
 
-  // Montgomery product a*b/R' ; operands normalised, values bounded by a_k*p, b_k*p with
-  // a_k*b_k < 2528 ; result normalised and < 2p.
+  // Montgomery product a*b/R' ; values bounded by a_k*p, b_k*p with a_k*b_k < 2528 ; result
+  // normalised and < 2p.  Operands may be LAZY (limbs < 2^30, i.e. the un-normalised output of
+  // sub_lazy / add_lazy): a column accumulator receives at most 14 products a_j*b_i < 2^60 and
+  // 14 products m*p_j < 2^56 during its life, 14 * (2^60 + 2^56) < 2^63.9.
   HD static Fp28 mul(const Fp28& a, const Fp28& b) {
     uint64_t acc[N];
 #pragma unroll
@@ -105,7 +107,72 @@ struct Fp28 {
     r.l[N - 1] = (uint32_t)acc[N - 1];
     return r;
   }
-  HD Fp28 sqr() const { return mul(*this, *this); }
+  // a*a/R' with the symmetric half of the partial products (105 instead of 196 mads): row i
+  // adds a_i^2 and the doubled products 2 a_i a_j (j > i) into the columns i + j; column i is
+  // complete when row i reduces it because every pair (k, i - k) was added by row min(k, i - k).
+  // Same column totals as mul(a, a), hence the same bounds (operand may be lazy).
+  HD Fp28 sqr() const {
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t ai = l[i], ai2 = l[i] << 1;
+      acc[i] += (uint64_t)ai * ai;
+#pragma unroll
+      for (int j = i + 1; j < N; ++j) acc[j] += (uint64_t)l[j] * ai2;
+      // rows shift the window down by one column per iteration: position j holds column i + j,
+      // so the products above were placed at positions (i + j) - i = j  [a_i^2 -> 2i - i = i]
+      const uint32_t m = ((uint32_t)acc[0] * INV) & MASK;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * mod(j);
+      const uint64_t carry = acc[0] >> B;
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
+      acc[N - 1] = 0;
+      acc[0] += carry;
+    }
+    Fp28 r;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      acc[j + 1] += acc[j] >> B;
+      r.l[j] = (uint32_t)acc[j] & MASK;
+    }
+    r.l[N - 1] = (uint32_t)acc[N - 1];
+    return r;
+  }
+  // (a*b + c*d)/R' with ONE Montgomery reduction.  Limb bounds: at most one operand of each
+  // product lazy (limbs < 2^30), the other normalised: 14 * (2^58 + 2^58 + 2^56) < 2^63.
+  // Value bounds: a_k*b_k + c_k*d_k < 2528 ; result normalised and < 2p.
+  HD static Fp28 mul2(const Fp28& a, const Fp28& b, const Fp28& c, const Fp28& d) {
+    uint64_t acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const uint32_t bi = b.l[i], di = d.l[i];
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += (uint64_t)a.l[j] * bi;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += (uint64_t)c.l[j] * di;
+      const uint32_t m = ((uint32_t)acc[0] * INV) & MASK;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] += (uint64_t)m * mod(j);
+      const uint64_t carry = acc[0] >> B;
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) acc[j] = acc[j + 1];
+      acc[N - 1] = 0;
+      acc[0] += carry;
+    }
+    Fp28 r;
+#pragma unroll
+    for (int j = 0; j < N - 1; ++j) {
+      acc[j + 1] += acc[j] >> B;
+      r.l[j] = (uint32_t)acc[j] & MASK;
+    }
+    r.l[N - 1] = (uint32_t)acc[N - 1];
+    return r;
+  }
 
   // value(a) + value(b), normalised
   HD static Fp28 add(const Fp28& a, const Fp28& b) {
@@ -122,6 +189,35 @@ struct Fp28 {
     Fp28 r;
 #pragma unroll
     for (int i = 0; i < N; ++i) r.l[i] = a.l[i] + (pad<K>(i) - b.l[i]);
+    r.normalize();
+    return r;
+  }
+
+  // ---- lazy forms: no carry propagation; limbs < 2^30 as long as the inputs are normalised.
+  // Valid as operands of mul / sqr / mul2 (see their limb bounds), as the minuend of sub<K>,
+  // and (add_lazy of two normalised values, limbs <= 2^29 - 2) as its subtrahend.
+  HD static Fp28 add_lazy(const Fp28& a, const Fp28& b) {
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = a.l[i] + b.l[i];
+    return r;
+  }
+  template <int K>
+  HD static Fp28 sub_lazy(const Fp28& a, const Fp28& b) {   // a, b normalised, value(b) < (K/2) p
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = a.l[i] + (pad<K>(i) - b.l[i]);
+    return r;
+  }
+  template <int K>
+  HD static Fp28 neg_lazy(const Fp28& b) {                  // K p - value(b)
+    Fp28 r;
+#pragma unroll
+    for (int i = 0; i < N; ++i) r.l[i] = pad<K>(i) - b.l[i];
+    return r;
+  }
+  HD Fp28 normalized() const {
+    Fp28 r = *this;
     r.normalize();
     return r;
   }

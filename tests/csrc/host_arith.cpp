@@ -47,6 +47,21 @@ void h_fp28_chain(const uint32_t* a, const uint32_t* b, uint32_t* o) {
 int h_fp28_zero_test(const uint32_t* a) { Fp x; memcpy(&x, a, 48); Fp28 A = Fp28::from_fp(x); Fp28 z = Fp28::sub<4>(A, A); Fp28 z2 = Fp28::sub<32>(Fp28::add(Fp28::add(A, A), A.dbl().dbl()), Fp28::add(A.dbl(), A.dbl().dbl())); return (z.is_zero_mod() ? 1 : 0) | (z2.is_zero_mod() ? 2 : 0) | (A.is_zero_mod() ? 4 : 0); }
 void h_fp28_roundtrip(const uint32_t* a, uint32_t* o) { Fp x; memcpy(&x, a, 48); Fp r = Fp28::from_fp(x).to_fp(); memcpy(o, &r, 48); }
 }
+// raw-limb access (14 x u32, possibly lazy): op 0 = mul(a,b), 1 = a.sqr(), 2 = mul2(a,b,c,d)
+extern "C" void h_fp28_raw(int op, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint32_t* o) {
+  Fp28 A, Bv, C, D;
+  memcpy(A.l, a, 56); memcpy(Bv.l, b, 56); memcpy(C.l, c, 56); memcpy(D.l, d, 56);
+  Fp28 r = op == 0 ? Fp28::mul(A, Bv) : op == 1 ? A.sqr() : Fp28::mul2(A, Bv, C, D);
+  memcpy(o, r.l, 56);
+}
+// lazy helpers on normalised inputs: op 0 = sub_lazy<32>(a,b), 1 = neg_lazy<16>(b), 2 = add_lazy(a,b)
+extern "C" void h_fp28_lazy(int op, const uint32_t* a, const uint32_t* b, uint32_t* o) {
+  Fp28 A, Bv;
+  memcpy(A.l, a, 56); memcpy(Bv.l, b, 56);
+  Fp28 r = op == 0 ? Fp28::sub_lazy<32>(A, Bv) : op == 1 ? Fp28::neg_lazy<16>(Bv) : Fp28::add_lazy(A, Bv);
+  memcpy(o, r.l, 56);
+}
+
 // ---- XYZZ over Fp28 (curve28.cuh) ----
 #include "../../plonk_amd/csrc/curve28.cuh"
 extern "C" {

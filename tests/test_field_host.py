@@ -135,6 +135,55 @@ def test_fp28_reduced_radix_matches_oracle(lib):
         assert flags & 3 == 3 and bool(flags & 4) == (a == 0)
 
 
+def test_fp28_lazy_operands_sqr_and_fused_product(lib):
+    """fp28.cuh: dedicated squaring, mul2 (two products, one reduction) and lazy (un-normalised,
+    limbs < 2^30) operands, checked on raw limbs incl. the all-ones patterns that maximise the
+    64-bit column accumulators."""
+    rnd = random.Random(28)
+    M28 = (1 << 28) - 1
+    RINV = pow(1 << 392, -1, P)
+    A14 = ctypes.c_uint32 * 14
+
+    def limbs(v):   # normalised 14 x 28
+        return [(v >> (28 * i)) & M28 for i in range(14)]
+
+    def val(ls):
+        return sum(int(x) << (28 * i) for i, x in enumerate(ls))
+
+    def run(op, a, b, c, d):
+        out = A14()
+        lib.h_fp28_raw(op, A14(*a), A14(*b), A14(*c), A14(*d), out)
+        assert all(x <= M28 for x in out[:13]), "result not normalised"
+        return val(out)
+
+    def lazy(op, a, b):
+        out = A14()
+        lib.h_fp28_lazy(op, A14(*a), A14(*b), out)
+        return list(out)
+
+    ones = [M28] * 13 + [0x1a010]            # < p, every low limb saturated
+    norm = [limbs(rnd.randrange(2 * P)) for _ in range(6)] + [ones, limbs(0), limbs(1), limbs(P - 1), limbs(2 * P - 1)]
+    zero = limbs(0)
+    for a in norm:
+        for b in norm:
+            # lazy minuend/subtrahend combos (values: a - b + 32p < 34p needs b < 16p: ok, b < 2p)
+            la = lazy(0, a, b)
+            assert max(la) < (1 << 30) and val(la) == val(a) + 32 * P - val(b)
+            nb = lazy(1, zero, b)
+            assert val(nb) == 16 * P - val(b)
+            r = run(1, la, zero, zero, zero)                       # sqr of a lazy operand, value < 34p
+            assert r < 2 * P and r % P == val(la) ** 2 * RINV % P
+            r = run(0, la, la, zero, zero)                         # lazy x lazy through mul
+            assert r < 2 * P and r % P == val(la) ** 2 * RINV % P
+            r = run(1, a, zero, zero, zero)
+            assert r < 2 * P and r % P == val(a) ** 2 * RINV % P
+            # mul2 as the point formulas use it: (norm x lazy) + (norm x lazy)
+            r = run(2, a, la, b, nb)
+            assert r < 2 * P and r % P == (val(a) * val(la) + val(b) * val(nb)) * RINV % P
+            dbl = lazy(2, b, b)
+            assert val(dbl) == 2 * val(b)
+
+
 def test_g1_xyzz_over_fp28_matches_oracle(lib):
     """curve28.cuh: lazily-reduced XYZZ formulas — long accumulation chains (bounds must stay
     closed), negated operands, P + P and P + (-P) through the mixed and the full addition."""
