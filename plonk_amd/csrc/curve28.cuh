@@ -69,17 +69,18 @@ struct G1R {
   }
   HD static G1R dbl_affine(const Fp28& x, const Fp28& y) { return from_affine(x, y).dbl(); }
 
-  // this + (x2, y2), affine operand never the identity; x2 < 2p, y2 < 4p (after negation).
+  // this + (x2, y2), affine operand never the identity; x2 < 2p, y2 < 4p (after negation; y2
+  // may carry lazy limbs, it is normalised only on the rare paths that store it).
   // 8 products + 2 squarings, 9 Montgomery reductions (Y3 is one fused two-product reduction).
   // In: X<16p Y<8p.  Out: X<14p Y<2p.
   HD G1R add_affine(const Fp28& x2, const Fp28& y2) const {
-    if (is_identity()) return from_affine(x2, y2);
+    if (is_identity()) return from_affine(x2, y2.normalized());
     const Fp28 U2 = Fp28::mul(x2, ZZ);                        // 2*2               -> < 2p
     const Fp28 S2 = Fp28::mul(y2, ZZZ);                       // 4*2               -> < 2p
     const Fp28 P_ = Fp28::sub_lazy<32>(U2, X);                // X<16p  -> < 34p, lazy limbs
     const Fp28 R_ = Fp28::sub<16>(S2, Y);                     // Y<8p   -> < 18p, normalised
     if (maybe_zero(P_) && P_.normalized().is_zero_mod()) {
-      if (R_.is_zero_mod()) return dbl_affine(x2, y2);
+      if (R_.is_zero_mod()) return dbl_affine(x2, y2.normalized());
       return identity();
     }
     const Fp28 PP = P_.sqr();                                 // 34*34 = 1156      -> < 2p

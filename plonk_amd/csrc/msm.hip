@@ -288,13 +288,25 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   const uint32_t bend = offsets[b + 1];
   if (end > bend) end = bend;
   G1R acc = G1R::identity();
+  // software pipeline: the table entry of step k+1 is in flight while step k's ~5k VALU
+  // instructions run (two waves per SIMD are not enough to hide a 128-B gather otherwise)
+  uint32_t ent = entries[beg];
+  Fp28 x = ld_f28(&table[ent & 0x7fffffffu].x);
+  Fp28 y = ld_f28(&table[ent & 0x7fffffffu].y);
   for (uint32_t k = beg; k < end; ++k) {
-    const uint32_t ent = entries[k];
-    const G1AffineR* e = table + (ent & 0x7fffffffu);
-    const Fp28 x = ld_f28(&e->x);
-    Fp28 y = ld_f28(&e->y);
-    if (ent & 0x80000000u) y = Fp28::sub<4>(Fp28::zero(), y);   // -y : 4p - y < 4p
-    acc = acc.add_affine(x, y);
+    const uint32_t ent_c = ent;
+    const Fp28 xc = x, yc = y;
+    if (k + 1 < end) {
+      ent = entries[k + 1];
+      x = ld_f28(&table[ent & 0x7fffffffu].x);
+      y = ld_f28(&table[ent & 0x7fffffffu].y);
+    }
+    // -y as 4p - y without carry propagation (lazy limbs): it only feeds a product
+    Fp28 y2;
+    const bool neg = ent_c & 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < Fp28::N; ++i) y2.l[i] = neg ? Fp28::pad<4>(i) - yc.l[i] : yc.l[i];
+    acc = acc.add_affine(xc, y2);
   }
   st_g1r(partial + s, acc);
 }
