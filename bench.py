@@ -224,12 +224,15 @@ def main():
         avg_acc = acc_ms / max(acc_n, 1)
         acc_ms_per_prove = acc_ms / args.steps
         achieved = alg_bytes_per_prove / (acc_ms_per_prove * 1e-3) / 1e9 if acc_ms_per_prove > 0 else 0.0
+        valu_busy = None   # SQ_ACTIVE_INST_VALU / SIMD time of the same kernel, same PMC passes
         traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, profiles/*/pmc.json)
         if world == 1 and log_n == 20:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json"))):
                 try:
-                    traffic = round(json.load(open(f))["traffic_bytes_per_launch"])
+                    pj = json.load(open(f))
+                    traffic = round(pj["traffic_bytes_per_launch"])
+                    valu_busy = pj.get("valu_busy_frac")
                 except Exception:
                     pass
         out = {
@@ -246,7 +249,7 @@ def main():
             "proof_blake2b": __import__("hashlib").blake2b(proof).hexdigest()[:32],
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
+                         "traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3), "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
                          "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
                          "launch_groups_per_prove": list(groups),
                          "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; see DESIGN.md"},

@@ -55,7 +55,21 @@ if acc in pm["FETCH_SIZE"]:
     out.append("* algorithmic bytes per launch (bench.py): (32 b + 96) m averaged over the groups = 0.193 GB.  The excess is by design: 16 precomputed "
                "window tables are gathered (16 x 128 B per term) so that all windows share one bucket set; the kernel is integer-VALU bound, not HBM bound.")
     import json
+    valu = None
+    try:
+        a = agg["plonk::msm_accumulate_kernel"]
+        # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles summed over waves (MI355X_MICROARCH.md,
+        # "s_memtime tick vs SQ PMC units"); the kernel runs 2 waves per SIMD (216 VGPRs), so SIMD time =
+        # WAVE_CYCLES / 2 and VALU-busy = ACTIVE_INST_VALU / (WAVE_CYCLES / 2).
+        valu = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
+        out.append(f"\n## VALU utilisation of msm_accumulate\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu:.2f}** — "
+                   "the integer VALU pipe is saturated; only fewer instructions per point addition make this kernel faster.")
+        b = agg["void plonk::ntt_pass_kernel<8, false>"]
+        out.append(f"Same ratio for `ntt_pass_kernel<8,false>` (2 workgroups x 4 waves per CU = 2 waves per SIMD): {b['SQ_ACTIVE_INST_VALU'] / (b['SQ_WAVE_CYCLES'] / 2):.2f}.")
+    except Exception as e:  # noqa
+        out.append(f"\n(VALU utilisation unavailable: {e})")
     json.dump({"kernel": "msm_accumulate_kernel", "workload": "bench.py 2^20 gates, 1 GPU", "fetch_size_kib_per_launch": fa,
+               "valu_busy_frac": valu, "valu_busy_formula": "SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD), quad-cycle units",
                "write_size_kib_per_launch": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
                "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes"},
               open(dst + "pmc.json", "w"), indent=1)
