@@ -49,7 +49,10 @@ enum {
   PLONK_ERR_NO_SRS = -4,  /* plonk_msm before plonk_srs_load                            */
   PLONK_ERR_NO_GPU = -5,  /* no gfx950 device visible                                   */
   PLONK_ERR_UNSAT = -6,   /* prover: quotient degree check failed (CircuitUnsatisfied)  */
-  PLONK_ERR_STATE = -7    /* prover: called out of order / missing key                  */
+  PLONK_ERR_STATE = -7,   /* prover: called out of order / missing key                  */
+  PLONK_ERR_BYTES = -8,   /* serialized input too short (Error::NotEnoughBytes)         */
+  PLONK_ERR_DATA = -9,    /* serialized input malformed (dusk_bytes::Error::InvalidData) */
+  PLONK_ERR_POINT = -10   /* commit-key point off curve / not in the subgroup (Error::PointMalformed) */
 };
 
 /* `devices`: HIP device ordinals; ndev must be 1 (one process per GPU — multi-GPU runs
@@ -154,6 +157,31 @@ int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const ui
 int plonk_prover_prove_dev(plonk_prover* p, const void* wires_dev, const uint64_t* pi_idx,
                            const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
                            uint8_t proof[1008]);
+
+/* ---- serialized Prover ---------------------------------------------------------------
+ * plonk_prover_from_bytes replaces Prover::try_from_bytes (src/compiler/prover.rs:266-345): `blob`
+ * is exactly what the reference's Prover::to_bytes() writes (prover.rs:238-263 — six big-endian u64
+ * lengths, label, ProverKey::to_var_bytes widget.rs:347-447, CommitKey::to_raw_var_bytes
+ * key.rs:215-229, VerifierKey::to_bytes widget.rs:84-111).  It validates the blob as the
+ * reference does (errors: PLONK_ERR_BYTES / PLONK_ERR_DATA / PLONK_ERR_POINT), loads the commit
+ * key into `ctx` (replacing any SRS it held) and builds the device prover.  The 8n evaluation
+ * arrays in the blob are validated structurally and then rebuilt on the device from the
+ * coefficient forms.
+ * plonk_prover_blob_check is the host-only decoder/validator (no GPU, no context): offsets of the
+ * pieces inside `blob`; polynomials in the plonk_prover_desc order.  It checks the curve
+ * equation of the commit-key points; the subgroup check needs the GPU (plonk_srs_validate).
+ * plonk_srs_validate: CommitKey::from_raw_var_bytes' per-point is_on_curve & is_torsion_free
+ * (key.rs:283-294) for x||y points as taken by plonk_srs_load. */
+typedef struct {
+  uint64_t size, constraints;
+  uint64_t label_off, label_len;
+  uint64_t poly_off[15], poly_len[15]; /* canonical 32-byte little-endian scalars */
+  uint64_t srs_off, srs_points;        /* 97-byte raw points (x || y || infinity) */
+  uint64_t vk_off;                     /* 15 x 48 bytes, VerifierKey::to_bytes order */
+} plonk_prover_blob_info;
+int plonk_prover_blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob_info* info);
+int plonk_prover_from_bytes(plonk_ctx* ctx, const uint8_t* blob, uint64_t len, plonk_prover** out);
+int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
 
 /* ---- measurement --------------------------------------------------------------
  * When enabled, every launch of the dominant kernels is bracketed by a hipEvent

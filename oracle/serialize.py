@@ -1,0 +1,93 @@
+"""Prover::to_bytes restatement (oracle; test infrastructure only).
+
+Produces the exact byte layout the reference writes, so that the product-side loader
+(`plonk_prover_from_bytes`, plonk_amd/csrc/serial.hip) can be tested against blobs a real
+dusk-plonk `Prover::to_bytes()` would hand over.
+
+Follows (paths relative to the dusk-network/plonk tree):
+  src/compiler/prover.rs:211-263          Prover::prepare_serialize / to_bytes — six big-endian
+                                           u64 (label, prover-key, commit-key, verifier-key
+                                           lengths, size, constraints), then the four sections
+  src/proof_system/widget.rs:347-447      ProverKey::to_var_bytes — n, evaluation size, 15 x
+                                           (poly len, poly, 8n evaluations), linear evaluations,
+                                           v_h_coset_8n (dusk-bytes integers are little-endian)
+  src/fft/polynomial.rs:141-149           Polynomial::to_var_bytes — canonical 32-byte LE scalars
+  src/fft/evaluations.rs:52-61            Evaluations::to_var_bytes — domain, then the scalars
+  src/fft/domain.rs:59-79                 EvaluationDomain::to_bytes — 8 + 4 + 5 x 32 = 172 bytes
+  src/commitment_scheme/kzg10/key.rs:215-229   CommitKey::to_raw_var_bytes — u64 LE count, then
+                                           97-byte raw points (x || y Montgomery limbs || infinity)
+  src/proof_system/widget.rs:84-111       VerifierKey::to_bytes — u64 n + 15 compressed
+                                           commitments inside a 20 x 48 + 8 = 968-byte buffer
+"""
+from __future__ import annotations
+
+from . import bls12_381 as E
+from .bls12_381 import Q
+from .fft import EvaluationDomain
+
+# order in which ProverKey::to_var_bytes writes the (polynomial, evaluations) pairs
+BLOB_POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_logic", "q_range",
+                   "q_fixed_group_add", "q_variable_group_add",
+                   "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+# order of the commitments in VerifierKey::to_bytes
+VK_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_logic", "q_range",
+            "q_fixed_group_add", "q_variable_group_add",
+            "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+VERIFIER_KEY_SIZE = 20 * 48 + 8
+DOMAIN_SIZE = 8 + 4 + 5 * 32
+
+
+def scalar_bytes(x: int) -> bytes:
+    return (x % Q).to_bytes(32, "little")
+
+
+def domain_to_bytes(d: EvaluationDomain) -> bytes:
+    out = d.size.to_bytes(8, "little") + d.log_size_of_group.to_bytes(4, "little")
+    for v in (d.size_as_field_element, d.size_inv, d.group_gen, d.group_gen_inv, d.generator_inv):
+        out += scalar_bytes(v)
+    assert len(out) == DOMAIN_SIZE
+    return out
+
+
+def evaluations_to_var_bytes(evals, d: EvaluationDomain) -> bytes:
+    assert len(evals) == d.size
+    return domain_to_bytes(d) + b"".join(scalar_bytes(v) for v in evals)
+
+
+def polynomial_to_var_bytes(coeffs) -> bytes:
+    return b"".join(scalar_bytes(c) for c in coeffs)   # already trimmed (degree + 1 coefficients)
+
+
+def prover_key_to_var_bytes(pk) -> bytes:
+    d8 = EvaluationDomain(8 * pk.n)
+    eval_size = 8 * pk.n * 32 + DOMAIN_SIZE
+    out = [pk.n.to_bytes(8, "little"), eval_size.to_bytes(8, "little")]
+    for name in BLOB_POLY_ORDER:
+        poly = pk.polys[name]
+        out.append(len(poly).to_bytes(8, "little"))
+        out.append(polynomial_to_var_bytes(poly))
+        out.append(evaluations_to_var_bytes(pk.evals8[name], d8))
+    out.append(evaluations_to_var_bytes(pk.evals8["linear"], d8))
+    out.append(evaluations_to_var_bytes(pk.v_h_coset_8n, d8))
+    return b"".join(out)
+
+
+def commit_key_to_raw_var_bytes(ck) -> bytes:
+    out = [len(ck).to_bytes(8, "little")]
+    for pt in ck:
+        out.append(E.g1_to_raw96(pt) + b"\x00")
+    return b"".join(out)
+
+
+def verifier_key_to_bytes(vk: dict) -> bytes:
+    out = vk["n"].to_bytes(8, "little") + b"".join(E.g1_compress(vk[name]) for name in VK_ORDER)
+    return out + bytes(VERIFIER_KEY_SIZE - len(out))
+
+
+def prover_to_bytes(prover) -> bytes:
+    pk = prover_key_to_var_bytes(prover.pk)
+    ck = commit_key_to_raw_var_bytes(prover.ck)
+    vk = verifier_key_to_bytes(prover.vk)
+    head = b"".join(v.to_bytes(8, "big") for v in (len(prover.label), len(pk), len(ck), len(vk),
+                                                   prover.size, prover.constraints))
+    return head + prover.label + pk + ck + vk

@@ -32,7 +32,8 @@ PLONK_OK = 0
 ERRORS = {
     -1: "PLONK_ERR_ARG", -2: "PLONK_ERR_HIP", -3: "PLONK_ERR_DEGREE (PolynomialDegreeTooLarge)",
     -4: "PLONK_ERR_NO_SRS", -5: "PLONK_ERR_NO_GPU", -6: "PLONK_ERR_UNSAT (CircuitUnsatisfied)",
-    -7: "PLONK_ERR_STATE",
+    -7: "PLONK_ERR_STATE", -8: "PLONK_ERR_BYTES (NotEnoughBytes)", -9: "PLONK_ERR_DATA (InvalidData)",
+    -10: "PLONK_ERR_POINT (PointMalformed)",
 }
 
 # every symbol include/plonk_hip.h declares (checked by tests/test_capi_symbols.py)
@@ -44,6 +45,7 @@ EXPORTS = [
     "plonk_profile_enable", "plonk_profile_read", "plonk_profile_reset",
     "plonk_prover_create", "plonk_prover_destroy", "plonk_prover_vk", "plonk_prover_size",
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
+    "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -55,6 +57,12 @@ class _ProverDesc(ctypes.Structure):
                 ("polys", ctypes.c_void_p * 15), ("poly_len", ctypes.c_uint64 * 15),
                 ("vk_commitments", ctypes.c_char_p), ("shard_rank", ctypes.c_int), ("shard_world", ctypes.c_int),
                 ("srs_total", ctypes.c_uint64), ("allgather", ctypes.c_void_p), ("allgather_user", ctypes.c_void_p)]
+
+
+class _BlobInfo(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_uint64), ("constraints", ctypes.c_uint64), ("label_off", ctypes.c_uint64),
+                ("label_len", ctypes.c_uint64), ("poly_off", ctypes.c_uint64 * 15), ("poly_len", ctypes.c_uint64 * 15),
+                ("srs_off", ctypes.c_uint64), ("srs_points", ctypes.c_uint64), ("vk_off", ctypes.c_uint64)]
 
 
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
@@ -75,6 +83,21 @@ class PlonkError(RuntimeError):
     def __init__(self, code: int, detail: str = ""):
         self.code = code
         super().__init__(f"{ERRORS.get(code, code)} {detail}".strip())
+
+
+class NotEnoughBytes(PlonkError):
+    """Mirrors Error::NotEnoughBytes (reference prover.rs:274,310; widget.rs:484; key.rs:265,281)."""
+
+
+class InvalidData(PlonkError):
+    """Mirrors dusk_bytes::Error::InvalidData as the reference's decoders raise it."""
+
+
+class PointMalformed(PlonkError):
+    """Mirrors Error::PointMalformed (reference key.rs:292)."""
+
+
+_DECODE_ERRORS = {-8: NotEnoughBytes, -9: InvalidData, -10: PointMalformed}
 
 
 class PolynomialDegreeTooLarge(PlonkError):
@@ -126,8 +149,27 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_prover_peek.argtypes = [vp, ci, u64, u64, vp]
     lib.plonk_prover_prove.argtypes = [vp, ctypes.POINTER(vp), vp, vp, u64, vp, vp]
     lib.plonk_prover_prove_dev.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+    lib.plonk_prover_blob_check.argtypes = [vp, u64, ctypes.POINTER(_BlobInfo)]
+    lib.plonk_prover_from_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
+    lib.plonk_srs_validate.argtypes = [vp, vp, u64]
     _lib = lib
     return lib
+
+
+def prover_blob_check(blob: bytes) -> dict:
+    """Host-only decode + validation of a reference Prover::to_bytes() blob (no GPU needed):
+    returns the layout (offsets into `blob`) or raises NotEnoughBytes / InvalidData / PointMalformed."""
+    lib = load_library()
+    info = _BlobInfo()
+    rc = lib.plonk_prover_blob_check(blob, len(blob), ctypes.byref(info))
+    if rc in _DECODE_ERRORS:
+        raise _DECODE_ERRORS[rc](rc, (lib.plonk_last_error() or b"").decode())
+    if rc != PLONK_OK:
+        raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
+    return {"size": info.size, "constraints": info.constraints,
+            "label": blob[info.label_off:info.label_off + info.label_len],
+            "polys": {name: (info.poly_off[k], info.poly_len[k]) for k, name in enumerate(POLY_ORDER)},
+            "srs": (info.srs_off, info.srs_points), "vk_off": info.vk_off}
 
 
 # ---- marshalling -----------------------------------------------------------------
@@ -215,6 +257,8 @@ class Context:
             raise PolynomialDegreeTooLarge(rc)
         if rc == -6:
             raise CircuitUnsatisfied()
+        if rc in _DECODE_ERRORS:
+            raise _DECODE_ERRORS[rc](rc, (self.lib.plonk_last_error() or b"").decode())
         if rc != PLONK_OK:
             raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
 
@@ -339,6 +383,19 @@ class Prover:
         self.handle = h
         self.size = ctx.lib.plonk_prover_size(h)
         self._keep = None
+
+    @classmethod
+    def from_bytes(cls, ctx: Context, blob: bytes) -> "Prover":
+        """Prover::try_from_bytes (reference prover.rs:266-345) on the output of the reference's
+        Prover::to_bytes(): validates the blob, loads its commit key into `ctx` and builds the device
+        prover.  Raises NotEnoughBytes / InvalidData / PointMalformed like the reference."""
+        self = cls.__new__(cls)
+        self.ctx, self._cb, self._keep = ctx, None, None
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.plonk_prover_from_bytes(ctx.handle, blob, len(blob), ctypes.byref(h)))
+        self.handle = h
+        self.size = ctx.lib.plonk_prover_size(h)
+        return self
 
     def vk_commitments(self) -> bytes:
         out = ctypes.create_string_buffer(15 * 48)

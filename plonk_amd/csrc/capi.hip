@@ -255,6 +255,29 @@ int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
   return rc;
 }
 
+int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
+  if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  G1Affine* tmp = nullptr;
+  int* flag = nullptr;
+  HIP_TRY(hipMalloc((void**)&tmp, sizeof(G1Affine) * (npoints ? npoints : 1)));
+  if (hipMalloc((void**)&flag, sizeof(int)) != hipSuccess) { (void)hipFree(tmp); return PLONK_ERR_HIP; }
+  int bad = 0;
+  hipError_t e = hipMemcpyAsync(tmp, xy96, sizeof(G1Affine) * npoints, hipMemcpyHostToDevice, c.stream);
+  int rc = (e == hipSuccess) ? srs_validate_device(&c, tmp, npoints, flag) : PLONK_ERR_HIP;
+  if (rc == PLONK_OK && hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  if (hipStreamSynchronize(c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  (void)hipFree(tmp);
+  (void)hipFree(flag);
+  if (rc == PLONK_OK && bad) {
+    plonk::set_last_error("PointMalformed", "commit key point off the curve or outside the prime-order subgroup", __FILE__, __LINE__);
+    rc = PLONK_ERR_POINT;
+  }
+  return rc;
+}
+
 int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t g_scalar[4], uint64_t npoints,
                            void* out_dev) {
   if (!ctx || !tau || !g_scalar || !out_dev) return PLONK_ERR_ARG;

@@ -134,6 +134,29 @@ __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __
   }
 }
 
+// CommitKey::from_raw_var_bytes (key.rs:263-300) validates every decoded point with
+// is_on_curve() & is_torsion_free(); here one lane per point: y^2 = x^3 + 4 and [q]P = O
+// (255 doublings + one mixed addition per set bit of q).  flag |= 1 on any failure.
+__global__ void srs_validate_kernel(const G1Affine* __restrict__ pts, uint64_t n, int* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G1Affine a = ld_aff(pts + i);
+  const Fp28 x = Fp28::from_fp(a.x), y = Fp28::from_fp(a.y);
+  const Fp28 one = Fp28::one();
+  const Fp28 four = Fp28::add(Fp28::add(one, one), Fp28::add(one, one));
+  const Fp28 rhs = Fp28::add(Fp28::mul(x.sqr(), x), four);          // < 6p
+  bool ok = Fp28::sub<16>(y.sqr(), rhs).is_zero_mod();
+  if (ok) {
+    G1R acc = G1R::from_affine(x, y);                                // top bit of q (bit 254)
+    for (int b = 253; b >= 0; --b) {
+      acc = acc.dbl();
+      if ((FrP::MOD[b >> 5] >> (b & 31)) & 1) acc = acc.add_affine(x, y);
+    }
+    ok = acc.is_identity();
+  }
+  if (!ok) atomicOr(flag, 1);
+}
+
 __device__ __forceinline__ G1Affine g1_generator() {
   G1Affine g;
   const uint32_t gx[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
@@ -426,6 +449,13 @@ int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->srs_n = n;
+  return PLONK_OK;
+}
+
+int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev) {
+  HIP_TRY(hipMemsetAsync(flag_dev, 0, sizeof(int), c->stream));
+  if (n) hipLaunchKernelGGL(srs_validate_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, n, flag_dev);
+  HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
 

@@ -98,6 +98,7 @@ void ntt_plan(uint32_t L, int r[3], int* npass);
 
 // msm.hip
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
+int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev);
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev);
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);

@@ -1,0 +1,171 @@
+"""Prover::to_bytes blob (reference prover.rs:238-263) -> plonk_prover_blob_check / from_bytes.
+
+The blob is produced by the oracle's restatement of the reference serialisers
+(oracle/serialize.py) from the reference KAT circuit; the product-side decoder (serial.hip, C++,
+no GPU needed for the structural part) must locate every piece and reject what
+Prover::try_from_bytes / ProverKey::from_slice / Evaluations::from_slice /
+CommitKey::from_raw_var_bytes reject, with the same error kinds."""
+import hashlib
+
+import pytest
+
+import plonk_amd
+from oracle import bls12_381 as E
+from oracle.bls12_381 import P, Q
+from oracle.rng import StdRng
+from oracle.serialize import DOMAIN_SIZE, VERIFIER_KEY_SIZE, prover_to_bytes
+
+
+@pytest.fixture(scope="module")
+def blob(kat_setup):
+    _, oprover, _ = kat_setup
+    return prover_to_bytes(oprover)
+
+
+def test_blob_layout_matches_reference_sizes(blob, kat_setup):
+    _, op, _ = kat_setup
+    n = op.size
+    eval_size = 8 * n * 32 + DOMAIN_SIZE
+    pk_len = 16 + sum(8 + 32 * len(op.pk.polys[k]) for k in op.pk.polys) + 17 * eval_size   # widget.rs:322-345
+    assert len(blob) == 48 + len(op.label) + pk_len + (8 + 97 * len(op.ck)) + VERIFIER_KEY_SIZE
+    info = plonk_amd.prover_blob_check(blob)
+    assert info["size"] == n == 8 and info["constraints"] == op.constraints == 5
+    assert info["label"] == b"proof-compatibility"
+    for name in plonk_amd.POLY_ORDER:
+        off, ln = info["polys"][name]
+        assert ln == len(op.pk.polys[name])
+        got = [int.from_bytes(blob[off + 32 * i:off + 32 * i + 32], "little") for i in range(ln)]
+        assert got == op.pk.polys[name]
+    off, npts = info["srs"]
+    assert npts == len(op.ck) == 23
+    assert E.g1_from_raw96(blob[off:off + 96]) == op.ck[0]
+    assert E.g1_from_raw96(blob[off + 97 * 22:off + 97 * 22 + 96]) == op.ck[22]
+    assert blob[info["vk_off"]:info["vk_off"] + 48] == E.g1_compress(op.vk["q_m"])
+
+
+def _sections(blob):
+    label_len, pk_len, ck_len, vk_len = (int.from_bytes(blob[8 * i:8 * i + 8], "big") for i in range(4))
+    pk = 48 + label_len
+    return pk, pk + pk_len, pk + pk_len + ck_len
+
+
+def _patch(blob, off, data):
+    b = bytearray(blob)
+    b[off:off + len(data)] = data
+    return bytes(b)
+
+
+def test_truncated_blobs_are_not_enough_bytes(blob):
+    for cut in (0, 47, 48, len(blob) // 2, len(blob) - 1):
+        with pytest.raises(plonk_amd.NotEnoughBytes):
+            plonk_amd.prover_blob_check(blob[:cut])
+
+
+def test_header_consistency(blob):
+    with pytest.raises(plonk_amd.InvalidData):    # size must be constraints.next_power_of_two()
+        plonk_amd.prover_blob_check(_patch(blob, 32, (16).to_bytes(8, "big")))
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, 40, (9).to_bytes(8, "big")))
+    # constraints 6..8 keep size 8 valid but disagree with verifier_key.n
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, 40, (7).to_bytes(8, "big")))
+    with pytest.raises(plonk_amd.NotEnoughBytes):  # a section length pointing past the end
+        plonk_amd.prover_blob_check(_patch(blob, 8, (1 << 40).to_bytes(8, "big")))
+
+
+def test_prover_key_validation(blob, kat_setup):
+    _, op, _ = kat_setup
+    pk, ck, vk = _sections(blob)
+    info = plonk_amd.prover_blob_check(blob)
+    # prover_key.n != size / 8n not a power of two
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, pk, (16).to_bytes(8, "little")))
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, pk, (7).to_bytes(8, "little")))
+    # non-canonical coefficient (q itself) in q_l
+    off, ln = info["polys"]["q_l"]
+    assert ln > 0
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, off, Q.to_bytes(32, "little")))
+    # announced polynomial length > n
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, pk + 16, (9).to_bytes(8, "little")))
+    # first evaluation block: corrupt the serialized domain (group_gen), then one evaluation
+    q_m_off, q_m_len = info["polys"]["q_m"]
+    ev = q_m_off + 32 * q_m_len
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, ev + 12 + 64, (5).to_bytes(32, "little")))
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, ev + DOMAIN_SIZE + 32 * 3, Q.to_bytes(32, "little")))
+    # a canonical but different evaluation is NOT detected by the reference either (it trusts the
+    # cached evaluations); the loader rebuilds them from the polynomial, so it is harmless here
+    plonk_amd.prover_blob_check(_patch(blob, ev + DOMAIN_SIZE + 32 * 3, (1).to_bytes(32, "little")))
+    # linear evaluations / vanishing evaluations are checked against their closed forms
+    eval_size = 8 * op.size * 32 + DOMAIN_SIZE
+    lin = ck - 2 * eval_size
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, lin + DOMAIN_SIZE + 32 * 5, (1).to_bytes(32, "little")))
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, ck - eval_size + DOMAIN_SIZE, (0).to_bytes(32, "little")))
+
+
+def test_commit_key_validation(blob):
+    pk, ck, vk = _sections(blob)
+    with pytest.raises(plonk_amd.InvalidData):        # len == 0
+        plonk_amd.prover_blob_check(_patch(blob, ck, (0).to_bytes(8, "little")))
+    with pytest.raises(plonk_amd.NotEnoughBytes):     # count disagrees with the section length
+        plonk_amd.prover_blob_check(_patch(blob, ck, (22).to_bytes(8, "little")))
+    with pytest.raises(plonk_amd.PointMalformed):     # y <- y + 1 leaves the curve
+        y = bytearray(blob[ck + 8 + 48:ck + 8 + 96])
+        y[0] ^= 1
+        plonk_amd.prover_blob_check(_patch(blob, ck + 8 + 48, bytes(y)))
+    with pytest.raises(plonk_amd.PointMalformed):     # identity flag set
+        plonk_amd.prover_blob_check(_patch(blob, ck + 8 + 96, b"\x01"))
+    with pytest.raises(plonk_amd.PointMalformed):     # unreduced limbs
+        plonk_amd.prover_blob_check(_patch(blob, ck + 8, b"\xff" * 48))
+
+
+@pytest.mark.gpu
+def test_from_bytes_reproduces_reference_kat_digest(blob, kat_setup):
+    """The whole chain through the serialized form: reference-format blob -> device prover ->
+    blake2b(proof) == literal of prover.rs:1151-1158."""
+    from test_gpu_prover import KAT_DIGEST as DIGEST, wires_of
+    _, op, circuit = kat_setup
+    ctx = plonk_amd.Context(0)
+    gp = plonk_amd.Prover.from_bytes(ctx, blob)
+    assert gp.size == 8
+    assert gp.vk_commitments() == b"".join(E.g1_compress(op.vk[n]) for n in plonk_amd.POLY_ORDER)
+    rng = StdRng.seed_from_u64(0x9235E701)
+    blinders = [rng.random_scalar() for _ in range(14)]
+    proof = gp.prove(wires_of(circuit(), op.size), {}, blinders)
+    assert hashlib.blake2b(proof).digest() == DIGEST
+    gp.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_from_bytes_rejects_point_outside_the_subgroup(blob):
+    """is_torsion_free (key.rs:287): a curve point of E(Fp) \\ G1 in the commit key."""
+    pk, ck, vk = _sections(blob)
+    def times_q(pt):   # [q]pt without reducing the scalar mod q (E.g1_mul does)
+        acc = E.JAC_ID
+        for bit in bin(Q)[2:]:
+            acc = E.jac_double(acc)
+            if bit == "1":
+                acc = E.jac_add(acc, E.to_jac(pt))
+        return E.to_affine(acc)
+
+    assert times_q(E.G1_GEN) is None
+    for x in range(5, 200):
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs and times_q((x, y)) is not None:
+            break
+    else:
+        raise AssertionError("no test point found")
+    bad = _patch(blob, ck + 8 + 97 * 3, E.g1_to_raw96((x, y)))
+    plonk_amd.prover_blob_check(bad)                  # on the curve: the host check passes
+    ctx = plonk_amd.Context(0)
+    with pytest.raises(plonk_amd.PointMalformed):
+        plonk_amd.Prover.from_bytes(ctx, bad)
+    ctx.close()
