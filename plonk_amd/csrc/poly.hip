@@ -301,7 +301,7 @@ __device__ __forceinline__ Fr29 c29(const uint32_t (&v)[9]) {
 __global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= q.n8) return;
-  const uint64_t iw = (i + 8) & (q.n8 - 1);           // extended arrays wrap (quotient_poly.rs:61-67)
+  const uint64_t iw = (i + q.rot) & (q.n8 - 1);       // extended arrays wrap (quotient_poly.rs:61-67)
   const Fr29 a = ld29(q.a + i), b = ld29(q.b + i), c = ld29(q.c + i), d = ld29(q.d + i);
   const Fr29 z = ld29(q.z + i), z_w = ld29(q.z + iw);
   const Fr29 gamma = c29(q.k.gamma);
@@ -386,6 +386,24 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
     t = Fr29::add_csub(t, Fr29::from_fr(u));
   }
   stf(q.out + i, Fr29::mul(t, c29(q.k.vinv[i & 7])).to_fr());
+}
+
+// t holds A = T mod (X^nq - g^nq) (nq coefficients).  T = T_lo + X^nq T_hi with deg T_hi <= 6, so
+// A[k] = T[k] + g^nq T[nq + k] for k < 7 and A[k] = T[k] above.  Given the true low coefficients
+// T[0..7) this restores T in place: t[k] = low[k], t[nq + k] = (A[k] - low[k]) / g^nq, zeros above.
+struct DealiasArgs {
+  Fr low[7];
+  Fr g_inv;
+};
+__global__ void dealias_kernel(Fr* __restrict__ t, uint64_t nq, DealiasArgs a) {
+  const uint32_t k = threadIdx.x;
+  if (k < 7) {
+    const Fr A = ldf(t + k);
+    stf(t + nq + k, (A - a.low[k]) * a.g_inv);
+    stf(t + k, a.low[k]);
+  } else if (k < 16) {
+    stf(t + nq + k, Fr::zero());
+  }
 }
 
 // v[i] *= s  (one-off pre-scaling of key arrays for the kernel above)
@@ -541,6 +559,14 @@ void quotient_const(const Fr& c, int shift, uint32_t out[9]) {
 void quotient_data(const Fr& c, uint32_t out[9]) {   // plain re-slicing (stays in R form)
   const Fr29 r = Fr29::from_fr(c);
   for (int k = 0; k < 9; ++k) out[k] = r.l[k];
+}
+int poly_dealias(Ctx* c, Fr* t, uint64_t nq, const Fr low[7], const Fr& g_inv) {
+  DealiasArgs a;
+  for (int k = 0; k < 7; ++k) a.low[k] = low[k];
+  a.g_inv = g_inv;
+  hipLaunchKernelGGL(dealias_kernel, dim3(1), dim3(64), 0, c->stream, t, nq, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
 }
 int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a) {
   hipLaunchKernelGGL(l1_prepare_kernel, grid1(n8, 256), dim3(256), 0, c->stream, linear, l1, n8);

@@ -39,7 +39,8 @@ struct QuotientConst {
   uint32_t vinv[8][9];     // vanishing_coset_inverses * R''
 };
 struct QuotientArgs {
-  uint64_t n8;
+  uint64_t n8;               // quotient-domain size (8n as the reference, or 4n: prover.hip)
+  uint32_t rot;              // index distance of the X -> omega X rotation = n8 / n
   QuotientConst k;
   Fr inv32;                // 2^-5: undoes the pre-scaling of q_l / q_r for the fixed-base widget
   const Fr *a, *b, *c, *d, *z, *pi;
@@ -88,6 +89,8 @@ int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n);
 int poly_perm_terms(Ctx* c, const PermArgs& a);
 int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag);
 int poly_quotient(Ctx* c, const QuotientArgs& q);
+// de-aliasing of a quotient interpolated on the 4n coset (prover.hip)
+int poly_dealias(Ctx* c, Fr* t, uint64_t nq, const Fr low[7], const Fr& g_inv);
 int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a);
 int poly_scale_array(Ctx* c, Fr* v, uint64_t n, const Fr& s);
 void quotient_const(const Fr& c, int shift, uint32_t out[9]);

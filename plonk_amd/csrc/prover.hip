@@ -7,6 +7,7 @@
 // kernel on arrays that stay in HBM (ntt.hip, msm.hip, poly.hip).  Witness generation
 // (Composer::prove, composer.rs:442) and the RNG stay with the caller: the prover takes
 // the padded wire columns and the 11 blinding scalars in the reference's draw order.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -28,8 +29,12 @@ static const char* VK_LABEL[15] = {"q_m", "q_l", "q_r", "q_o", "q_c", "q_f", "q_
 
 struct Prover {
   Ctx* c = nullptr;
-  uint64_t n = 0, n8 = 0, np = 0, constraints = 0;
+  uint64_t n = 0, n8 = 0, np = 0, constraints = 0;   // n8 = quotient-domain size = qf * n
   uint32_t logn = 0;
+  uint32_t qf = 8, lq = 3;         // quotient domain: 8n (the reference's) or 4n + de-aliasing, see quotient_low()
+  Fr key_low[P_COUNT][7];          // lowest 7 coefficients of the key polynomials (host copy)
+  Fr* low_host = nullptr;          // pinned: lowest 7 coefficients of a, b, c, d, z, pi
+  hipEvent_t ev_pi = nullptr;
   std::string label;
   uint8_t vk[15][48];              // compressed commitments in PolyId order
   Fr* polys = nullptr;             // [P_COUNT][np] coefficient form
@@ -44,7 +49,7 @@ struct Prover {
   Fr* zpoly = nullptr;             // [np]
   Fr* pipoly = nullptr;            // [np]
   Fr* cos = nullptr;               // [6][n8] coset evals of z, a, b, c, d, pi
-  Fr* tbuf = nullptr;              // [n8] quotient evals -> coefficients
+  Fr* tbuf = nullptr;              // [n8 + 16] quotient evals -> coefficients
   Fr* tmp8 = nullptr;              // [n8] NTT scratch (main stream)
   Fr* tmp8b = nullptr;             // [n8] NTT scratch (side stream)
   hipEvent_t ev_ready = nullptr, ev_side = nullptr;
@@ -107,52 +112,142 @@ static void g1_compress97(const uint8_t in[97], uint8_t out[48]) {
   if (greater) out[0] |= 0x20;
 }
 
-static Fr delta_h(const Fr& f) {   // f (f-1)(f-2)(f-3)
-  const Fr one = Fr::one();
-  return f * (f - one) * (f - fr_small(2)) * (f - fr_small(3));
-}
 
-struct Evals {
-  Fr a, b, c, d, a_w, b_w, d_w, q_arith, q_c, q_l, q_r, s1, s2, s3, z;
+// Truncated power series mod X^7 over Fr: the widget formulas below are evaluated in this ring
+// to obtain the 7 lowest coefficients of the quotient numerator (quotient_low()).
+struct Ser {
+  static constexpr int K = 7;
+  Fr c[K];
+  static Ser zero() { Ser r; for (int i = 0; i < K; ++i) r.c[i] = Fr::zero(); return r; }
+  static Ser constant(const Fr& v) { Ser r = zero(); r.c[0] = v; return r; }
+  static Ser load(const Fr* p) { Ser r; for (int i = 0; i < K; ++i) r.c[i] = p[i]; return r; }
+  Ser rotated(const Fr& w) const {   // p(wX)
+    Ser r;
+    Fr pw = Fr::one();
+    for (int i = 0; i < K; ++i) { r.c[i] = c[i] * pw; pw = pw * w; }
+    return r;
+  }
+  Ser sqr() const { return *this * *this; }
+  Ser dbl() const { return *this + *this; }
+  friend Ser operator+(const Ser& a, const Ser& b) { Ser r; for (int i = 0; i < K; ++i) r.c[i] = a.c[i] + b.c[i]; return r; }
+  friend Ser operator-(const Ser& a, const Ser& b) { Ser r; for (int i = 0; i < K; ++i) r.c[i] = a.c[i] - b.c[i]; return r; }
+  friend Ser operator*(const Ser& a, const Ser& b) {
+    Ser r = zero();
+    for (int i = 0; i < K; ++i)
+      for (int j = 0; i + j < K; ++j) r.c[i + j] = r.c[i + j] + a.c[i] * b.c[j];
+    return r;
+  }
+  friend Ser operator*(const Ser& a, const Fr& k) { Ser r; for (int i = 0; i < K; ++i) r.c[i] = a.c[i] * k; return r; }
+  friend Ser operator*(const Fr& k, const Ser& a) { return a * k; }
+  friend Ser operator+(const Ser& a, const Fr& k) { Ser r = a; r.c[0] = r.c[0] + k; return r; }
+  friend Ser operator-(const Ser& a, const Fr& k) { Ser r = a; r.c[0] = r.c[0] - k; return r; }
 };
 
-// widget identities at the evaluation point (the scalar factors of compute_linearization)
-static Fr range_identity(const Fr& ch, const Evals& e) {            // range/proverkey.rs:60-85
+template <class T>
+struct EvalsT {
+  T a, b, c, d, a_w, b_w, d_w, q_arith, q_c, q_l, q_r, s1, s2, s3, z;
+};
+using Evals = EvalsT<Fr>;
+
+template <class T>
+static T delta_h(const T& f) {   // f (f-1)(f-2)(f-3)
+  return f * (f - Fr::one()) * (f - fr_small(2)) * (f - fr_small(3));
+}
+
+// widget identities: at the evaluation point (T = Fr, the scalar factors of compute_linearization)
+// and as power series in X (T = Ser, the same expressions inside compute_quotient_i)
+template <class T>
+static T range_identity(const Fr& ch, const EvalsT<T>& e) {            // range/proverkey.rs:60-85
   const Fr four = fr_small(4);
   const Fr k1 = ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
   return delta_h(e.c - four * e.d) + delta_h(e.b - four * e.c) * k1 + delta_h(e.a - four * e.b) * k2 +
          delta_h(e.d_w - four * e.a) * k3;
 }
-static Fr logic_identity(const Fr& ch, const Evals& e) {            // logic/proverkey.rs:72-144
+template <class T>
+static T logic_identity(const Fr& ch, const EvalsT<T>& e) {            // logic/proverkey.rs:72-144
   const Fr four = fr_small(4);
   const Fr k1 = ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1, k4 = k3 * k1;
-  const Fr a = e.a_w - four * e.a, b = e.b_w - four * e.b, d = e.d_w - four * e.d, w = e.c;
-  const Fr ab = a + b;
-  const Fr F = w * (w * (four * w - fr_small(18) * ab + fr_small(81)) + fr_small(18) * (a.sqr() + b.sqr()) -
-                    fr_small(81) * ab + fr_small(83));
-  const Fr Ee = fr_small(3) * (ab + d) - F.dbl();
-  const Fr Bb = e.q_c * (fr_small(9) * d - fr_small(3) * ab);
+  const T a = e.a_w - four * e.a, b = e.b_w - four * e.b, d = e.d_w - four * e.d, w = e.c;
+  const T ab = a + b;
+  const T F = w * (w * (four * w - fr_small(18) * ab + fr_small(81)) + fr_small(18) * (a.sqr() + b.sqr()) -
+                   fr_small(81) * ab + fr_small(83));
+  const T Ee = fr_small(3) * (ab + d) - F.dbl();
+  const T Bb = e.q_c * (fr_small(9) * d - fr_small(3) * ab);
   return delta_h(a) + delta_h(b) * k1 + delta_h(d) * k2 + (w - a * b) * k3 + (Bb + Ee) * k4;
 }
-static Fr fixed_identity(const Fr& ch, const Evals& e, const Fr& ed) {   // fixed_base/proverkey.rs:103-159
+template <class T>
+static T fixed_identity(const Fr& ch, const EvalsT<T>& e, const Fr& ed) {   // fixed_base/proverkey.rs:103-159
   const Fr one = Fr::one();
   const Fr k1 = ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
-  const Fr bit = e.d_w - e.d - e.d;
-  const Fr bit_cons = bit * (bit - one) * (bit + one);
-  const Fr y_alpha = bit.sqr() * (e.q_r - one) + one;
-  const Fr x_alpha = e.q_l * bit;
-  const Fr xy_cons = (bit * e.q_c - e.c) * k1;
-  const Fr cab = e.c * e.a * e.b * ed;
-  const Fr x_acc = ((e.a_w + e.a_w * cab) - (x_alpha * e.b + y_alpha * e.a)) * k2;
-  const Fr y_acc = ((e.b_w - e.b_w * cab) - (x_alpha * e.a + y_alpha * e.b)) * k3;
+  const T bit = e.d_w - e.d - e.d;
+  const T bit_cons = bit * (bit - one) * (bit + one);
+  const T y_alpha = bit.sqr() * (e.q_r - one) + one;
+  const T x_alpha = e.q_l * bit;
+  const T xy_cons = (bit * e.q_c - e.c) * k1;
+  const T cab = e.c * e.a * e.b * ed;
+  const T x_acc = ((e.a_w + e.a_w * cab) - (x_alpha * e.b + y_alpha * e.a)) * k2;
+  const T y_acc = ((e.b_w - e.b_w * cab) - (x_alpha * e.a + y_alpha * e.b)) * k3;
   return bit_cons + x_acc + y_acc + xy_cons;
 }
-static Fr var_identity(const Fr& ch, const Evals& e, const Fr& ed) {     // curve_addition/proverkey.rs:79-120
+template <class T>
+static T var_identity(const Fr& ch, const EvalsT<T>& e, const Fr& ed) {     // curve_addition/proverkey.rs:79-120
   const Fr k1 = ch.sqr();
-  const Fr x1y2 = e.d_w, y1x2 = e.b * e.c, y1y2 = e.b * e.d, x1x2 = e.a * e.c;
-  const Fr dxy = ed * x1y2 * y1x2;
+  const T x1y2 = e.d_w, y1x2 = e.b * e.c, y1y2 = e.b * e.d, x1x2 = e.a * e.c;
+  const T dxy = ed * x1y2 * y1x2;
   return (e.a * e.d - x1y2) + ((x1y2 + y1x2) - (e.a_w + e.a_w * dxy)) * k1 +
          ((y1y2 + x1x2) - (e.b_w - e.b_w * dxy)) * k1.sqr();
+}
+
+// ---- quotient on the 4n coset ---------------------------------------------------------------
+// The reference interpolates t = num / Z_H from 8n evaluations (quotient_poly.rs:96-137).  t has at
+// most 4n + 7 coefficients, so 4n evaluations determine it up to aliasing: the inverse coset FFT
+// on 4n returns A = t mod (X^4n - g^4n), i.e. A[k] = t[k] + g^4n t[4n + k] for k < 7.  The 7
+// lowest coefficients of t come for free: modulo X^7 (and n >= 8) 1/Z_H = 1/(X^n - 1) = -1, so
+// t = -num mod X^7, and num mod X^7 only needs the 7 lowest coefficients of every polynomial —
+// the numerator formula evaluated in F[X]/(X^7) on the host (~10^4 field multiplications).
+// Result: the same t, bit for bit, from half the coset FFT / point-wise work and half the key
+// memory.  What changes is how an UNSATISFIED circuit is noticed: the reference sees non-zero
+// coefficients above 7n (quotient_poly.rs:132); here the quotient identity is checked at the
+// Fiat-Shamir point z (the remainder of the W_z division, free by-product of ruffini), which
+// fails to flag an unsatisfied circuit with probability <= 5n/q ~ 2^-230.
+// PLONK_QUOTIENT_DOMAIN=8 selects the reference-shaped 8n path (also used when n < 8).
+struct QuotientLowIn {
+  const Fr* low;   // a b c d z pi, 7 coefficients each
+  Fr alpha, beta, gamma, range_ch, logic_ch, fixed_ch, var_ch, edwards_d, omega, n_inv;
+};
+static void quotient_low(const Fr key_low[P_COUNT][7], const bool has[QS_COUNT], const QuotientLowIn& in, Fr out[7]) {
+  const Fr one = Fr::one();
+  const Ser a = Ser::load(in.low), b = Ser::load(in.low + 7), c = Ser::load(in.low + 14), d = Ser::load(in.low + 21);
+  const Ser z = Ser::load(in.low + 28), pi = Ser::load(in.low + 35);
+  Ser K[P_COUNT];
+  for (int k = 0; k < P_COUNT; ++k) K[k] = Ser::load(key_low[k]);
+  // arithmetic (arithmetic/proverkey.rs:44-71)
+  Ser num = pi + (K[P_QM] * a * b + K[P_QL] * a + K[P_QR] * b + K[P_QO] * c + K[P_QF] * d + K[P_QC]) * K[P_QARITH];
+  if (has[QS_RANGE] || has[QS_LOGIC] || has[QS_FIXED] || has[QS_VAR]) {
+    EvalsT<Ser> e;
+    e.a = a; e.b = b; e.c = c; e.d = d;
+    e.a_w = a.rotated(in.omega); e.b_w = b.rotated(in.omega); e.d_w = d.rotated(in.omega);
+    e.q_c = K[P_QC]; e.q_l = K[P_QL]; e.q_r = K[P_QR];
+    if (has[QS_RANGE]) num = num + K[P_QRANGE] * range_identity(in.range_ch, e) * in.range_ch;
+    if (has[QS_LOGIC]) num = num + K[P_QLOGIC] * logic_identity(in.logic_ch, e) * in.logic_ch;
+    if (has[QS_FIXED]) num = num + K[P_QFIXED] * fixed_identity(in.fixed_ch, e, in.edwards_d) * in.fixed_ch;
+    if (has[QS_VAR]) num = num + K[P_QVAR] * var_identity(in.var_ch, e, in.edwards_d) * in.var_ch;
+  }
+  // permutation (permutation/proverkey.rs:40-125)
+  Ser X = Ser::zero();
+  X.c[1] = one;
+  const Fr ks[4] = {one, fr_small(7), fr_small(13), fr_small(17)};
+  const Ser* w[4] = {&a, &b, &c, &d};
+  Ser p1 = Ser::constant(one), p2 = Ser::constant(one);
+  for (int k = 0; k < 4; ++k) {
+    p1 = p1 * (*w[k] + X * (in.beta * ks[k]) + in.gamma);
+    p2 = p2 * (*w[k] + K[P_S1 + k] * in.beta + in.gamma);
+  }
+  num = num + p1 * z * in.alpha - p2 * z.rotated(in.omega) * in.alpha;
+  Ser l1;   // L1(X) = (X^n - 1) / (n (X - 1)) = (1 + X + X^2 + ...) / n  mod X^n
+  for (int k = 0; k < Ser::K; ++k) l1.c[k] = in.n_inv;
+  num = num + (z - one) * l1 * in.alpha.sqr();
+  for (int k = 0; k < 7; ++k) out[k] = num.c[k].neg();
 }
 
 #define PTRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
@@ -236,6 +331,8 @@ static void prover_free(Prover* p) {
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
+  if (p->ev_pi) (void)hipEventDestroy(p->ev_pi);
+  if (p->low_host) (void)hipHostFree(p->low_host);
   if (p->res_host) (void)hipHostFree(p->res_host);
   if (p->gather_host) free(p->gather_host);
   if (p->ev_host) (void)hipHostFree(p->ev_host);
@@ -253,7 +350,13 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   uint32_t L = 0;
   while (n < d->constraints) { n <<= 1; ++L; }   // constraints.next_power_of_two() (compiler.rs:141)
   if (L + 3 >= 28) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
-  p->n = n; p->logn = L; p->n8 = 8 * n; p->np = n + 8;
+  {
+    const char* qd = getenv("PLONK_QUOTIENT_DOMAIN");
+    const bool force8 = qd && qd[0] == '8';
+    p->qf = (n >= 8 && !force8) ? 4 : 8;
+    p->lq = p->qf == 4 ? 2 : 3;
+  }
+  p->n = n; p->logn = L; p->n8 = p->qf * n; p->np = n + 8;
   p->label.assign((const char*)d->label, d->label_len);
   p->world = d->shard_world > 1 ? d->shard_world : 1;
   p->rank = p->world > 1 ? d->shard_rank : 0;
@@ -280,7 +383,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   ALLOC(p->zpoly, np);
   ALLOC(p->pipoly, np);
   ALLOC(p->cos, 6 * n8);
-  ALLOC(p->tbuf, n8);
+  ALLOC(p->tbuf, n8 + 16);
   ALLOC(p->tmp8, n8);
   ALLOC(p->tmp8b, n8);
   ALLOC(p->tparts, 3 * np);
@@ -298,6 +401,8 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
 #undef ALLOC
   HIP_TRY(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_pi, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc((void**)&p->low_host, 42 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * RES_STRIDE, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->ev_host, 16 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->len_host, sizeof(unsigned long long), hipHostMallocDefault));
@@ -315,15 +420,18 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
     p->poly_len[k] = len;
   }
   for (int s = 0; s < QS_COUNT; ++s) p->has[s] = p->poly_len[s] != 0;   // PolyId 0..10 == QS_*
-
-  // ---- cached evaluations: 16 coset FFTs on 8n (compiler.rs:312-377) ...
   for (int k = 0; k < P_COUNT; ++k)
-    PTRY(ntt_device(c, p->polys + k * np, p->evals8 + k * n8, p->tmp8, L + 3, false, true, p->poly_len[k]));
+    for (int i = 0; i < 7; ++i)
+      p->key_low[k][i] = (uint64_t)i < p->poly_len[k] ? ((const Fr*)d->polys[k])[i] : Fr::zero();
+
+  // ---- cached evaluations: 16 coset FFTs on the quotient domain (8n in compiler.rs:312-377) ...
+  for (int k = 0; k < P_COUNT; ++k)
+    PTRY(ntt_device(c, p->polys + k * np, p->evals8 + k * n8, p->tmp8, L + p->lq, false, true, p->poly_len[k]));
   {
     const Fr lin[2] = {Fr::zero(), Fr::one()};
     HIP_TRY(hipMemcpyAsync(p->scratch, lin, sizeof lin, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    PTRY(ntt_device(c, p->scratch, p->evals8 + P_COUNT * n8, p->tmp8, L + 3, false, true, 2));
+    PTRY(ntt_device(c, p->scratch, p->evals8 + P_COUNT * n8, p->tmp8, L + p->lq, false, true, 2));
   }
   // ... 4 sigma FFTs on n (prover.rs:95-100)
   for (int k = 0; k < 4; ++k)
@@ -333,7 +441,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   L1Args l1a;
   {
     Fr point = fr_generator().pow_u64(n);
-    const Fr step = omega_of(L + 3).pow_u64(n);
+    const Fr step = omega_of(L + p->lq).pow_u64(n);   // order qf: the 8 slots repeat with period qf
     for (int i = 0; i < 8; ++i) {
       l1a.vh[i] = point - Fr::one();
       p->vinv[i] = l1a.vh[i].inv();
@@ -398,12 +506,14 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   }
   SideJoin side_join{c};
   uint64_t pi_len = 0;
+  for (int k = 0; k < 4; ++k)   // lowest coefficients of the blinded wire polynomials (quotient_low)
+    HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
     // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments below
     SideScope side(c, p->ev_ready);
     for (int k = 0; k < 4; ++k)
-      PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + 3, false, true, n + 2));
+      PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + p->lq, false, true, n + 2));
     PTRY(poly_fill_zero(c, p->pipoly, np));
     if (pi_count) {
       if (pi_count > p->pi_cap) {
@@ -419,7 +529,9 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8b, L, true, false, n));
       pi_len = n;
     }
-    PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + 3, false, true, pi_len));
+    HIP_TRY(hipMemcpyAsync(p->low_host + 35, p->pipoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(p->ev_pi, c->stream));
+    PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + p->lq, false, true, pi_len));
   }
   {
     const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
@@ -456,9 +568,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
     PTRY(poly_blind(c, p->zpoly, n, ba));
   }
+  HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   {
     SideScope side(c, p->ev_ready);   // z's coset FFT only needs z(X): overlap with its commitment
-    PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + 3, false, true, n + 3));
+    PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
     HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
   }
   PTRY(msm_to(p, p->zpoly, n + 3, 4));
@@ -478,6 +591,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   {
     QuotientArgs q;
     q.n8 = n8;
+    q.rot = p->qf;
     q.z = p->cos; q.a = p->cos + n8; q.b = p->cos + 2 * n8; q.c = p->cos + 3 * n8; q.d = p->cos + 4 * n8; q.pi = p->cos + 5 * n8;
     const Fr* e = p->evals8;
     q.q_m = e + P_QM * n8; q.q_l = e + P_QL * n8; q.q_r = e + P_QR * n8; q.q_o = e + P_QO * n8; q.q_f = e + P_QF * n8;
@@ -499,9 +613,20 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     for (int i = 0; i < 8; ++i) quotient_const(p->vinv[i], 0, q.k.vinv[i]);
     q.out = p->tbuf;
     PTRY(poly_quotient(c, q));
-    PTRY(ntt_device(c, p->tbuf, p->tbuf, p->tmp8, L + 3, true, true, n8));
+    PTRY(ntt_device(c, p->tbuf, p->tbuf, p->tmp8, L + p->lq, true, true, n8));
   }
-  PTRY(poly_trimmed_len(c, p->tbuf, n8, p->len_dev));
+  if (p->qf == 4) {   // de-alias the 4n interpolation with the host-computed low coefficients (see quotient_low)
+    HIP_TRY(hipEventSynchronize(p->ev_pi));   // wire / z lows were complete at the round-1/2 synchronisations
+    QuotientLowIn qi;
+    qi.low = p->low_host;
+    qi.alpha = alpha; qi.beta = beta; qi.gamma = gamma;
+    qi.range_ch = range_ch; qi.logic_ch = logic_ch; qi.fixed_ch = fixed_ch; qi.var_ch = var_ch;
+    qi.edwards_d = edwards_d; qi.omega = omega; qi.n_inv = Fr::from_u64(n).inv();
+    Fr tlow[7];
+    quotient_low(p->key_low, p->has, qi, tlow);
+    PTRY(poly_dealias(c, p->tbuf, n8, tlow, fr_generator().pow_u64(n8).inv()));
+  }
+  PTRY(poly_trimmed_len(c, p->tbuf, p->qf == 4 ? n8 + 8 : n8, p->len_dev));
   HIP_TRY(hipMemcpyAsync(p->len_host, p->len_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -649,6 +774,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   }
   const bool z_zero = z_ch.is_zero();
   PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : z_ch.inv(), p->scratch, p->totals));
+  // ruffini's suffix scan leaves sum_j c_j z^j = (W_z numerator)(z) in scratch[0]: keep it for the
+  // quotient-identity check below
+  HIP_TRY(hipMemcpyAsync(p->evout + 15, p->scratch, sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(p->ev_host + 15, p->evout + 15, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   if (z_zero) return PLONK_ERR_STATE;   // probability 2^-255; (X - 0) division is a shift — not worth a code path
   // W_z's commitment is not absorbed before v_w is drawn (prover.rs:727-730), so both opening
   // witnesses can be committed as one group.
@@ -673,6 +802,17 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(msm_group(p, sc, ms, 2, 9));
   }
   PTRY(fetch_commitments(p, 9, 2, comm + 9));
+  {
+    // num(z) = t(z) Z_H(z)  <=>  r(z) = alpha^2 L1(z) + alpha (a + beta s1 + gamma)(b + beta s2 + gamma)
+    // (c + beta s3 + gamma)(d + gamma) z(omega z)  (the constant the verifier calls pi(z) - r_0, proof.rs:290-310);
+    // the W_z numerator adds sum_i v^i eval_i to r.  A mismatch means the witness does not
+    // satisfy the circuit (Error::CircuitUnsatisfied).
+    Fr expect = alpha.sqr() * l1_z + (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) *
+                                         (ev.c + beta * ev.s3 + gamma) * (ev.d + gamma) * ev.z * alpha;
+    const Fr* evs[11] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.s1, &ev.s2, &ev.s3, &ev.q_arith, &ev.q_c, &ev.q_l, &ev.q_r};
+    for (int k = 0; k < 11; ++k) expect = expect + vp[k + 1] * *evs[k];
+    if (p->ev_host[15] != expect) return PLONK_ERR_UNSAT;
+  }
 
   // ---- Proof::to_bytes (proof.rs:137-162, linearization_poly.rs:98-124)
   memcpy(proof, comm, 11 * 48);

@@ -64,6 +64,17 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True, params=["quotient-4n", "quotient-8n"])
+def quotient_domain(request, monkeypatch):
+    """Every test runs on both quotient domains: the default 4n (+ de-aliasing by the low
+    coefficients, prover.hip quotient_low) and the reference-shaped 8n (quotient_poly.rs:96-137)."""
+    if request.param == "quotient-8n":
+        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
+    else:
+        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    return request.param
+
+
 def test_deterministic_v3_proof_matches_base_digest(ctx, kat_setup):
     """reference prover.rs:1132-1162 through the HIP prover: SRS seed 0x9235e700, proving
     RNG seed 0x9235e701, MinimalCircuit -> blake2b(proof bytes) == literal at :1151-1158."""
@@ -162,6 +173,11 @@ def test_unsatisfied_circuit_is_rejected(ctx):
     gp = gpu_prover(ctx, oprover)
     with pytest.raises((plonk_amd.CircuitUnsatisfied, plonk_amd.PolynomialDegreeTooLarge)):
         gp.prove(cols, {}, list(range(1, 15)))
+    # the prover stays usable and still proves the honest witness bit-exactly afterwards
+    rec = FixedBlinders(StdRng.seed_from_u64(31))
+    honest = build()
+    expected, _ = O.prove(oprover, rec, honest, msm=E.msm_pippenger)
+    assert gp.prove(wires_of(honest, oprover.size), {}, rec.drawn) == expected
     gp.close()
     comp.witnesses[comp.constraints[7].c] = cols[2][7]
     with pytest.raises((ValueError, AssertionError)):
