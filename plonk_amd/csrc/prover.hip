@@ -270,6 +270,100 @@ struct SideJoin {   // never leave side work in flight when prove() returns (buf
   ~SideJoin() { (void)hipStreamSynchronize(c->side_stream); }
 };
 
+// ---- host-side affine normalisation of the MSM results ----------------------------------------
+// The transcript needs the commitments of a group before the next kernels can be queued, so this
+// sits on the critical path with the GPU idle: 64-bit-limb Montgomery arithmetic (the generic
+// 32-bit Field<> costs 130 us per Fp inversion on the host) and ONE shared inversion per group.
+struct Fp64 {
+  uint64_t l[6];
+};
+static uint64_t fp64_ninv() {   // -p^-1 mod 2^64 by Newton iteration
+  uint64_t p0 = (uint64_t)FpP::MOD[0] | ((uint64_t)FpP::MOD[1] << 32), inv = 1;
+  for (int i = 0; i < 6; ++i) inv *= 2 - p0 * inv;
+  return 0 - inv;
+}
+static Fp64 fp64_mod() {
+  Fp64 m;
+  for (int i = 0; i < 6; ++i) m.l[i] = (uint64_t)FpP::MOD[2 * i] | ((uint64_t)FpP::MOD[2 * i + 1] << 32);
+  return m;
+}
+static Fp64 fp64_mul(const Fp64& a, const Fp64& b) {   // CIOS, R = 2^384 (same Montgomery form as Fp)
+  static const uint64_t NINV = fp64_ninv();
+  static const Fp64 M = fp64_mod();
+  typedef unsigned __int128 u128;
+  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 6; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 6; ++j) {
+      c += (u128)a.l[j] * b.l[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[6];
+    t[6] = (uint64_t)c;
+    t[7] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * NINV;
+    c = ((u128)m * M.l[0] + t[0]) >> 64;
+    for (int j = 1; j < 6; ++j) {
+      c += (u128)m * M.l[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[6];
+    t[5] = (uint64_t)c;
+    t[6] = t[7] + (uint64_t)(c >> 64);
+  }
+  Fp64 r, d;
+  uint64_t borrow = 0;
+  for (int j = 0; j < 6; ++j) {
+    r.l[j] = t[j];
+    const u128 s = (u128)t[j] - M.l[j] - borrow;
+    d.l[j] = (uint64_t)s;
+    borrow = (uint64_t)(s >> 64) & 1;
+  }
+  return (t[6] || !borrow) ? d : r;
+}
+static Fp64 fp64_inv(const Fp64& a) {   // a^(p-2)
+  Fp64 e = fp64_mod();
+  e.l[0] -= 2;   // p is odd and p mod 2^64 > 2: no borrow
+  Fp64 acc = a;
+  bool started = false;
+  for (int w = 5; w >= 0; --w)
+    for (int b = 63; b >= 0; --b) {
+      const bool bit = (e.l[w] >> b) & 1;
+      if (!started) { started = bit; continue; }
+      acc = fp64_mul(acc, acc);
+      if (bit) acc = fp64_mul(acc, a);
+    }
+  return acc;
+}
+static Fp64 to64(const Fp& x) { Fp64 r; memcpy(r.l, x.l, 48); return r; }
+static Fp from64(const Fp64& x) { Fp r; memcpy(r.l, x.l, 48); return r; }
+
+// x = X / ZZ, y = Y / ZZZ for a group of XYZZ points -> 97-byte raw affine (x || y || infinity)
+static void batch_xyzz_to_affine97(const G1* pts, int count, uint8_t (*out)[97]) {
+  Fp64 den[16], pre[16];
+  int idx[16], m = 0;
+  for (int i = 0; i < count; ++i) {
+    memset(out[i], 0, 97);
+    if (pts[i].is_identity()) { out[i][96] = 1; continue; }
+    den[m] = fp64_mul(to64(pts[i].ZZ), to64(pts[i].ZZZ));
+    pre[m] = m ? fp64_mul(pre[m - 1], den[m]) : den[m];
+    idx[m++] = i;
+  }
+  if (!m) return;
+  Fp64 inv = fp64_inv(pre[m - 1]);
+  for (int k = m - 1; k >= 0; --k) {
+    const Fp64 dinv = k ? fp64_mul(inv, pre[k - 1]) : inv;
+    if (k) inv = fp64_mul(inv, den[k]);
+    const G1& p = pts[idx[k]];
+    const Fp x = from64(fp64_mul(to64(p.X), fp64_mul(dinv, to64(p.ZZZ))));
+    const Fp y = from64(fp64_mul(to64(p.Y), fp64_mul(dinv, to64(p.ZZ))));
+    memcpy(out[idx[k]], x.l, 48);
+    memcpy(out[idx[k]] + 48, y.l, 48);
+  }
+}
+
 static constexpr int RES_STRIDE = 256;
 
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
@@ -315,11 +409,9 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
       sums[i] = acc;
     }
   }
-  for (int i = 0; i < count; ++i) {
-    uint8_t aff[97];
-    xyzz_to_affine97_host(sums[i], aff);
-    g1_compress97(aff, out48[i]);
-  }
+  uint8_t aff[16][97];
+  batch_xyzz_to_affine97(sums.data(), count, aff);
+  for (int i = 0; i < count; ++i) g1_compress97(aff[i], out48[i]);
   return PLONK_OK;
 }
 
