@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
 // bucket[b] = sum of its slice partials.  Eight lanes cooperate on one bucket (strided
 // partial sums, then a 3-step LDS tree), so a bucket that attracted most of the scalars
 // (equal coefficients => equal digits) costs n/8 serial additions instead of n.
-static constexpr int BS_G = 8;
+static constexpr int BS_G = 4;
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all) {

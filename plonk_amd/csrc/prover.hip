@@ -718,14 +718,21 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     quotient_low(p->key_low, p->has, qi, tlow);
     PTRY(poly_dealias(c, p->tbuf, n8, tlow, fr_generator().pow_u64(n8).inv()));
   }
-  PTRY(poly_trimmed_len(c, p->tbuf, p->qf == 4 ? n8 + 8 : n8, p->len_dev));
-  HIP_TRY(hipMemcpyAsync(p->len_host, p->len_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (*p->flag_host) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);                 // "permutation denominator must be nonzero" (permutation.rs:231-234)
-  const uint64_t tlen = *p->len_host;
-  if (tlen > 7 * n) return PLONK_ERR_UNSAT;                // quotient_poly.rs:132
-  const uint64_t len4 = tlen > 3 * n ? tlen - 3 * n : 0;
+  uint64_t len4;
+  if (p->qf == 4) {
+    // t has 4n + 7 coefficients by construction (the top one is a product of blinding scalars);
+    // explicit zeros at the top would not change the commitment, so no length scan and no
+    // synchronisation here — the permutation flag is checked at the next one
+    len4 = n + 7;
+  } else {
+    PTRY(poly_trimmed_len(c, p->tbuf, n8, p->len_dev));
+    HIP_TRY(hipMemcpyAsync(p->len_host, p->len_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t tlen = *p->len_host;
+    if (tlen > 7 * n) return PLONK_ERR_UNSAT;                // quotient_poly.rs:132
+    len4 = tlen > 3 * n ? tlen - 3 * n : 0;
+  }
   // honest quotient: degree <= 4n + 6 (quotient_poly.rs:106-111) => t_fourth has <= n + 7 coefficients;
   // anything longer cannot be committed with the trimmed key (key.rs:362-370)
   if (len4 > n + 7 || len4 > p->srs_total) return PLONK_ERR_DEGREE;
@@ -743,6 +750,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(msm_group(p, sc, ms, 4, 5));
   }
   PTRY(fetch_commitments(p, 5, 4, comm + 5));
+  if (*p->flag_host) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // "permutation denominator must be nonzero" (permutation.rs:231-234)
   tr.append_commitment("t_low_comm", comm[5]);
   tr.append_commitment("t_mid_comm", comm[6]);
   tr.append_commitment("t_high_comm", comm[7]);
