@@ -334,10 +334,13 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   st_g1r(partial + s, acc);
 }
 
-// bucket[b] = sum of its slice partials.  Eight lanes cooperate on one bucket (strided
-// partial sums, then a 3-step LDS tree), so a bucket that attracted most of the scalars
-// (equal coefficients => equal digits) costs n/8 serial additions instead of n.
-static constexpr int BS_G = 4;
+// bucket[b] = sum of its slice partials.  Uniform scalars give ~16 slices per bucket: two lanes
+// per bucket (strided partial sums + one LDS step) keep the SIMDs busy without idling lanes in a
+// deep tree.  A bucket that attracted a large share of the scalars (equal coefficients => equal
+// digits: up to m/32 slices) is left to msm_bucket_heavy_kernel, where a whole workgroup
+// cooperates on it — m/8192 serial additions instead of m/64.
+static constexpr int BS_G = 2;
+static constexpr uint32_t BS_HEAVY = 128;   // slices; never reached by uniformly distributed digits
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all) {
@@ -349,9 +352,12 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t b = t / BS_G, g = t % BS_G;
   G1R acc = G1R::identity();
+  bool heavy = false;
   if (b < MSM_NB) {
     const uint32_t beg = slice_off[b], end = slice_off[b + 1];
-    for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
+    heavy = end - beg > BS_HEAVY;
+    if (!heavy)
+      for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
   }
   for (int d = BS_G / 2; d >= 1; d >>= 1) {
     sh[threadIdx.x] = acc;
@@ -359,7 +365,42 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
     if ((int)g < d) acc = acc.add(sh[threadIdx.x + d]);
     __syncthreads();
   }
-  if (g == 0 && b < MSM_NB) st_g1r(buckets + b, acc);
+  if (g == 0 && b < MSM_NB && !heavy) st_g1r(buckets + b, acc);
+}
+
+// the heavy buckets: 256 workgroups sweep the bucket range; a workgroup that finds one sums it
+// with 256 lanes (strided) and an 8-step LDS tree.  Costs a few microseconds when there is none.
+__global__ void __launch_bounds__(256) msm_bucket_heavy_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
+                                                               const uint32_t* __restrict__ slice_off_all,
+                                                               G1RSlot* __restrict__ buckets_all) {
+  const int kb = blockIdx.y;
+  const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
+  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
+  G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
+  __shared__ G1R sh[256];
+  __shared__ uint32_t heavy[MSM_NB / 256], nheavy;
+  constexpr uint32_t PER = MSM_NB / 256;   // buckets swept by one workgroup: one lane looks at each
+  if (threadIdx.x == 0) nheavy = 0;
+  __syncthreads();
+  if (threadIdx.x < PER) {
+    const uint32_t b = blockIdx.x * PER + threadIdx.x;
+    if (slice_off[b + 1] - slice_off[b] > BS_HEAVY) heavy[atomicAdd(&nheavy, 1u)] = b;
+  }
+  __syncthreads();
+  const uint32_t cnt = nheavy;
+  for (uint32_t i = 0; i < cnt; ++i) {
+    const uint32_t b = heavy[i];
+    const uint32_t beg = slice_off[b], end = slice_off[b + 1];
+    G1R acc = G1R::identity();
+    for (uint32_t k = beg + threadIdx.x; k < end; k += 256) acc = acc.add(ld_g1r(partial + k));
+    for (int d = 128; d >= 1; d >>= 1) {
+      sh[threadIdx.x] = acc;
+      __syncthreads();
+      if ((int)threadIdx.x < d) acc = acc.add(sh[threadIdx.x + d]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) st_g1r(buckets + b, acc);
+  }
 }
 
 // ---- weighted bucket reduction  W = sum_{b=1..NB} b * B_b  in two shallow kernels -------------
@@ -547,6 +588,8 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   prof_end(c, 1);
   prof_begin(c, 2);
   hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB * BS_G / 128, count), dim3(128), 0, st, bt,
+                     (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
+  hipLaunchKernelGGL(msm_bucket_heavy_kernel, dim3(256, count), dim3(256), 0, st, bt,
                      (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
   hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_ROWS + RC_COLS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);

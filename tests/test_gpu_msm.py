@@ -136,3 +136,21 @@ def test_full_size_closed_form(ctx, logm):
     got = ctx.msm(sc)
     assert got == E.g1_mul(E.G1_GEN, g * acc % Q)
     assert len(plonk_amd.g1_compress(got)) == 48
+
+
+def test_skewed_scalars_take_the_heavy_bucket_path(ctx):
+    """Equal coefficients put every term of a window into ONE bucket (m/32 slices): the
+    cooperative heavy-bucket kernel must give the same group element; mixed with uniform
+    scalars so that both bucket-sum kernels contribute to the same commitment."""
+    r = random.Random(41)
+    n = 20000
+    tau, g = r.randrange(1, Q), r.randrange(1, Q)
+    buf = _gen_srs_dev(ctx, n, tau, g)
+    ctx.srs_load_dev(buf.ptr, n)
+    buf.free()
+    geo = [pow(tau, i, Q) for i in range(n)]
+    for sc in ([0x1234567890ABCDEF1234567890ABCDEF % Q] * n,                       # one bucket per window
+               [r.randrange(Q) if i % 3 else 7 for i in range(n)],                  # heavy + uniform buckets
+               [Q - 1] * 9000):                                                     # all-negative digits
+        k = g * sum(s * t for s, t in zip(sc, geo)) % Q
+        assert ctx.msm(sc) == E.g1_mul(E.G1_GEN, k)
