@@ -406,32 +406,40 @@ __global__ void __launch_bounds__(256) msm_bucket_heavy_kernel(MsmBatch bt, cons
 // ---- weighted bucket reduction  W = sum_{b=1..NB} b * B_b  in two shallow kernels -------------
 // Write b = 128 h + l with h in [0,256), l in [1,128]  (bucket array index b-1 = 128 h + (l-1)):
 //     W = sum_l l * C_l + 128 * sum_h h * R_h ,   C_l = sum_h B_{h,l} ,  R_h = sum_l B_{h,l} .
-// msm_rowcol_kernel forms the 256 row sums and 128 column sums with LDS trees (depth 8);
+// msm_rowcol_kernel forms the 256 row sums and 128 column sums (one wave each);
 // msm_final_kernel turns both weighted sums into sums of suffix sums (Hillis-Steele scans in LDS),
 // doubles the row part 7 times and tree-sums everything: ~24 dependent additions instead of the
 // ~70 of a running-sum-per-chunk scheme — these kernels are pure latency (one wave per SIMD).
 static constexpr uint32_t RC_ROWS = 256, RC_COLS = 128;
 static_assert(RC_ROWS * RC_COLS == MSM_NB, "row/column split must cover the bucket range");
 
+// One wave (64 lanes) per sum, four sums per workgroup: a lane adds 2 (rows) or 4 (columns)
+// buckets serially, then a 6-step LDS tree — depth 7 / 9 additions and ~1.5 waves per SIMD for a
+// group of four commitments, so the whole kernel is one latency round.
+static constexpr uint32_t RC_WG_ROWS = RC_ROWS / 4, RC_WG = (RC_ROWS + RC_COLS) / 4;
 __global__ void __launch_bounds__(256) msm_rowcol_kernel(const G1RSlot* __restrict__ buckets_all,
                                                          G1RSlot* __restrict__ rc_all) {
   __shared__ G1R sh[256];
   const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
   G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * (RC_ROWS + RC_COLS);
-  const uint32_t t = threadIdx.x, blk = blockIdx.x;
-  G1R acc = G1R::identity();
-  if (blk < RC_ROWS) {               // R_h : 128 buckets of row h
-    if (t < RC_COLS) acc = ld_g1r(buckets + blk * RC_COLS + t);
-  } else {                           // C_l : 256 buckets of column l0 = blk - 256
-    acc = ld_g1r(buckets + t * RC_COLS + (blk - RC_ROWS));
+  const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t sum = blockIdx.x * 4 + wave;   // 0..255 rows, 256..383 columns; uniform kind per workgroup
+  G1R acc;
+  if (blockIdx.x < RC_WG_ROWS) {     // R_h : the 128 buckets of row h
+    const G1RSlot* row = buckets + sum * RC_COLS;
+    acc = ld_g1r(row + lane).add(ld_g1r(row + lane + 64));
+  } else {                           // C_l : the 256 buckets of column l0
+    const G1RSlot* col = buckets + (sum - RC_ROWS);
+    acc = ld_g1r(col + (uint64_t)lane * RC_COLS);
+    for (uint32_t k = 1; k < 4; ++k) acc = acc.add(ld_g1r(col + (uint64_t)(lane + 64 * k) * RC_COLS));
   }
-  for (uint32_t d = 128; d >= 1; d >>= 1) {
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
     sh[t] = acc;
     __syncthreads();
-    if (t < d) acc = acc.add(sh[t + d]);
+    if (lane < d) acc = acc.add(sh[t + d]);
     __syncthreads();
   }
-  if (t == 0) st_g1r(rc + blk, acc);
+  if (lane == 0) st_g1r(rc + sum, acc);
 }
 
 // one workgroup of 384 lanes per commitment: lanes 0..255 own R_h, lanes 256..383 own C_l
@@ -459,6 +467,41 @@ __global__ void __launch_bounds__(384) msm_final_kernel(MsmBatch bt, const G1RSl
     sh[t] = acc;
     __syncthreads();
     if (t < d && t + d < RC_ROWS + RC_COLS) acc = acc.add(sh[t + d]);
+    __syncthreads();
+  }
+  if (t == 0) st_g1(out, acc.to_g1());
+}
+
+// Alternative tail used by the device prover (prover.hip): instead of finishing W on one
+// workgroup (~24 dependent additions at ~18 us each), emit the 16 "bit sums"
+//   T_j  = sum of the rows    h whose index has bit j set (j < 8),
+//   T'_j = sum of the columns l whose weight has bit j set (j < 7),  and C_128,
+// each a plain tree sum of <= 128 points (depth 7, all 16 in parallel), and let the host finish
+//   W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j
+// as a 15-term Horner chain: a 64-bit-limb host addition takes ~0.6 us against ~18 us for a
+// dependent addition on one GPU lane.  out[k] receives 16 XYZZ points (rows 0..7, cols 8..14, C_128).
+__global__ void __launch_bounds__(128) msm_bits_kernel(MsmBatch bt, const G1RSlot* __restrict__ rc_all) {
+  __shared__ G1R sh[128];
+  const G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * (RC_ROWS + RC_COLS);
+  G1* __restrict__ out = bt.out[blockIdx.y] + blockIdx.x;
+  const uint32_t u = blockIdx.x, t = threadIdx.x;
+  G1R acc = G1R::identity();
+  if (u < 8) {                       // 128 of the 256 rows
+    const uint32_t h = ((t >> u) << (u + 1)) | (1u << u) | (t & ((1u << u) - 1u));
+    acc = ld_g1r(rc + h);
+  } else if (u < 15) {               // 64 of the column weights 1..127
+    const uint32_t j = u - 8;
+    if (t < 64) {
+      const uint32_t l = ((t >> j) << (j + 1)) | (1u << j) | (t & ((1u << j) - 1u));
+      acc = ld_g1r(rc + RC_ROWS + (l - 1));
+    }
+  } else if (t == 0) {
+    acc = ld_g1r(rc + RC_ROWS + (RC_COLS - 1));   // weight 128
+  }
+  for (uint32_t d = 64; d >= 1; d >>= 1) {
+    sh[t] = acc;
+    __syncthreads();
+    if (t < d) acc = acc.add(sh[t + d]);
     __syncthreads();
   }
   if (t == 0) st_g1(out, acc.to_g1());
@@ -544,7 +587,7 @@ void prof_end(Ctx* c, int slot);
 // `count` (<= MSM_MAX_BATCH) independent MSMs over the same bases, launched together: the
 // latency-bound reduction kernels run once per group instead of once per commitment
 // (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
-int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev) {
+int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums) {
   if (count <= 0) return PLONK_OK;
   if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   uint64_t mmax = 0;
@@ -554,7 +597,8 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   }
   hipStream_t st = c->stream;
   if (mmax == 0) {
-    for (int k = 0; k < count; ++k) hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, st, out_dev[k]);
+    for (int k = 0; k < count; ++k)
+      for (int j = 0; j < (bit_sums ? MSM_BIT_SUMS : 1); ++j) hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, st, out_dev[k] + j);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
   }
@@ -591,9 +635,11 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
                      (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
   hipLaunchKernelGGL(msm_bucket_heavy_kernel, dim3(256, count), dim3(256), 0, st, bt,
                      (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
-  hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_ROWS + RC_COLS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
+  hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);
-  {
+  if (bit_sums) {
+    hipLaunchKernelGGL(msm_bits_kernel, dim3(MSM_BIT_SUMS, count), dim3(128), 0, st, bt, (const G1RSlot*)w.chunk);
+  } else {
     constexpr size_t smem = sizeof(G1R) * (RC_ROWS + RC_COLS);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)msm_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
@@ -605,7 +651,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
 }
 
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {
-  return msm_batch_device(c, &scalars_dev, &m, 1, &out_dev);
+  return msm_batch_device(c, &scalars_dev, &m, 1, &out_dev, false);
 }
 
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev) {

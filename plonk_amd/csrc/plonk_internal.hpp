@@ -100,7 +100,11 @@ void ntt_plan(uint32_t L, int r[3], int* npass);
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
 int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev);
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
-int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev);
+// bit_sums = false: out[k] = the commitment (one XYZZ point).  true: out[k][0..16) = partial sums the
+// host combines with a short doubling chain (msm.hip msm_bits_kernel, prover.hip finish_bit_sums).
+static constexpr int MSM_BIT_SUMS = 16;
+int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
+                     bool bit_sums = false);
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
 // host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);

@@ -337,6 +337,94 @@ static Fp64 fp64_inv(const Fp64& a) {   // a^(p-2)
     }
   return acc;
 }
+static Fp64 fp64_add(const Fp64& a, const Fp64& b) {
+  static const Fp64 M = fp64_mod();
+  typedef unsigned __int128 u128;
+  Fp64 r, d;
+  u128 c = 0;
+  for (int j = 0; j < 6; ++j) { c += (u128)a.l[j] + b.l[j]; r.l[j] = (uint64_t)c; c >>= 64; }
+  uint64_t borrow = 0;
+  for (int j = 0; j < 6; ++j) {
+    const u128 s = (u128)r.l[j] - M.l[j] - borrow;
+    d.l[j] = (uint64_t)s;
+    borrow = (uint64_t)(s >> 64) & 1;
+  }
+  return ((uint64_t)c || !borrow) ? d : r;
+}
+static Fp64 fp64_sub(const Fp64& a, const Fp64& b) {
+  static const Fp64 M = fp64_mod();
+  typedef unsigned __int128 u128;
+  Fp64 r;
+  uint64_t borrow = 0;
+  for (int j = 0; j < 6; ++j) {
+    const u128 s = (u128)a.l[j] - b.l[j] - borrow;
+    r.l[j] = (uint64_t)s;
+    borrow = (uint64_t)(s >> 64) & 1;
+  }
+  if (borrow) {
+    u128 c = 0;
+    for (int j = 0; j < 6; ++j) { c += (u128)r.l[j] + M.l[j]; r.l[j] = (uint64_t)c; c >>= 64; }
+  }
+  return r;
+}
+static bool fp64_is_zero(const Fp64& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
+
+// XYZZ group law on the host (same formulas as curve.cuh: EFD dbl-2008-s-1 / add-2008-s), canonical
+// coordinates; ZZ == 0 marks the identity.
+struct H1 {
+  Fp64 X, Y, ZZ, ZZZ;
+  bool inf() const { return fp64_is_zero(ZZ); }
+};
+static H1 h1_dbl(const H1& p) {
+  if (p.inf()) return p;
+  const Fp64 U = fp64_add(p.Y, p.Y), V = fp64_mul(U, U), W = fp64_mul(U, V), S = fp64_mul(p.X, V);
+  const Fp64 XX = fp64_mul(p.X, p.X), M = fp64_add(fp64_add(XX, XX), XX);
+  H1 r;
+  r.X = fp64_sub(fp64_mul(M, M), fp64_add(S, S));
+  r.Y = fp64_sub(fp64_mul(M, fp64_sub(S, r.X)), fp64_mul(W, p.Y));
+  r.ZZ = fp64_mul(V, p.ZZ);
+  r.ZZZ = fp64_mul(W, p.ZZZ);
+  return r;
+}
+static H1 h1_add(const H1& a, const H1& b) {
+  if (a.inf()) return b;
+  if (b.inf()) return a;
+  const Fp64 U1 = fp64_mul(a.X, b.ZZ), U2 = fp64_mul(b.X, a.ZZ), S1 = fp64_mul(a.Y, b.ZZZ), S2 = fp64_mul(b.Y, a.ZZZ);
+  const Fp64 P = fp64_sub(U2, U1), R = fp64_sub(S2, S1);
+  if (fp64_is_zero(P)) {
+    if (fp64_is_zero(R)) return h1_dbl(a);
+    H1 id;
+    memset(&id, 0, sizeof id);
+    return id;
+  }
+  const Fp64 PP = fp64_mul(P, P), PPP = fp64_mul(P, PP), Q = fp64_mul(U1, PP);
+  H1 r;
+  r.X = fp64_sub(fp64_sub(fp64_mul(R, R), PPP), fp64_add(Q, Q));
+  r.Y = fp64_sub(fp64_mul(R, fp64_sub(Q, r.X)), fp64_mul(S1, PPP));
+  r.ZZ = fp64_mul(fp64_mul(a.ZZ, b.ZZ), PP);
+  r.ZZZ = fp64_mul(fp64_mul(a.ZZZ, b.ZZZ), PPP);
+  return r;
+}
+// W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j  from the 16 bit sums of msm_bits_kernel
+// (rows T_0..T_7, columns T'_0..T'_6, C_128): Horner over U_0..U_14.
+static G1 finish_bit_sums(const G1* bits) {
+  H1 u[16];
+  for (int k = 0; k < 16; ++k) {
+    memcpy(u[k].X.l, bits[k].X.l, 48); memcpy(u[k].Y.l, bits[k].Y.l, 48);
+    memcpy(u[k].ZZ.l, bits[k].ZZ.l, 48); memcpy(u[k].ZZZ.l, bits[k].ZZZ.l, 48);
+  }
+  H1 U[15];
+  for (int j = 0; j < 7; ++j) U[j] = u[8 + j];
+  U[7] = h1_add(u[15], u[0]);
+  for (int j = 1; j < 8; ++j) U[7 + j] = u[j];
+  H1 acc = U[14];
+  for (int j = 13; j >= 0; --j) acc = h1_add(h1_dbl(acc), U[j]);
+  G1 r;
+  if (acc.inf()) return G1::identity();
+  memcpy(r.X.l, acc.X.l, 48); memcpy(r.Y.l, acc.Y.l, 48); memcpy(r.ZZ.l, acc.ZZ.l, 48); memcpy(r.ZZZ.l, acc.ZZZ.l, 48);
+  return r;
+}
+
 static Fp64 to64(const Fp& x) { Fp64 r; memcpy(r.l, x.l, 48); return r; }
 static Fp from64(const Fp64& x) { Fp r; memcpy(r.l, x.l, 48); return r; }
 
@@ -364,7 +452,7 @@ static void batch_xyzz_to_affine97(const G1* pts, int count, uint8_t (*out)[97])
   }
 }
 
-static constexpr int RES_STRIDE = 256;
+static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 16 bit sums per commitment (msm_bits_kernel)
 
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
 // [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
@@ -382,7 +470,7 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
     sc[k] = scalars[k] + (cnt[k] ? lo : 0);
     out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
   }
-  return msm_batch_device(p->c, sc, cnt, count, out);
+  return msm_batch_device(p->c, sc, cnt, count, out, true);
 }
 static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) { return msm_group(p, &scalars, &m, 1, slot); }
 // Bring `count` results to the host, all-gather the per-rank partial sums (EC addition is not
@@ -394,7 +482,7 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
                          hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   std::vector<G1> sums(count);
-  for (int i = 0; i < count; ++i) memcpy(&sums[i], p->res_host + RES_STRIDE * (first + i), sizeof(G1));
+  for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)));
   if (p->world > 1) {
     if (!p->allgather) return PLONK_ERR_STATE;
     const size_t bytes = sizeof(G1) * (size_t)count;
