@@ -94,31 +94,141 @@ __global__ void scatter_pi_kernel(Fr* dense, const uint64_t* idx, const Fr* val,
 }
 
 // ---------------------------------------------------------------------------
-// batch inversion: chunks of 16 per lane, one Fermat inversion per chunk
+// Reduced-radix helpers for the O(n) kernels below.  Values in "twiddle form" x * R'' (fr29.cuh)
+// are closed under Fr29::mul (x R'' * y R'' / R'' = xy R''), so chains of data x data products
+// run there: one product converts in (twiddle_from_fr), one converts out (* R / R'').
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) batch_inverse_kernel(Fr* __restrict__ v, uint64_t n) {
-  constexpr int CH = 16;
-  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * CH;
-  if (base >= n) return;
-  Fr pre[CH];
-  Fr acc = Fr::one();
+struct Tw {
+  uint32_t w[9];
+};
+__device__ __forceinline__ Fr29 tw29(const Tw& t) {
+  Fr29 r;
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    pre[k] = acc;
-    if (base + k < n) {
-      Fr x = ldf(v + base + k);
-      if (!x.is_zero()) acc = acc * x;
+  for (int i = 0; i < 9; ++i) r.l[i] = t.w[i];
+  return r;
+}
+static Tw tw_of(const Fr& x) {   // host: x (R form) -> x * R''
+  const Fr29 t = Fr29::twiddle_from_fr(x);
+  Tw r;
+  for (int i = 0; i < 9; ++i) r.w[i] = t.l[i];
+  return r;
+}
+static Tw tw_plain(const Fr& x) {   // host: re-sliced R-form value (multiplying a twiddle-form value by it converts back)
+  const Fr29 t = Fr29::from_fr(x);
+  Tw r;
+  for (int i = 0; i < 9; ++i) r.w[i] = t.l[i];
+  return r;
+}
+__device__ __forceinline__ Fr29 ld29_(const Fr* p) { return Fr29::from_fr(ldf(p)); }
+// x^e in twiddle form (e > 0 handled by square-and-multiply; e == 0 -> one_t)
+__device__ __forceinline__ Fr29 pow_tw(const Fr29& xt, uint64_t e, const Fr29& one_t) {
+  Fr29 acc = one_t;
+  bool started = false;
+  for (int b = 63; b >= 0; --b) {
+    if (started) acc = Fr29::mul(acc, acc);
+    if ((e >> b) & 1) {
+      acc = started ? Fr29::mul(acc, xt) : xt;
+      started = true;
     }
   }
-  Fr inv = acc.inv();
+  return acc;
+}
+
+// ---------------------------------------------------------------------------
+// batch inversion (util.rs:87-117, zeros skipped): one Fermat inversion per workgroup of
+// 256 x 16 elements.  Every element is converted to twiddle form; per-lane prefix products,
+// Hillis-Steele prefix AND suffix scans of the lane totals in LDS (limb-planar), one lane inverts
+// the workgroup total, and  1/x = (1/total) * (product of everything before) * (product of
+// everything after).  ~7 reduced-radix products per element + 380 per workgroup, against
+// 27 32-bit-limb products per element for one inversion per 16 elements.
+// ---------------------------------------------------------------------------
+static constexpr int BI_T = 256, BI_E = 16;
+struct BatchInvArgs {
+  Tw one_t;      // 1 * R''
+  Tw one_r;      // R (plain): twiddle form -> data form
+  Tw conv;       // R''^2 / R: data form -> twiddle form (Fr29::twiddle_from_fr's constant)
+};
+__device__ __forceinline__ void lds_put(uint32_t (*sh)[BI_T], int t, const Fr29& v) {
 #pragma unroll
-  for (int k = CH - 1; k >= 0; --k) {
-    if (base + k < n) {
-      Fr x = ldf(v + base + k);
+  for (int i = 0; i < 9; ++i) sh[i][t] = v.l[i];
+}
+__device__ __forceinline__ Fr29 lds_get(uint32_t (*sh)[BI_T], int t) {
+  Fr29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = sh[i][t];
+  return r;
+}
+__global__ void __launch_bounds__(BI_T) batch_inverse_kernel(Fr* __restrict__ v, uint64_t n, BatchInvArgs a) {
+  __shared__ uint32_t shp[9][BI_T], shs[9][BI_T], shinv[9];
+  const int t = threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * (BI_T * BI_E) + t;   // element k of this lane: base + k * BI_T (coalesced)
+  const Fr29 one_t = tw29(a.one_t), conv = tw29(a.conv);
+  Fr29 pre[BI_E];
+  Fr29 acc = one_t;
+  uint32_t nz = 0;
+#pragma unroll
+  for (int k = 0; k < BI_E; ++k) {
+    pre[k] = acc;
+    const uint64_t i = base + (uint64_t)k * BI_T;
+    if (i < n) {
+      const Fr x = ldf(v + i);
       if (!x.is_zero()) {
-        stf(v + base + k, inv * pre[k]);
-        inv = inv * x;
+        nz |= 1u << k;
+        acc = Fr29::mul(acc, Fr29::mul(Fr29::from_fr(x), conv).csub_q());
       }
+    }
+  }
+  // exclusive prefix (shp) and suffix (shs) products of the lane totals
+  Fr29 pfx = acc, sfx = acc;
+  for (int d = 1; d < BI_T; d <<= 1) {
+    lds_put(shp, t, pfx);
+    lds_put(shs, t, sfx);
+    __syncthreads();
+    if (t >= d) pfx = Fr29::mul(pfx, lds_get(shp, t - d));
+    if (t + d < BI_T) sfx = Fr29::mul(sfx, lds_get(shs, t + d));
+    __syncthreads();
+  }
+  // pfx = prod_{s <= t} total_s, sfx = prod_{s >= t} total_s
+  lds_put(shp, t, pfx);
+  lds_put(shs, t, sfx);
+  __syncthreads();
+  if (t == 0) {   // 1 / (product of the whole workgroup) = (sfx_0)^(q-2)
+    uint32_t e[8];
+    uint64_t borrow = 2;
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t w = (uint64_t)FrP::MOD[i] - borrow;
+      e[i] = (uint32_t)w;
+      borrow = (w >> 63) & 1;
+    }
+    Fr29 r = sfx;
+    bool started = false;
+    for (int w = 7; w >= 0; --w)
+      for (int b = 31; b >= 0; --b) {
+        const bool bit = (e[w] >> b) & 1;
+        if (!started) { started = bit; continue; }
+        r = Fr29::mul(r, r);
+        if (bit) r = Fr29::mul(r, sfx);
+      }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) shinv[i] = r.l[i];
+  }
+  __syncthreads();
+  Fr29 outer;   // (1/total) * prod_{s < t} total_s * prod_{s > t} total_s
+#pragma unroll
+  for (int i = 0; i < 9; ++i) outer.l[i] = shinv[i];
+  if (t > 0) outer = Fr29::mul(outer, lds_get(shp, t - 1));
+  if (t + 1 < BI_T) outer = Fr29::mul(outer, lds_get(shs, t + 1));
+  // within the lane: 1/x_k = outer * pre_k * (product of the lane's later elements)
+  const Fr29 one_r = tw29(a.one_r);
+  Fr29 suf = outer;
+#pragma unroll
+  for (int k = BI_E - 1; k >= 0; --k) {
+    const uint64_t i = base + (uint64_t)k * BI_T;
+    if ((nz >> k) & 1) {
+      const Fr29 xt = Fr29::mul(Fr29::from_fr(ldf(v + i)), conv).csub_q();
+      const Fr29 inv_t = Fr29::mul(suf, pre[k]);
+      stf(v + i, Fr29::mul(inv_t, one_r).to_fr());
+      suf = Fr29::mul(suf, xt);
     }
   }
 }
@@ -423,69 +533,141 @@ __global__ void l1_finish_kernel(Fr* __restrict__ l1, uint64_t n8, L1Args a) {
 }
 
 // ---------------------------------------------------------------------------
-// polynomial evaluation: partial[b] = sum over the block's coefficients of c_i x^i
+// polynomial evaluation (Polynomial::evaluate, polynomial.rs:120-137): each lane runs Horner over
+// 16 coefficients with the point in twiddle form; lanes, then workgroups, are combined by a
+// tree in which the right half is multiplied by x^(distance): x^(2^k) comes from a squaring
+// chain computed once per workgroup — no per-lane exponentiation.
 // ---------------------------------------------------------------------------
 static constexpr int EV_T = 256;
-static constexpr int EV_E = 16;
-__global__ void __launch_bounds__(EV_T) eval_kernel(EvalArgs a) {
-  __shared__ Fr sh[EV_T];
-  const EvalItem it = a.items[blockIdx.y];
-  const uint64_t base = ((uint64_t)blockIdx.x * EV_T + threadIdx.x) * EV_E;
-  Fr acc = Fr::zero();
+static constexpr int EV_E = 16;     // 2^4 coefficients per lane, 2^12 per workgroup
+struct EvalItemD {
+  const Fr* poly;
+  uint64_t len;
+  Tw xt;
+};
+struct EvalArgsD {
+  EvalItemD items[16];
+  Fr* partial;
+  uint32_t max_blocks;
+};
+// tree over the 256 lane values; lane t's value stands for x^(step * t) * v_t, pw[s] = x^(step * 2^s)
+__device__ __forceinline__ Fr29 eval_tree(Fr29 acc, uint32_t (*sh)[EV_T], const uint32_t (*pw)[9], int t) {
+  for (int s = 0; s < 8; ++s) {
+    const int d = 1 << s;
+    lds_put(sh, t, acc);
+    __syncthreads();
+    if ((t & (2 * d - 1)) == 0) {
+      Fr29 w;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) w.l[i] = pw[s][i];
+      acc = Fr29::add_csub(acc, Fr29::mul(lds_get(sh, t + d), w));
+    }
+    __syncthreads();
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(EV_T) eval_kernel(EvalArgsD a) {
+  __shared__ uint32_t sh[9][EV_T];
+  __shared__ uint32_t pw[8][9];
+  const EvalItemD& it = a.items[blockIdx.y];
+  const int t = threadIdx.x;
+  const Fr29 xt = tw29(it.xt);
+  if (t == 0) {   // x^(2^k), k = 4..11
+    Fr29 p = xt;
+    for (int k = 1; k <= 11; ++k) {
+      p = Fr29::mul(p, p);
+      if (k >= 4)
+        for (int i = 0; i < 9; ++i) pw[k - 4][i] = p.l[i];
+    }
+  }
+  const uint64_t base = ((uint64_t)blockIdx.x * EV_T + t) * EV_E;
+  Fr29 acc = Fr29::zero();
   if (base < it.len) {
 #pragma unroll
     for (int k = EV_E - 1; k >= 0; --k) {
-      acc = acc * it.x;
-      if (base + k < it.len) acc = acc + ldf(it.poly + base + k);
+      acc = Fr29::mul(acc, xt);
+      if (base + k < it.len) acc = Fr29::add_csub(acc, ld29_(it.poly + base + k));
     }
-    acc = acc * it.x.pow_u64(base);
   }
-  sh[threadIdx.x] = acc;
   __syncthreads();
-  for (int d = EV_T / 2; d >= 1; d >>= 1) {
-    if ((int)threadIdx.x < d) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + d];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) stf(a.partial + (uint64_t)blockIdx.y * a.max_blocks + blockIdx.x, sh[0]);
+  acc = eval_tree(acc, sh, pw, t);
+  if (t == 0) stf(a.partial + (uint64_t)blockIdx.y * a.max_blocks + blockIdx.x, acc.to_fr());
 }
-__global__ void __launch_bounds__(EV_T) eval_final_kernel(const Fr* __restrict__ partial, uint32_t max_blocks, uint32_t nblocks,
-                                                          Fr* __restrict__ out) {
-  __shared__ Fr sh[EV_T];
-  Fr acc = Fr::zero();
-  for (uint32_t k = threadIdx.x; k < nblocks; k += EV_T) acc = acc + ldf(partial + (uint64_t)blockIdx.x * max_blocks + k);
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int d = EV_T / 2; d >= 1; d >>= 1) {
-    if ((int)threadIdx.x < d) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + d];
-    __syncthreads();
+__global__ void __launch_bounds__(EV_T) eval_final_kernel(EvalArgsD a, uint32_t nblocks, Fr* __restrict__ out) {
+  __shared__ uint32_t sh[9][EV_T];
+  __shared__ uint32_t pw[9][9];   // x^(2^k), k = 12..19, and x^(2^20)
+  const EvalItemD& it = a.items[blockIdx.x];
+  const int t = threadIdx.x;
+  if (t == 0) {
+    Fr29 p = tw29(it.xt);
+    for (int k = 1; k <= 20; ++k) {
+      p = Fr29::mul(p, p);
+      if (k >= 12)
+        for (int i = 0; i < 9; ++i) pw[k - 12][i] = p.l[i];
+    }
   }
-  if (threadIdx.x == 0) stf(out + blockIdx.x, sh[0]);
+  __syncthreads();
+  Fr29 big;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) big.l[i] = pw[8][i];
+  // lane t: Horner in x^(2^20) over workgroup partials t, t + 256, ...
+  Fr29 acc = Fr29::zero();
+  const Fr* part = a.partial + (uint64_t)blockIdx.x * a.max_blocks;
+  if ((uint32_t)t < nblocks) {
+    const uint32_t last = t + ((nblocks - 1 - t) / EV_T) * EV_T;
+    for (int64_t k = last; k >= t; k -= EV_T) acc = Fr29::add_csub(Fr29::mul(acc, big), ld29_(part + k));
+  }
+  acc = eval_tree(acc, sh, pw, t);
+  if (t == 0) stf(out + blockIdx.x, acc.to_fr());
 }
 
-// out[i] = sum_k s_k * P_k[i]  (+ constant at i == 0)
-__global__ void lincomb_kernel(LinCombArgs a) {
+// out[i] = sum_k s_k * P_k[i]  (+ constant at i == 0); the scalars are in twiddle form
+struct LinTermD {
+  const Fr* p;
+  uint64_t len;
+  Tw st;
+};
+struct LinCombArgsD {
+  LinTermD t[24];
+  int count;
+  uint64_t len;
+  Fr constant;
+  Fr* out;
+};
+__global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgsD a) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.len) return;
-  Fr acc = (i == 0) ? a.constant : Fr::zero();
+  Fr29 acc = (i == 0) ? Fr29::from_fr(a.constant) : Fr29::zero();
   for (int k = 0; k < a.count; ++k)
-    if (i < a.t[k].len) acc = acc + a.t[k].s * ldf(a.t[k].p + i);
-  stf(a.out + i, acc);
+    if (i < a.t[k].len) acc = Fr29::add_csub(acc, Fr29::mul(ld29_(a.t[k].p + i), tw29(a.t[k].st)));
+  stf(a.out + i, acc.to_fr());
 }
 
 // ruffini: q_i = z^-(i+1) * sum_{j > i} c_j z^j
 //   step 1: d_j = c_j z^j ; step 2: suffix sums ; step 3: q_i = S_{i+1} * zinv^(i+1)
-__global__ void mul_powers_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n, Fr x, uint64_t src_off,
-                                  uint64_t exp_off) {
-  constexpr int CH = 8;
-  const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * CH;
-  if (base >= n) return;
-  Fr p = x.pow_u64(base + exp_off);
+// dst[i] = src[i + src_off] * x^(i + exp_off): a wave covers 64 * MP_E consecutive elements, lane l
+// takes l, l + 64, ... (coalesced) and steps its power by x^64.
+static constexpr int MP_E = 16;
+struct MulPowArgs {
+  Tw xt, one_t;
+};
+__global__ void __launch_bounds__(256) mul_powers_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n,
+                                                         MulPowArgs a, uint64_t src_off, uint64_t exp_off) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t wave = g >> 6, lane = g & 63;
+  const uint64_t first = wave * (64 * MP_E) + lane;
+  if (first >= n) return;
+  const Fr29 xt = tw29(a.xt), one_t = tw29(a.one_t);
+  Fr29 p = pow_tw(xt, first + exp_off, one_t);
+  Fr29 step = xt;
 #pragma unroll
-  for (int k = 0; k < CH; ++k) {
-    if (base + k < n) {
-      stf(dst + base + k, ldf(src + base + k + src_off) * p);
-      p = p * x;
-    }
+  for (int k = 0; k < 6; ++k) step = Fr29::mul(step, step);   // x^64
+#pragma unroll 1
+  for (int k = 0; k < MP_E; ++k) {
+    const uint64_t i = first + 64ull * k;
+    if (i >= n) break;
+    stf(dst + i, Fr29::mul(ld29_(src + i + src_off), p).to_fr());
+    p = Fr29::mul(p, step);
   }
 }
 
@@ -523,7 +705,15 @@ int poly_scatter_pi(Ctx* c, Fr* dense, const uint64_t* idx, const Fr* val, uint6
   return PLONK_OK;
 }
 int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n) {
-  hipLaunchKernelGGL(batch_inverse_kernel, grid1((n + 15) / 16, 128), dim3(128), 0, c->stream, v, n);
+  static const BatchInvArgs a = [] {
+    BatchInvArgs r;
+    r.one_t = tw_of(Fr::one());
+    r.one_r = tw_plain(Fr::one());
+    // R''^2 / R = (R''/R) in twiddle form; R''/R = 2^5
+    r.conv = tw_of(Fr::from_u64(32));
+    return r;
+  }();
+  hipLaunchKernelGGL(batch_inverse_kernel, grid1(n, BI_T * BI_E), dim3(BI_T), 0, c->stream, v, n, a);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
@@ -578,25 +768,48 @@ int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a) {
 }
 int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev) {
   const uint32_t nb = (uint32_t)((max_len + (uint64_t)EV_T * EV_E - 1) / ((uint64_t)EV_T * EV_E));
-  if (nb > a.max_blocks) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-  hipLaunchKernelGGL(eval_kernel, dim3(nb, count), dim3(EV_T), 0, c->stream, a);
-  hipLaunchKernelGGL(eval_final_kernel, dim3(count), dim3(EV_T), 0, c->stream, a.partial, a.max_blocks, nb, out_dev);
+  if (nb > a.max_blocks || count > 16) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  EvalArgsD d;
+  for (int k = 0; k < count; ++k) {
+    d.items[k].poly = a.items[k].poly;
+    d.items[k].len = a.items[k].len;
+    d.items[k].xt = tw_of(a.items[k].x);
+  }
+  d.partial = a.partial;
+  d.max_blocks = a.max_blocks;
+  hipLaunchKernelGGL(eval_kernel, dim3(nb, count), dim3(EV_T), 0, c->stream, d);
+  hipLaunchKernelGGL(eval_final_kernel, dim3(count), dim3(EV_T), 0, c->stream, d, nb, out_dev);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
 int poly_lincomb(Ctx* c, const LinCombArgs& a) {
-  hipLaunchKernelGGL(lincomb_kernel, grid1(a.len, 256), dim3(256), 0, c->stream, a);
+  LinCombArgsD d;
+  for (int k = 0; k < a.count; ++k) {
+    d.t[k].p = a.t[k].p;
+    d.t[k].len = a.t[k].len;
+    d.t[k].st = tw_of(a.t[k].s);
+  }
+  d.count = a.count;
+  d.len = a.len;
+  d.constant = a.constant;
+  d.out = a.out;
+  hipLaunchKernelGGL(lincomb_kernel, grid1(a.len, 256), dim3(256), 0, c->stream, d);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
+static void launch_mul_powers(Ctx* c, const Fr* src, Fr* dst, uint64_t n, const Fr& x, uint64_t src_off, uint64_t exp_off) {
+  MulPowArgs a;
+  a.xt = tw_of(x);
+  a.one_t = tw_of(Fr::one());
+  hipLaunchKernelGGL(mul_powers_kernel, grid1((n + MP_E - 1) / MP_E, 256), dim3(256), 0, c->stream, src, dst, n, a, src_off, exp_off);
+}
 // quotient of src[0..len) by (X - z) -> dst[0..len-1); dst[len-1] = 0.  scratch: len Fr + totals.
 int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, const Fr& zinv, Fr* scratch, Fr* totals) {
-  hipLaunchKernelGGL(mul_powers_kernel, grid1((len + 7) / 8, 128), dim3(128), 0, c->stream, src, scratch, len, z, 0, 0);
+  launch_mul_powers(c, src, scratch, len, z, 0, 0);
   int rc = scan_suffix_sum(c, scratch, len, totals);
   if (rc) return rc;
   // q_i = S_{i+1} * zinv^(i+1), i < len - 1
-  hipLaunchKernelGGL(mul_powers_kernel, grid1((len - 1 + 7) / 8, 128), dim3(128), 0, c->stream, scratch, dst, len - 1, zinv,
-                     1, 1);
+  launch_mul_powers(c, scratch, dst, len - 1, zinv, 1, 1);
   rc = poly_fill_zero(c, dst + (len - 1), 1);
   HIP_TRY(hipGetLastError());
   return rc;

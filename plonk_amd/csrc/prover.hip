@@ -32,6 +32,7 @@ struct Prover {
   uint64_t n = 0, n8 = 0, np = 0, constraints = 0;   // n8 = quotient-domain size = qf * n
   uint32_t logn = 0;
   uint32_t qf = 8, lq = 3;         // quotient domain: 8n (the reference's) or 4n + de-aliasing, see quotient_low()
+  Fr n_inv, inv32, edwards_d, gq_inv, omega, omega_inv;   // proof-independent host constants (inversions are ~25 us each)
   Fr key_low[P_COUNT][7];          // lowest 7 coefficients of the key polynomials (host copy)
   Fr* low_host = nullptr;          // pinned: lowest 7 coefficients of a, b, c, d, z, pi
   hipEvent_t ev_pi = nullptr;
@@ -628,6 +629,12 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
       point = point * step;
     }
     l1a.n_inv = Fr::from_u64(n).inv();
+    p->n_inv = l1a.n_inv;
+    p->inv32 = Fr::from_u64(32).inv();
+    p->edwards_d = (fr_small(10240) * fr_small(10241).inv()).neg();   // dusk_jubjub::EDWARDS_D
+    p->gq_inv = fr_generator().pow_u64(p->n8).inv();                    // g^-(quotient domain size), de-aliasing
+    p->omega = omega_of(L);
+    p->omega_inv = p->omega.inv();
   }
   PTRY(poly_l1(c, p->evals8 + P_COUNT * n8, p->evals8 + (P_COUNT + 1) * n8, n8, l1a));
   // pre-scaling for the reduced-radix quotient kernel (poly.hip): q_m * 2^10; q_l q_r q_o q_f q_arith, L1 * 2^5
@@ -764,7 +771,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const Fr logic_ch = tr.challenge_scalar("logic separation challenge");
   const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
   const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
-  const Fr edwards_d = (fr_small(10240) * fr_small(10241).inv()).neg();   // dusk_jubjub::EDWARDS_D
+  const Fr edwards_d = p->edwards_d;
   // quotient (quotient_poly.rs:20-137): the 6 coset FFTs on 8n were issued on the side stream in
   // rounds 1-2; point-wise pass, then coset iFFT
   HIP_TRY(hipStreamWaitEvent(c->main_stream, p->ev_side, 0));
@@ -782,7 +789,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     for (int s = 0; s < QS_COUNT; ++s) q.has[s] = p->has[s];
     q.range_ch = range_ch; q.logic_ch = logic_ch; q.fixed_ch = fixed_ch; q.var_ch = var_ch;
     q.edwards_d = edwards_d;
-    q.inv32 = Fr::from_u64(32).inv();
+    q.inv32 = p->inv32;
     quotient_data(gamma, q.k.gamma);
     quotient_data(Fr::one(), q.k.one);
     const Fr ks[4] = {Fr::one(), fr_small(7), fr_small(13), fr_small(17)};
@@ -801,10 +808,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     qi.low = p->low_host;
     qi.alpha = alpha; qi.beta = beta; qi.gamma = gamma;
     qi.range_ch = range_ch; qi.logic_ch = logic_ch; qi.fixed_ch = fixed_ch; qi.var_ch = var_ch;
-    qi.edwards_d = edwards_d; qi.omega = omega; qi.n_inv = Fr::from_u64(n).inv();
+    qi.edwards_d = edwards_d; qi.omega = omega; qi.n_inv = p->n_inv;
     Fr tlow[7];
     quotient_low(p->key_low, p->has, qi, tlow);
-    PTRY(poly_dealias(c, p->tbuf, n8, tlow, fr_generator().pow_u64(n8).inv()));
+    PTRY(poly_dealias(c, p->tbuf, n8, tlow, p->gq_inv));
   }
   HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   uint64_t len4;
@@ -893,11 +900,21 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const Fr one = Fr::one();
   const Fr z_n = z_ch.pow_u64(n);
   const Fr zh = z_n - one;                                           // evaluate_vanishing_polynomial
-  const Fr n_inv = Fr::from_u64(n).inv();
+  const Fr n_inv = p->n_inv;
+  // 1/z, 1/(z - 1) and 1/(z omega) from one shared inversion
+  const bool z_zero = z_ch.is_zero();
+  Fr inv_z, inv_zm1;
+  {
+    const Fr zm1 = z_ch - one;
+    const Fr a = z_zero ? one : z_ch, b = zm1.is_zero() ? one : zm1;
+    const Fr iab = (a * b).inv();
+    inv_z = iab * b;
+    inv_zm1 = iab * a;
+  }
   // public-input evaluation (compute_barycentric_eval, proof.rs:1041-1088)
   Fr pi_eval = Fr::zero();
   if (pi_count) {
-    const Fr omega_inv = omega.inv();
+    const Fr omega_inv = p->omega_inv;
     Fr acc = Fr::zero();
     for (uint64_t i = 0; i < pi_count; ++i) {
       if (pi_val[i].is_zero()) continue;
@@ -914,7 +931,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
                    (beta * ev.z) * alpha;
   Fr l1_z;                                                            // evaluate_all_lagrange_coefficients(z)[0]
   if (z_n == one) l1_z = (z_ch == one) ? one : Fr::zero();
-  else l1_z = zh * n_inv * (z_ch - one).inv();
+  else l1_z = zh * n_inv * inv_zm1;
   const Fr c_range = range_identity(range_ch, ev) * range_ch;
   const Fr c_logic = logic_identity(logic_ch, ev) * logic_ch;
   const Fr c_fixed = fixed_identity(fixed_ch, ev, edwards_d) * fixed_ch;
@@ -960,8 +977,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     la.out = p->agg;
     PTRY(poly_lincomb(c, la));
   }
-  const bool z_zero = z_ch.is_zero();
-  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : z_ch.inv(), p->scratch, p->totals));
+  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : inv_z, p->scratch, p->totals));
   // ruffini's suffix scan leaves sum_j c_j z^j = (W_z numerator)(z) in scratch[0]: keep it for the
   // quotient-identity check below
   HIP_TRY(hipMemcpyAsync(p->evout + 15, p->scratch, sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
@@ -983,7 +999,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_lincomb(c, la));
   }
   if (zw.is_zero()) return PLONK_ERR_STATE;
-  PTRY(poly_ruffini(c, p->agg, p->wit2, np - 1, zw, zw.inv(), p->scratch, p->totals));
+  PTRY(poly_ruffini(c, p->agg, p->wit2, np - 1, zw, inv_z * p->omega_inv, p->scratch, p->totals));
   {
     const Fr* sc[2] = {p->wit, p->wit2};
     const uint64_t ms[2] = {np - 2, np - 2};
