@@ -18,7 +18,7 @@ import os
 from typing import Iterable, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplonk_hip.so")
+LIB_PATH = os.environ.get("PLONK_HIP_LIB") or os.path.join(_HERE, "lib", "libplonk_hip.so")   # override: A/B builds
 
 # field constants needed to marshal Python ints <-> Montgomery limbs at the ABI
 Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
