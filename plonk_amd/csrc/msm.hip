@@ -338,9 +338,10 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
 // per bucket (strided partial sums + one LDS step) keep the SIMDs busy without idling lanes in a
 // deep tree.  A bucket that attracted a large share of the scalars (equal coefficients => equal
 // digits: up to m/32 slices) is left to msm_bucket_heavy_kernel, where a whole workgroup
-// cooperates on it — m/8192 serial additions instead of m/64.
-static constexpr int BS_G = 2;
+// cooperates on it — m/8192 serial additions instead of m/64.  Lanes per bucket follow the expected
+// slice count: 1 (sparse), 2 (m ~ 2^20: 16 slices), 4, 8 (m >= 2^22).
 static constexpr uint32_t BS_HEAVY = 128;   // slices; never reached by uniformly distributed digits
+template <int BS_G>   // lanes per bucket, chosen from the expected slices per bucket (msm_batch_device)
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all) {
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
   G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
-  __shared__ G1R sh[128];
+  __shared__ G1R sh[BS_G > 1 ? 128 : 1];
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t b = t / BS_G, g = t % BS_G;
   G1R acc = G1R::identity();
@@ -631,8 +632,16 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
                      (const G1AffineR*)c->srs_table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
   prof_begin(c, 2);
-  hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3(MSM_NB * BS_G / 128, count), dim3(128), 0, st, bt,
-                     (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
+  {
+    const uint64_t avg_slices = (MSM_W * mmax) / MSM_KSL / MSM_NB;   // per bucket, uniform digits
+#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128, count), dim3(128), 0, st, bt, \
+                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets)
+    if (avg_slices <= 4) BSUM(1);
+    else if (avg_slices <= 16) BSUM(2);
+    else if (avg_slices <= 32) BSUM(4);
+    else BSUM(8);
+#undef BSUM
+  }
   hipLaunchKernelGGL(msm_bucket_heavy_kernel, dim3(256, count), dim3(256), 0, st, bt,
                      (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
   hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
