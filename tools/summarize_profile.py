@@ -14,13 +14,23 @@ shutil.copy(base + "trace/bench_kernel_stats.csv", dst + "bench_kernel_stats.csv
 out = [f"# {tag} — rocprofv3 summary of `python bench.py` (2^20 gates, 1x MI355X)\n"]
 if note:
     out.append(note + "\n")
-out.append("Commands (on the GPU box, tools/profile_bench.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --steps 3`; "
+out.append("Commands (on the GPU box, tools/profile_bench.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 2`; "
            "PMC in separate passes `rocprofv3 --pmc FETCH_SIZE --kernel-trace ...` / `--pmc WRITE_SIZE ...` / SQ counters (1 proof each).")
-out.append("Counts include the one-off setup (SRS generation + window tables, key commitments, 16 key coset NTTs) and 1 warm-up + 3 timed proofs.\n")
+out.append("Counts include the one-off setup (SRS generation + window tables, key commitments, 16 key coset NTTs) and the warm-up + timed proofs (7 in total).\n")
 out.append("## Kernel time (--kernel-trace --stats)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
 for r in list(csv.DictReader(open(base + "trace/bench_kernel_stats.csv")))[:22]:
     out.append("| `%s` | %s | %.3f | %.1f | %s |" % (r["Name"].split("(")[0][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                 float(r["AverageNs"]) / 1e3, r["Percentage"]))
+try:   # the launches that belong to proofs (bench.py's roofline leg times exactly these): 4 per proof, at the end
+    tr = sorted(csv.DictReader(open(base + "trace/bench_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+    acc_d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if "msm_accumulate" in r["Kernel_Name"]]
+    nproofs = (len(acc_d) - 4) // 4          # setup commits the 15 key polynomials in 4 group launches
+    prove_d = acc_d[-4 * nproofs:]
+    out.append(f"\n`msm_accumulate_kernel` launches inside prove() only ({len(prove_d)} launches = {nproofs} proofs x 4 commitment groups): "
+               f"average **{sum(prove_d) / len(prove_d) / 1e6:.3f} ms** per launch, {4 * sum(prove_d) / len(prove_d) / 1e6:.2f} ms per proof "
+               "(compare `roofline.avg_launch_ms` / `kernel_ms_per_prove.msm_accumulate` printed by bench.py).")
+except Exception as e:  # noqa
+    out.append(f"\n(per-proof accumulate average unavailable: {e})")
 pm = {}
 for C in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(base + f"pmc_{C}/bench_counter_collection.csv")))
