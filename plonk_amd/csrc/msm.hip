@@ -34,10 +34,11 @@ struct MsmBatch {
   uint64_t m[MSM_MAX_BATCH];
   G1* out[MSM_MAX_BATCH];
   int count;
+  uint32_t ksl;   // entries per slice of this launch
   uint64_t cap_m, cap_slices;
 };
 
-static constexpr uint32_t MSM_KSL = 32;   // entries per slice
+static constexpr uint32_t MSM_KSL = 32;   // entries per slice for m >= 2^20 (msm_ksl: shorter slices keep ~2^19 lanes busy for smaller m)
 static constexpr uint32_t MSM_CHUNK = 16; // buckets per chunk in the weighted reduction
 
 __device__ __forceinline__ Fr ld_fr_g(const Fr* p) {
@@ -241,7 +242,7 @@ __global__ void msm_counts_kernel(MsmBatch bt, const uint32_t* __restrict__ keys
 __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts_all,
                                                         uint32_t* __restrict__ offsets_all,
                                                         uint32_t* __restrict__ slice_off_all,
-                                                        uint32_t* __restrict__ cursors_all) {
+                                                        uint32_t* __restrict__ cursors_all, uint32_t ksl) {
   const uint32_t* __restrict__ counts = counts_all + (uint64_t)blockIdx.x * MSM_NB;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
   uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restri
   for (uint32_t k = 0; k < PER; ++k) {
     const uint32_t c = counts[t * PER + k];
     a += c;
-    b += (c + MSM_KSL - 1) / MSM_KSL;
+    b += (c + ksl - 1) / ksl;
   }
   sa[t] = a;
   sb[t] = b;
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restri
     slice_off[idx] = rb;
     cursors[idx] = 0;
     ra += c;
-    rb += (c + MSM_KSL - 1) / MSM_KSL;
+    rb += (c + ksl - 1) / ksl;
   }
   if (t == 1023) {
     offsets[MSM_NB] = ra;
@@ -306,8 +307,8 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   }
   const uint32_t b = lo;
   const uint32_t q = s - slice_off[b];
-  const uint32_t beg = offsets[b] + q * MSM_KSL;
-  uint32_t end = beg + MSM_KSL;
+  const uint32_t beg = offsets[b] + q * bt.ksl;
+  uint32_t end = beg + bt.ksl;
   const uint32_t bend = offsets[b + 1];
   if (end > bend) end = bend;
   G1R acc = G1R::identity();
@@ -551,6 +552,20 @@ int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G
   return PLONK_OK;
 }
 
+// Slice length: 32 entries from m = 2^20 up; halved with m below that (down to 4) so that a smaller
+// MSM still spreads over ~2^19 lanes instead of leaving most SIMDs idle behind 32 serial additions.
+static uint32_t msm_ksl(uint64_t m) {
+  uint32_t r = 4;
+  while (r < MSM_KSL && (uint64_t)r * MSM_NB < m) r *= 2;   // smallest power of two >= m / 2^15, clamped to [4, 32]
+  return r;
+}
+// upper bound of the slice count over every m <= cap (MSM_W * m / msm_ksl(m) <= 16 * 2^15 below 2^20)
+static uint64_t msm_slice_cap(uint64_t cap) {
+  const uint64_t small = (uint64_t)MSM_W * cap / 4 < (uint64_t)MSM_W * MSM_NB ? (uint64_t)MSM_W * cap / 4 : (uint64_t)MSM_W * MSM_NB;
+  const uint64_t large = (uint64_t)MSM_W * cap / MSM_KSL;
+  return (small > large ? small : large) + MSM_NB + 1;
+}
+
 int msm_reserve(Ctx* c, uint64_t m) {
   MsmWork& w = c->msm;
   constexpr int KB = MSM_MAX_BATCH;
@@ -575,7 +590,7 @@ int msm_reserve(Ctx* c, uint64_t m) {
     int rc_t = msm_sort_temp_bytes((size_t)MSM_W * cap, &w.sort_tmp_bytes);
     if (rc_t) return rc_t;
     HIP_TRY(hipMalloc((void**)&w.sort_tmp, w.sort_tmp_bytes));
-    w.cap_slices = (MSM_W * cap) / MSM_KSL + MSM_NB + 1;
+    w.cap_slices = msm_slice_cap(cap);
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
     w.cap_m = cap;
   }
@@ -609,6 +624,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   MsmWork& w = c->msm;
   MsmBatch bt{};
   bt.count = count;
+  bt.ksl = msm_ksl(mmax);
   bt.cap_m = w.cap_m;
   bt.cap_slices = w.cap_slices;
   for (int k = 0; k < count; ++k) { bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k]; }
@@ -623,17 +639,17 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     if (rc) return rc;
   }
   hipLaunchKernelGGL(msm_counts_kernel, dim3(MSM_NB / 256, count), dim3(256), 0, st, bt, w.keys_out, w.counts);
-  hipLaunchKernelGGL(msm_scan_kernel, dim3(count), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors);
+  hipLaunchKernelGGL(msm_scan_kernel, dim3(count), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors, bt.ksl);
   prof_end(c, 2);
   // upper bound on slices known on the host: no device->host sync on the path
-  const uint64_t max_slices = (MSM_W * mmax) / MSM_KSL + MSM_NB + 1;
+  const uint64_t max_slices = (MSM_W * mmax) / bt.ksl + MSM_NB + 1;
   prof_begin(c, 1);
   hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
                      (const G1AffineR*)c->srs_table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
   prof_begin(c, 2);
   {
-    const uint64_t avg_slices = (MSM_W * mmax) / MSM_KSL / MSM_NB;   // per bucket, uniform digits
+    const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
 #define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128, count), dim3(128), 0, st, bt, \
                                    (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets)
     if (avg_slices <= 4) BSUM(1);
