@@ -154,6 +154,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     allgather = None
+    collective_backend = None
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -163,8 +164,26 @@ def main():
         if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":
             local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-        dev = "cuda" if backend == "nccl" else "cpu"
+        # RCCL carries the data-path collective (CUDA tensors); gloo (CPU tensors) carries the agreement
+        # below and is the fallback if RCCL cannot be brought up on this node
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if backend == "nccl" else backend, rank=rank, world_size=world)
+        use_rccl = backend == "nccl"
+        if use_rccl:   # self-test, then a unanimous decision so that no rank is left waiting in the other backend
+            ok = 1
+            try:
+                probe = torch.full((8,), rank + 1, dtype=torch.uint8, device="cuda")
+                got = torch.empty(8 * world, dtype=torch.uint8, device="cuda")
+                dist.all_gather_into_tensor(got, probe)
+                torch.cuda.synchronize()
+                ok = int(got.cpu().tolist() == [r + 1 for r in range(world) for _ in range(8)])
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench rank {rank}] RCCL self-test failed ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_rccl = bool(flag.item())
+        collective_backend = "rccl" if use_rccl else "gloo"
+        dev = "cuda" if use_rccl else "cpu"
 
         def allgather(send: bytes) -> bytes:   # all-gather of the MSM partial sums (RCCL over xGMI)
             t = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
@@ -184,7 +203,10 @@ def main():
         if dist is not None:
             import torch
             torch.cuda.synchronize()
-            dist.barrier()
+            tok = torch.zeros(1, dtype=torch.int32, device=dev)   # barrier on the backend that is known to work
+            dist.all_reduce(tok)
+            if dev == "cuda":
+                torch.cuda.synchronize()
 
     proof = None
     for _ in range(args.warmup):
@@ -244,7 +266,7 @@ def main():
             "config": {"workload": "Prover::prove V3, synthetic dense 2^%d-gate arithmetic circuit, random SRS of "
                                    "n+7 points, wires/ProverKey/SRS tables resident in HBM" % log_n,
                        "gates": n, "ntt": "6 iNTT(n) + 6 cosetNTT(4n) + 1 cosetiNTT(4n) [quotient interpolated on 4n + de-aliasing; reference: 8n]" if os.environ.get("PLONK_QUOTIENT_DOMAIN", "")[:1] != "8" else "6 iNTT(n) + 6 cosetNTT(8n) + 1 cosetiNTT(8n)", "msm": "11 x ~n terms",
-                       "parallelism": "msm-point-range-shard x%d" % world, "setup_s": round(t_setup, 1)},
+                       "parallelism": "msm-point-range-shard x%d" % world, "collective": collective_backend, "setup_s": round(t_setup, 1)},
             "msm_mscalar_per_s": round(11 * m_local / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),
             "proof_blake2b": __import__("hashlib").blake2b(proof).hexdigest()[:32],
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2),
@@ -264,7 +286,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

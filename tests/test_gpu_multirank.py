@@ -32,3 +32,17 @@ def test_sharded_prove_matches_single_gpu(ranks, log_gates):
                  {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
     assert multi["n_gpus"] == ranks and single["n_gpus"] == 1
     assert multi["proof_blake2b"] == single["proof_blake2b"]
+
+
+def test_default_backend_self_test_and_fallback():
+    """`bench.py --gpus 2` as the driver launches it (backend nccl = RCCL).  On this 1-GPU box both
+    ranks share the device, which RCCL refuses: the self-test must notice, every rank must agree
+    on the gloo fallback, and the proof must still equal the single-GPU one.  (On a real multi-GPU
+    node the same code path reports "collective": "rccl".)"""
+    single = _run([sys.executable, "bench.py", "--log-gates", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    multi = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                  "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2",
+                  "--log-gates", "12", "--steps", "1", "--warmup", "0"],
+                 {"PLONK_BENCH_SHARE_GPU": "1"})
+    assert multi["config"]["collective"] in ("rccl", "gloo")
+    assert multi["proof_blake2b"] == single["proof_blake2b"]
