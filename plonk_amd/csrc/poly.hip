@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
   const Fr29 a = ld29(q.a + i), b = ld29(q.b + i), c = ld29(q.c + i), d = ld29(q.d + i);
   const Fr29 z = ld29(q.z + i), z_w = ld29(q.z + iw);
   const Fr29 gamma = c29(q.k.gamma);
-  Fr29 t = ld29(q.pi + i);
+  Fr29 t = q.pi ? ld29(q.pi + i) : Fr29::zero();   // PI(X) = 0 when the circuit has no public inputs
   // arithmetic (arithmetic/proverkey.rs:44-71); selector arrays pre-scaled, see above
   {
     Fr29 s = ld29(q.q_c + i);

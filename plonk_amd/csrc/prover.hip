@@ -718,7 +718,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     }
     HIP_TRY(hipMemcpyAsync(p->low_host + 35, p->pipoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(p->ev_pi, c->stream));
-    PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + p->lq, false, true, pi_len));
+    if (pi_len) PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + p->lq, false, true, pi_len));   // no public inputs: PI(X) = 0, nothing to transform or read
   }
   {
     const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
@@ -779,7 +779,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     QuotientArgs q;
     q.n8 = n8;
     q.rot = p->qf;
-    q.z = p->cos; q.a = p->cos + n8; q.b = p->cos + 2 * n8; q.c = p->cos + 3 * n8; q.d = p->cos + 4 * n8; q.pi = p->cos + 5 * n8;
+    q.z = p->cos; q.a = p->cos + n8; q.b = p->cos + 2 * n8; q.c = p->cos + 3 * n8; q.d = p->cos + 4 * n8; q.pi = pi_len ? p->cos + 5 * n8 : nullptr;
     const Fr* e = p->evals8;
     q.q_m = e + P_QM * n8; q.q_l = e + P_QL * n8; q.q_r = e + P_QR * n8; q.q_o = e + P_QO * n8; q.q_f = e + P_QF * n8;
     q.q_c = e + P_QC * n8; q.q_arith = e + P_QARITH * n8; q.q_range = e + P_QRANGE * n8; q.q_logic = e + P_QLOGIC * n8;
