@@ -34,10 +34,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 def synth_circuit(log_n: int, seed: int = 0x5EED0001):
     """Dense synthetic circuit of n = 2^log_n arithmetic gates (SURVEY §8d `dense` profile):
-        q_M a b + q_L a + q_R b + q_O c + q_F d + q_C = 0,  q_M=q_L=q_F=1, q_R=2, q_O=-1,
-    random a_0, b_i, d_i, q_C_i; the output of gate i is wired to input a of gate i+1, so the
-    copy permutation is non-trivial (sigma_1, sigma_3).  Everything is kept in Montgomery
-    representation (x~ = x R) so rows can be emitted as raw limb bytes without conversion.
+        q_M a b + q_L a + q_R b + q_O c + q_F d + q_C = 0
+    with q_M, q_L, q_R, q_F, q_C uniformly random per gate (full-length selector polynomials, as
+    a compiled circuit has), q_O = -1, q_arith = 1; random a_0, b_i, d_i; the output of gate i is
+    wired to input a of gate i+1, so the copy permutation is non-trivial (sigma_1, sigma_3).
+    Everything is kept in Montgomery representation (x~ = x R) so rows can be emitted as raw limb
+    bytes without conversion.
     Returns (wires_bytes[4], key columns {name: bytes}, trivial polys {name: [ints]})."""
     import random
     n = 1 << log_n
@@ -46,14 +48,18 @@ def synth_circuit(log_n: int, seed: int = 0x5EED0001):
     a = [0] * n
     b = [rb(254) % Q for _ in range(n)]
     d = [rb(254) % Q for _ in range(n)]
+    qm = [rb(254) % Q for _ in range(n)]
+    ql = [rb(254) % Q for _ in range(n)]
+    qr = [rb(254) % Q for _ in range(n)]
+    qf = [rb(254) % Q for _ in range(n)]
     qc = [rb(254) % Q for _ in range(n)]
     c = [0] * n
     cur = rb(254) % Q
     for i in range(n):
         a[i] = cur
         bi = b[i]
-        # c~ = a~ b~ R^-1 + a~ + 2 b~ + d~ + qc~   (q_O = -1)
-        cur = (cur * bi * RINV + cur + 2 * bi + d[i] + qc[i]) % Q
+        # c~ = (qm~ a~ b~ R^-2 + ql~ a~ R^-1 + qr~ b~ R^-1 + qf~ d~ R^-1 + qc~)   (q_O = -1)
+        cur = ((qm[i] * cur % Q * bi % Q * RINV + ql[i] * cur + qr[i] * bi + qf[i] * d[i]) % Q * RINV + qc[i]) % Q
         c[i] = cur
     tb = int.to_bytes
     wires = [b"".join(tb(x, 32, "little") for x in col) for col in (a, b, c, d)]
@@ -66,11 +72,11 @@ def synth_circuit(log_n: int, seed: int = 0x5EED0001):
     # sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_1[0] = w^0 ; sigma_3[i] = w^(i+1) (Left(i+1)), last = itself
     s1 = [T[0]] + [K2 * T[i - 1] % Q for i in range(1, n)]
     s3 = [T[i + 1] for i in range(n - 1)] + [K2 * T[n - 1] % Q]
-    cols = {"q_c": b"".join(tb(x, 32, "little") for x in qc),
-            "s_sigma_1": b"".join(tb(x, 32, "little") for x in s1),
+    cols = {"s_sigma_1": b"".join(tb(x, 32, "little") for x in s1),
             "s_sigma_3": b"".join(tb(x, 32, "little") for x in s3)}
-    trivial = {"q_m": [1], "q_l": [1], "q_r": [2], "q_o": [Q - 1], "q_f": [1], "q_arith": [1],
-               "s_sigma_2": [0, K1], "s_sigma_4": [0, K3]}
+    for name, col in (("q_m", qm), ("q_l", ql), ("q_r", qr), ("q_f", qf), ("q_c", qc)):
+        cols[name] = b"".join(tb(x, 32, "little") for x in col)
+    trivial = {"q_o": [Q - 1], "q_arith": [1], "s_sigma_2": [0, K1], "s_sigma_4": [0, K3]}
     return wires, cols, trivial
 
 
