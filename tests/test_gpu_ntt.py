@@ -128,3 +128,43 @@ def test_full_size_properties(ctx, L):
     k = 4242
     exp = sum(v * pow(GENERATOR, p, Q) * pow(d.group_gen, p * k, Q) for p, v in zip(pos, val)) % Q
     assert plonk_amd.fr_from_bytes_mont(cf[32 * k:32 * k + 32])[0] == exp
+
+
+def test_concurrent_callers_share_one_context(ctx):
+    """The reference calls the transform from rayon workers concurrently (prover.rs:174-177,
+    quotient_poly.rs:150-152) and commits 4-way in parallel (prover.rs:194-197): every C-ABI
+    entry point takes the per-context mutex, so threads may share a context.  8 threads mix
+    NTTs of different sizes/modes with MSMs; every result must equal the sequential one."""
+    import threading
+
+    from oracle import bls12_381 as E
+    r = random.Random(77)
+    pts = [E.g1_mul(E.G1_GEN, r.randrange(1, Q)) for _ in range(48)]
+    ctx.srs_load(pts)
+    jobs = []
+    for k in range(8):
+        L = (9, 11, 12, 13)[k % 4]
+        a = [r.randrange(Q) for _ in range(1 << L)]
+        sc = [r.randrange(Q) for _ in range(48)]
+        jobs.append((L, a, sc, bool(k & 1), bool(k & 2)))
+    expected = [(ctx.ntt(a, L, inverse=inv, coset=cos), ctx.msm(sc)) for (L, a, sc, inv, cos) in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(i):
+        try:
+            L, a, sc, inv, cos = jobs[i]
+            for _ in range(3):
+                got[i] = (ctx.ntt(a, L, inverse=inv, coset=cos), ctx.msm(sc))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert got == expected
+    d = EvaluationDomain(1 << jobs[0][0])
+    assert expected[0][0] == d.fft(jobs[0][1])
