@@ -192,12 +192,12 @@ __global__ void srs_generate_kernel(Fr tau, Fr g_scalar, uint64_t n, G1Affine* _
 // Emits one (key, value) pair per window: key = bucket index |d| - 1 (MSM_NB for a zero
 // digit, which sorts behind every real bucket), value = (w * srs_n + i) | sign << 31.
 // Pair index = w * m + i.
-__global__ void msm_digits_kernel(MsmBatch bt, uint64_t srs_n, uint32_t* __restrict__ keys_all,
+__global__ void msm_digits_kernel(MsmBatch bt, uint64_t srs_n, uint16_t* __restrict__ keys_all,
                                   uint32_t* __restrict__ vals_all) {
   const int kb = blockIdx.y;
   const uint64_t m = bt.m[kb];
   const Fr* __restrict__ scalars = bt.scalars[kb];
-  uint32_t* __restrict__ keys = keys_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint16_t* __restrict__ keys = keys_all + (uint64_t)kb * MSM_W * bt.cap_m;   // 0..MSM_NB fits 16 bits: 25 % less sort traffic
   uint32_t* __restrict__ vals = vals_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
@@ -216,18 +216,18 @@ __global__ void msm_digits_kernel(MsmBatch bt, uint64_t srs_n, uint32_t* __restr
     } else if (v) {
       key = v - 1;
     }
-    keys[(uint64_t)w * m + i] = key;
+    keys[(uint64_t)w * m + i] = (uint16_t)key;
     vals[(uint64_t)w * m + i] = (uint32_t)((uint64_t)w * srs_n + i) | sign;
   }
 }
 
 // counts[b] = number of sorted keys equal to b (binary searches in the sorted key array)
-__global__ void msm_counts_kernel(MsmBatch bt, const uint32_t* __restrict__ keys_sorted_all,
+__global__ void msm_counts_kernel(MsmBatch bt, const uint16_t* __restrict__ keys_sorted_all,
                                   uint32_t* __restrict__ counts_all) {
   const int kb = blockIdx.y;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= MSM_NB) return;
-  const uint32_t* __restrict__ keys = keys_sorted_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint16_t* __restrict__ keys = keys_sorted_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint64_t n = (uint64_t)MSM_W * bt.m[kb];
   uint64_t lo0 = 0, hi0 = n;           // first index with key >= b
   while (lo0 < hi0) { const uint64_t mid = (lo0 + hi0) >> 1; if (keys[mid] < b) lo0 = mid + 1; else hi0 = mid; }
@@ -583,8 +583,8 @@ int msm_reserve(Ctx* c, uint64_t m) {
     if (w.digits) { HIP_TRY(hipFree(w.digits)); HIP_TRY(hipFree(w.entries)); HIP_TRY(hipFree(w.partial)); }
     const uint64_t cap = m;
     if (w.keys_out) { HIP_TRY(hipFree(w.keys_out)); HIP_TRY(hipFree(w.vals_in)); HIP_TRY(hipFree(w.sort_tmp)); }
-    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint32_t) * MSM_W * cap * KB));     // keys, unsorted
-    HIP_TRY(hipMalloc((void**)&w.keys_out, sizeof(uint32_t) * MSM_W * cap * KB));   // keys, sorted
+    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint16_t) * MSM_W * cap * KB));     // keys, unsorted
+    HIP_TRY(hipMalloc((void**)&w.keys_out, sizeof(uint16_t) * MSM_W * cap * KB));   // keys, sorted
     HIP_TRY(hipMalloc((void**)&w.vals_in, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, unsorted
     HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, grouped by bucket
     int rc_t = msm_sort_temp_bytes((size_t)MSM_W * cap, &w.sort_tmp_bytes);

@@ -1,5 +1,5 @@
 // Bucket grouping for the MSM: sort (bucket, table-entry) pairs by bucket with rocPRIM's
-// radix sort (16 key bits -> two 8-bit passes; 0.31 ms for 16.8 M pairs on MI355X versus
+// radix sort (16-bit keys -> two 8-bit passes; 0.31 ms for 16.8 M pairs on MI355X versus
 // 1.5 ms for a global-atomic histogram + scatter).  Kept in its own translation unit: the
 // rocPRIM templates are the slowest thing to compile in the library.
 #include <cstring>
@@ -12,12 +12,13 @@
 namespace plonk {
 
 int msm_sort_temp_bytes(size_t n, size_t* bytes) {
+  uint16_t* knul = nullptr;
   uint32_t* nul = nullptr;
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, *bytes, nul, nul, nul, nul, n, 0, 16));
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, *bytes, knul, knul, nul, nul, n, 0, 16));
   return PLONK_OK;
 }
 
-int msm_sort_pairs(Ctx* c, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+int msm_sort_pairs(Ctx* c, void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
                    const uint32_t* vals_in, uint32_t* vals_out, size_t n) {
   HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 16, c->stream));
   return PLONK_OK;

@@ -48,8 +48,8 @@ static constexpr int MSM_MAX_BATCH = 4;                  // commitments per grou
 
 struct MsmWork {   // per-stream scratch, grown on demand
   uint64_t cap_m = 0;
-  uint32_t* digits = nullptr;      // W * m bucket keys (unsorted)
-  uint32_t* keys_out = nullptr;    // W * m bucket keys (sorted)
+  uint16_t* digits = nullptr;      // W * m bucket keys (unsorted)
+  uint16_t* keys_out = nullptr;    // W * m bucket keys (sorted)
   uint32_t* vals_in = nullptr;     // W * m entries (unsorted)
   uint32_t* entries = nullptr;     // W * m entries grouped by bucket
   void* sort_tmp = nullptr;
@@ -111,7 +111,7 @@ void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);
 int msm_reserve(Ctx* c, uint64_t m);
 // msm_sort.hip
 int msm_sort_temp_bytes(size_t n, size_t* bytes);
-int msm_sort_pairs(Ctx* c, void* temp, size_t temp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+int msm_sort_pairs(Ctx* c, void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
                    const uint32_t* vals_in, uint32_t* vals_out, size_t n);
 
 }  // namespace plonk
