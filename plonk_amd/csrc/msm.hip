@@ -298,9 +298,20 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nslices = slice_off[MSM_NB];
+  // bucket of this slice: largest b with slice_off[b] <= s.  The 128 slices of a workgroup are
+  // consecutive, so their buckets lie in one narrow range: every 64th offset is staged in LDS
+  // (9 of the 15 search steps never leave the CU), the last 6 steps read global memory.
+  __shared__ uint32_t coarse[MSM_NB / 64];
+  for (uint32_t j = threadIdx.x; j < MSM_NB / 64; j += blockDim.x) coarse[j] = slice_off[j * 64];
+  __syncthreads();
   if (s >= nslices) return;
-  // bucket of this slice: largest b with slice_off[b] <= s
-  uint32_t lo = 0, hi = MSM_NB - 1;
+  uint32_t lo = 0, hi = MSM_NB / 64 - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (coarse[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  lo *= 64;
+  hi = lo + 63;
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     if (slice_off[mid] <= s) lo = mid; else hi = mid - 1;
