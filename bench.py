@@ -110,7 +110,7 @@ def cpu_baseline(log_n: int):
     cores, at a bounded size; reported scaled linearly to 2^log_n gates."""
     import numpy as np
     from oracle import cbind
-    sample_log = min(log_n, 17)
+    sample_log = min(log_n, 20)   # 2^20: every transform / MSM size is measured directly (a few seconds on 16 cores), no extrapolation
     n = 1 << sample_log
     threads = cbind.max_threads()
     rng = np.random.default_rng(1)
