@@ -125,8 +125,12 @@ __device__ __forceinline__ void dif_stage(Fr29 (&v)[8], int rlow_thread, const F
   constexpr int bitpos = LO + LB;
 #pragma unroll
   for (int x = 0; x < (1 << LB); ++x) {
+    // The twiddle is w_512^(rlow * 2^(8-bitpos)); in the round on the lowest row bits (LO == 0)
+    // rlow == x is a compile-time constant after unrolling, and x == 0 means w = 1: those
+    // butterflies (3 more per lane and pass besides the last stage) need no multiplication.
+    const bool trivial = bitpos == 0 || (LO == 0 && x == 0);
     Fr29 w;
-    if constexpr (bitpos > 0) {
+    if (!trivial) {
       const int rlow = rlow_thread | (x << LO);          // row & (2^bitpos - 1)
       w = ld_tw(wtab + (rlow << (8 - bitpos)));
     }
@@ -136,7 +140,7 @@ __device__ __forceinline__ void dif_stage(Fr29 (&v)[8], int rlow_thread, const F
       const int e2 = e | (1 << LB);
       const Fr29 a = v[e], b = v[e2];
       v[e] = Fr29::add_csub(a, b);
-      if constexpr (bitpos > 0) v[e2] = Fr29::mul(Fr29::sub_lazy(a, b), w);
+      if (!trivial) v[e2] = Fr29::mul(Fr29::sub_lazy(a, b), w);
       else v[e2] = Fr29::sub_reduce(a, b);
     }
   }
