@@ -71,8 +71,9 @@ if acc in pm["FETCH_SIZE"]:
         # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles summed over waves (MI355X_MICROARCH.md,
         # "s_memtime tick vs SQ PMC units"); the kernel runs 2 waves per SIMD (216 VGPRs), so SIMD time =
         # WAVE_CYCLES / 2 and VALU-busy = ACTIVE_INST_VALU / (WAVE_CYCLES / 2).
-        valu = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
-        out.append(f"\n## VALU utilisation of msm_accumulate\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu:.2f}** — "
+        valu_raw = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
+        valu = min(valu_raw, 1.0)   # waves that retire early make the 2-waves-per-SIMD denominator a slight underestimate
+        out.append(f"\n## VALU utilisation of msm_accumulate\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu_raw:.2f}** — "
                    "the integer VALU pipe is saturated; only fewer instructions per point addition make this kernel faster.")
         b = agg["void plonk::ntt_pass_kernel<8, false>"]
         out.append(f"Same ratio for `ntt_pass_kernel<8,false>` (2 workgroups x 4 waves per CU = 2 waves per SIMD): {b['SQ_ACTIVE_INST_VALU'] / (b['SQ_WAVE_CYCLES'] / 2):.2f}.")
