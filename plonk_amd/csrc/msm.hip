@@ -591,9 +591,14 @@ int msm_reserve(Ctx* c, uint64_t m) {
     HIP_TRY(hipHostMalloc((void**)&w.result_host, 256, hipHostMallocDefault));
   }
   if (m > w.cap_m) {
-    if (w.digits) { HIP_TRY(hipFree(w.digits)); HIP_TRY(hipFree(w.entries)); HIP_TRY(hipFree(w.partial)); }
     const uint64_t cap = m;
-    if (w.keys_out) { HIP_TRY(hipFree(w.keys_out)); HIP_TRY(hipFree(w.vals_in)); HIP_TRY(hipFree(w.sort_tmp)); }
+    // release first (the stream may still be reading the old buffers), and forget the old capacity so
+    // that a failed reallocation cannot leave a stale cap_m pointing at freed memory
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    w.cap_m = 0;
+    for (void** q : {(void**)&w.digits, (void**)&w.entries, (void**)&w.partial, (void**)&w.keys_out, (void**)&w.vals_in, &w.sort_tmp}) {
+      if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
+    }
     HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint16_t) * MSM_W * cap * KB));     // keys, unsorted
     HIP_TRY(hipMalloc((void**)&w.keys_out, sizeof(uint16_t) * MSM_W * cap * KB));   // keys, sorted
     HIP_TRY(hipMalloc((void**)&w.vals_in, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, unsorted
