@@ -1,0 +1,75 @@
+"""Widget identities pinned to the gates' semantics (tests/widget_circuits.py).
+CPU: the oracle proves the honest semantic witnesses and the proof verifies; corrupting one
+quad / one curve coordinate is rejected.  GPU: bit-exact against the oracle on both quotient
+domains (the 4n path evaluates the same widget formulas in F[X]/(X^7) on the host)."""
+import pytest
+
+from oracle import bls12_381 as E
+from oracle import plonk as O
+from oracle.rng import StdRng
+from oracle.verifier import verify_with_tau
+from widget_circuits import jj_add, jj_base, on_curve, semantic_widget_circuit
+
+Q = E.Q
+
+
+def test_jubjub_helpers():
+    b = jj_base()
+    assert on_curve(b) and on_curve(jj_add(b, b)) and jj_add(b, (0, 1)) == b
+    assert jj_add(jj_add(b, b), b) == jj_add(b, jj_add(b, b))
+
+
+def _setup(seed):
+    build = semantic_widget_circuit(seed)
+    comp = build()
+    n = len(comp.constraints)
+    rng = StdRng.seed_from_u64(0xABCD)
+    tau = rng.random_scalar()                       # srs_setup draws tau first (srs.rs:61-100)
+    pp = O.srs_setup(2 * n + 16, StdRng.seed_from_u64(0xABCD), keep=2 * n + 16)
+    prover = O.compile_circuit(pp, b"widgets-semantic", build(), msm=E.msm_pippenger)
+    return build, prover, pp, tau
+
+
+def test_oracle_accepts_semantic_witnesses_and_rejects_corrupted_ones():
+    build, prover, pp, tau = _setup(3)
+    assert all(prover.pk.polys[k] for k in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"))
+    comp = build()
+    proof, pis = O.prove(prover, StdRng.seed_from_u64(5), comp, msm=E.msm_pippenger)
+    assert verify_with_tau(proof, prover.vk, b"widgets-semantic", prover.constraints, dict(comp.public_inputs), tau, pp[0])
+    # corrupt one witness inside each widget family: no longer a polynomial quotient
+    for sel in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        bad = build()
+        row = next(i for i, g in enumerate(bad.constraints) if getattr(g, sel))
+        g = bad.constraints[row + 1]                # the row that carries the "next" values
+        bad.witnesses[g.d] = (bad.witnesses[g.d] + 1) % Q
+        with pytest.raises((ValueError, AssertionError)):
+            O.prove(prover, StdRng.seed_from_u64(5), bad, msm=E.msm_pippenger)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
+@pytest.mark.parametrize("seed", [3, 4])
+def test_hip_prover_bit_exact_on_semantic_widget_circuits(monkeypatch, domain, seed):
+    import plonk_amd
+    from test_gpu_prover import FixedBlinders, wires_of
+    if domain == "quotient-8n":
+        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
+    else:
+        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    build, prover, pp, tau = _setup(seed)
+    rec = FixedBlinders(StdRng.seed_from_u64(100 + seed))
+    comp = build()
+    expected, _ = O.prove(prover, rec, comp, msm=E.msm_pippenger)
+    ctx = plonk_amd.Context(0)
+    ctx.srs_load(prover.ck)
+    gp = plonk_amd.Prover(ctx, prover.constraints, prover.label, prover.pk.polys)
+    got = gp.prove(wires_of(comp, prover.size), dict(comp.public_inputs), rec.drawn)
+    assert got == expected
+    # a corrupted quad inside the logic gadget must be refused by the device prover as well
+    bad = build()
+    row = next(i for i, g in enumerate(bad.constraints) if g.q_logic)
+    bad.witnesses[bad.constraints[row + 1].d] += 1
+    with pytest.raises((plonk_amd.CircuitUnsatisfied, plonk_amd.PolynomialDegreeTooLarge)):
+        gp.prove(wires_of(bad, prover.size), dict(bad.public_inputs), rec.drawn)
+    gp.close()
+    ctx.close()
