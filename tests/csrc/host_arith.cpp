@@ -131,3 +131,11 @@ extern "C" void h_fr29_sub_reduce(const uint32_t* a, const uint32_t* b, uint32_t
   Fr29 A = Fr29::from_fr(x), Bv = Fr29::from_fr(y);
   Fr r = Fr29::sub_reduce(Fr29::add_csub(A, A), Fr29::add_csub(Bv, Bv)).to_fr(); memcpy(o, &r, 32);
 }
+
+// ---- host transcript (transcript.hpp): Merlin's published test protocol ----
+#include "../../plonk_amd/csrc/transcript.hpp"
+extern "C" void h_merlin_simple(uint8_t out[32]) {
+  plonk::Transcript t((const uint8_t*)"test protocol", 13);
+  t.append_message("some label", (const uint8_t*)"some data", 9);
+  t.challenge_bytes("challenge", out, 32);
+}

@@ -248,3 +248,12 @@ def test_fr29_sub_reduce(lib):
         for b in vals[:12] + [rnd.randrange(Q)]:
             lib.h_fr29_sub_reduce(fr_limbs(a), fr_limbs(b), o)
             assert fr_val(o) == (2 * a - 2 * b) % Q
+
+
+def test_host_transcript_matches_merlin_vector(lib):
+    """transcript.hpp (the C++ Merlin / STROBE-128 / Keccak-f[1600] used by prover.hip) on Merlin's
+    published `equivalence_simple` vector."""
+    from test_oracle_kat import MERLIN_SIMPLE
+    out = (ctypes.c_uint8 * 32)()
+    lib.h_merlin_simple(out)
+    assert bytes(out).hex() == MERLIN_SIMPLE

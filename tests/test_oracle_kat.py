@@ -130,3 +130,15 @@ def test_pippenger_matches_naive_random():
     sc[4] = 1
     sc[5] = Q - 1
     assert E.msm_pippenger(pts, sc) == E.msm_naive(pts, sc)
+
+
+MERLIN_SIMPLE = "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+def test_merlin_published_vector():
+    """merlin 3.0 `transcript::tests::equivalence_simple`: Transcript("test protocol"),
+    append_message("some label", "some data"), challenge_bytes("challenge", 32) — an anchor for the
+    STROBE-128 / Keccak restatement that is independent of the PLONK KAT."""
+    t = Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == MERLIN_SIMPLE
