@@ -142,3 +142,14 @@ def test_merlin_published_vector():
     t = Transcript(b"test protocol")
     t.append_message(b"some label", b"some data")
     assert t.challenge_bytes(b"challenge", 32).hex() == MERLIN_SIMPLE
+
+
+def test_g1_generator_compressed_encoding():
+    """The BLS12-381 G1 generator in the zcash 48-byte compressed form (G1Affine::to_bytes,
+    commitment.rs:49-51) — the published constant, for the oracle and for the product-side encoder."""
+    import plonk_amd
+    want = "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+    assert E.g1_compress(E.G1_GEN).hex() == want
+    assert plonk_amd.g1_compress(E.G1_GEN).hex() == want
+    assert E.g1_decompress(bytes.fromhex(want)) == E.G1_GEN
+    assert E.g1_compress(None) == bytes([0xC0]) + bytes(47)
