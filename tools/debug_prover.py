@@ -1,3 +1,8 @@
+"""Developer aid (GPU box): dumps the device prover's internal arrays for the reference KAT and compares
+them with the oracle's intermediate values.  Uses the reference-shaped 8n quotient domain so that the
+arrays line up index by index with the oracle's."""
+import os
+os.environ["PLONK_QUOTIENT_DOMAIN"] = "8"
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import plonk_amd
