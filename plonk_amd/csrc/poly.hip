@@ -408,7 +408,11 @@ __device__ __forceinline__ Fr29 c29(const uint32_t (&v)[9]) {
   return r;
 }
 
-__global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
+// WIDGETS = false: circuits without range / logic / ECC gates (their selector polynomials are
+// identically zero) get a kernel without the 32-bit exact path — fewer registers, more waves in
+// flight for what is the most bandwidth-hungry pass of a proof.
+template <bool WIDGETS>
+__global__ void __launch_bounds__(128, WIDGETS ? 1 : 4) quotient_kernel(QuotientArgs q) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= q.n8) return;
   const uint64_t iw = (i + q.rot) & (q.n8 - 1);       // extended arrays wrap (quotient_poly.rs:61-67)
@@ -444,7 +448,7 @@ __global__ void __launch_bounds__(128) quotient_kernel(QuotientArgs q) {
     const Fr29 l1a = Fr29::mul(ld29(q.l1 + i), c29(q.k.alpha_sq));                      // L1 * alpha^2 (* 2^5)
     t = Fr29::add_csub(t, Fr29::mul(Fr29::sub_lazy(z, c29(q.k.one)), l1a));             // (z - 1) L1 alpha^2
   }
-  const bool need_w = q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR];
+  const bool need_w = WIDGETS && (q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR]);
   if (need_w) {   // exact 32-bit path for the remaining widgets
     const Fr one = Fr::one();
     const Fr a_ = ldf(q.a + i), b_ = ldf(q.b + i), c_ = ldf(q.c + i), d_ = ldf(q.d + i);
@@ -729,7 +733,10 @@ int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag) {
 }
 int poly_quotient(Ctx* c, const QuotientArgs& q) {
   prof_begin(c, 3);
-  hipLaunchKernelGGL(quotient_kernel, grid1(q.n8, 128), dim3(128), 0, c->stream, q);
+  if (q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR])
+    hipLaunchKernelGGL(quotient_kernel<true>, grid1(q.n8, 128), dim3(128), 0, c->stream, q);
+  else
+    hipLaunchKernelGGL(quotient_kernel<false>, grid1(q.n8, 128), dim3(128), 0, c->stream, q);
   prof_end(c, 3);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
