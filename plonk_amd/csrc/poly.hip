@@ -411,8 +411,16 @@ __device__ __forceinline__ Fr29 c29(const uint32_t (&v)[9]) {
 // WIDGETS = false: circuits without range / logic / ECC gates (their selector polynomials are
 // identically zero) get a kernel without the 32-bit exact path — fewer registers, more waves in
 // flight for what is the most bandwidth-hungry pass of a proof.
+// twiddle-form constants of the widget path (poly_quotient fills them per proof)
+struct WidgetConst {
+  Tw conv, one_r, c1, c3, c9, c18, c81, c83, ed;
+  Tw rg[4];   // range_ch * {1, k, k^2, k^3},      k = range_ch^2
+  Tw lg[5];   // logic_ch * {k^3, 1, k, k^2, k^4}, k = logic_ch^2   (order of use in the kernel)
+  Tw fx[4];   // fixed_ch * {1, k, k^2, k^3},      k = fixed_ch^2
+  Tw vr[3];   // var_ch * {1, k, k^2},             k = var_ch^2
+};
 template <bool WIDGETS>
-__global__ void __launch_bounds__(128, WIDGETS ? 1 : 4) quotient_kernel(QuotientArgs q) {
+__global__ void __launch_bounds__(128, WIDGETS ? 2 : 4) quotient_kernel(QuotientArgs q, WidgetConst wc) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= q.n8) return;
   const uint64_t iw = (i + q.rot) & (q.n8 - 1);       // extended arrays wrap (quotient_poly.rs:61-67)
@@ -448,56 +456,77 @@ __global__ void __launch_bounds__(128, WIDGETS ? 1 : 4) quotient_kernel(Quotient
     const Fr29 l1a = Fr29::mul(ld29(q.l1 + i), c29(q.k.alpha_sq));                      // L1 * alpha^2 (* 2^5)
     t = Fr29::add_csub(t, Fr29::mul(Fr29::sub_lazy(z, c29(q.k.one)), l1a));             // (z - 1) L1 alpha^2
   }
-  const bool need_w = WIDGETS && (q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR]);
-  if (need_w) {   // exact 32-bit path for the remaining widgets
-    const Fr one = Fr::one();
-    const Fr a_ = ldf(q.a + i), b_ = ldf(q.b + i), c_ = ldf(q.c + i), d_ = ldf(q.d + i);
-    const Fr a_w = ldf(q.a + iw), b_w = ldf(q.b + iw), d_w = ldf(q.d + iw);
-    const Fr four = one.dbl().dbl();
-    Fr u = Fr::zero();
+  if constexpr (WIDGETS) {
+    // Remaining widgets, also in reduced radix.  Their formulas are long chains of data x data
+    // products, so everything is moved to "twiddle form" x * 2^261 (closed under Fr29::mul) with one
+    // product per operand (the arrays stored pre-scaled by 2^5 — q_l, q_r — already ARE in that form
+    // when re-sliced), the separation challenges and their powers come in as twiddle-form constants,
+    // and the widget sum returns to the data domain with one product at the end.
+    // Range discipline: products take at most ONE lazy operand (sub_lazy: a - b + 4q, first argument);
+    // every other difference is sub_reduce'd to [0, 2q + eps).
+    using F = Fr29;
+    const F conv = tw29(wc.conv), c1 = tw29(wc.c1);
+    auto T = [&](const Fr* p) { return F::mul(ld29(p), conv).csub_q(); };
+    auto add = [](const F& x, const F& y) { return F::add_csub(x, y); };
+    auto subn = [](const F& x, const F& y) { return F::sub_reduce(x, y); };
+    auto subl = [](const F& x, const F& y) { return F::sub_lazy(x, y); };
+    auto mul = [](const F& x, const F& y) { return F::mul(x, y); };
+    auto x4 = [&](const F& x) { const F d2 = add(x, x); return add(d2, d2); };
+    auto delta = [&](const F& f) {   // f (f-1)(f-2)(f-3)
+      const F c2 = add(c1, c1);
+      F r = mul(subl(f, c1), f);
+      r = mul(subl(f, c2), r);
+      return mul(subl(f, add(c2, c1)), r);
+    };
+    const F a_ = T(q.a + i), b_ = T(q.b + i), c_ = T(q.c + i), d_ = T(q.d + i);
+    const F a_w = T(q.a + iw), b_w = T(q.b + iw), d_w = T(q.d + iw);
+    F u = F::zero();
     if (q.has[QS_RANGE]) {   // range/proverkey.rs:32-58
-      const Fr k1 = q.range_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
-      Fr s = delta4(c_ - four * d_, one) + delta4(b_ - four * c_, one) * k1 + delta4(a_ - four * b_, one) * k2 +
-             delta4(d_w - four * a_, one) * k3;
-      u = u + s * ldf(q.q_range + i) * q.range_ch;
+      F s = mul(delta(subn(c_, x4(d_))), tw29(wc.rg[0]));
+      s = add(s, mul(delta(subn(b_, x4(c_))), tw29(wc.rg[1])));
+      s = add(s, mul(delta(subn(a_, x4(b_))), tw29(wc.rg[2])));
+      s = add(s, mul(delta(subn(d_w, x4(a_))), tw29(wc.rg[3])));
+      u = add(u, mul(s, T(q.q_range + i)));
     }
     if (q.has[QS_LOGIC]) {   // logic/proverkey.rs:34-70,108-144
-      const Fr k1 = q.logic_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1, k4 = k3 * k1;
-      const Fr la = a_w - four * a_, lb = b_w - four * b_, ld = d_w - four * d_, w = c_;
-      const Fr q_c = ldf(q.q_c + i);
-      const Fr n3 = small(3, one), n9 = small(9, one), n18 = small(18, one), n81 = small(81, one), n83 = small(83, one);
-      const Fr ab = la + lb;
-      const Fr F = w * (w * (four * w - n18 * ab + n81) + n18 * (la.sqr() + lb.sqr()) - n81 * ab + n83);
-      const Fr Ee = n3 * (ab + ld) - F.dbl();
-      const Fr Bb = q_c * (n9 * ld - n3 * ab);
-      Fr s = (w - la * lb) * k3 + delta4(la, one) + delta4(lb, one) * k1 + delta4(ld, one) * k2 + (Bb + Ee) * k4;
-      u = u + ldf(q.q_logic + i) * s * q.logic_ch;
+      const F c3 = tw29(wc.c3), c18 = tw29(wc.c18), c81 = tw29(wc.c81);
+      const F la = subn(a_w, x4(a_)), lb = subn(b_w, x4(b_)), ld = subn(d_w, x4(d_)), w = c_;
+      const F ab = add(la, lb);
+      const F in1 = subn(add(x4(w), c81), mul(ab, c18));                           // 4w - 18(a+b) + 81
+      const F in2 = subn(add(add(mul(in1, w), mul(add(mul(la, la), mul(lb, lb)), c18)), tw29(wc.c83)), mul(ab, c81));
+      const F Fv = mul(in2, w);
+      const F Ee = subn(mul(add(ab, ld), c3), add(Fv, Fv));
+      const F Bb = mul(subn(mul(ld, tw29(wc.c9)), mul(ab, c3)), T(q.q_c + i));
+      F s = mul(subl(w, mul(la, lb)), tw29(wc.lg[0]));
+      s = add(s, mul(delta(la), tw29(wc.lg[1])));
+      s = add(s, mul(delta(lb), tw29(wc.lg[2])));
+      s = add(s, mul(delta(ld), tw29(wc.lg[3])));
+      s = add(s, mul(add(Bb, Ee), tw29(wc.lg[4])));
+      u = add(u, mul(s, T(q.q_logic + i)));
     }
     if (q.has[QS_FIXED]) {   // ecc/scalar_mul/fixed_base/proverkey.rs:39-101
-      const Fr k1 = q.fixed_ch.sqr(), k2 = k1.sqr(), k3 = k2 * k1;
-      // q_l / q_r arrays are stored * 2^5 for the fast path: undo
-      const Fr x_beta = ldf(q.q_l + i) * q.inv32, y_beta = ldf(q.q_r + i) * q.inv32, q_c = ldf(q.q_c + i);
-      const Fr bit = d_w - d_ - d_;
-      const Fr bit_cons = bit * (bit - one) * (bit + one);
-      const Fr y_alpha = bit.sqr() * (y_beta - one) + one;
-      const Fr x_alpha = bit * x_beta;
-      const Fr xy_cons = (bit * q_c - c_) * k1;
-      const Fr cab_d = c_ * a_ * b_ * q.edwards_d;
-      const Fr x_acc = ((a_w + a_w * cab_d) - (a_ * y_alpha + b_ * x_alpha)) * k2;
-      const Fr y_acc = ((b_w - b_w * cab_d) - (b_ * y_alpha + a_ * x_alpha)) * k3;
-      u = u + (bit_cons + x_acc + y_acc + xy_cons) * ldf(q.q_fixed + i) * q.fixed_ch;
+      const F x_beta = ld29(q.q_l + i), y_beta = ld29(q.q_r + i), q_c = T(q.q_c + i);   // q_l, q_r: stored * 2^5
+      const F bit = subn(d_w, add(d_, d_));
+      const F bit_cons = mul(mul(subl(bit, c1), bit), add(bit, c1));
+      const F y_alpha = add(mul(subl(y_beta, c1), mul(bit, bit)), c1);
+      const F x_alpha = mul(bit, x_beta);
+      const F xy_cons = mul(subl(mul(bit, q_c), c_), tw29(wc.fx[1]));
+      const F cab = mul(mul(mul(c_, a_), b_), tw29(wc.ed));
+      const F x_acc = mul(subl(add(a_w, mul(a_w, cab)), add(mul(a_, y_alpha), mul(b_, x_alpha))), tw29(wc.fx[2]));
+      const F y_acc = mul(subl(subn(b_w, mul(b_w, cab)), add(mul(b_, y_alpha), mul(a_, x_alpha))), tw29(wc.fx[3]));
+      const F s = add(add(mul(bit_cons, tw29(wc.fx[0])), x_acc), add(y_acc, xy_cons));
+      u = add(u, mul(s, T(q.q_fixed + i)));
     }
     if (q.has[QS_VAR]) {     // ecc/curve_addition/proverkey.rs:33-77
-      const Fr k1 = q.var_ch.sqr();
-      const Fr x1y2 = d_w;
-      const Fr y1x2 = b_ * c_, y1y2 = b_ * d_, x1x2 = a_ * c_;
-      const Fr xy_cons = a_ * d_ - x1y2;
-      const Fr dxy = q.edwards_d * x1y2 * y1x2;
-      const Fr x3c = ((x1y2 + y1x2) - (a_w + a_w * dxy)) * k1;
-      const Fr y3c = ((y1y2 + x1x2) - (b_w - b_w * dxy)) * k1.sqr();
-      u = u + (xy_cons + x3c + y3c) * ldf(q.q_var + i) * q.var_ch;
+      const F x1y2 = d_w;
+      const F y1x2 = mul(b_, c_), y1y2 = mul(b_, d_), x1x2 = mul(a_, c_);
+      const F xy_cons = mul(subl(mul(a_, d_), x1y2), tw29(wc.vr[0]));
+      const F dxy = mul(mul(x1y2, y1x2), tw29(wc.ed));
+      const F x3c = mul(subl(add(x1y2, y1x2), add(a_w, mul(a_w, dxy))), tw29(wc.vr[1]));
+      const F y3c = mul(subl(add(y1y2, x1x2), subn(b_w, mul(b_w, dxy))), tw29(wc.vr[2]));
+      u = add(u, mul(add(add(xy_cons, x3c), y3c), T(q.q_var + i)));
     }
-    t = Fr29::add_csub(t, Fr29::from_fr(u));
+    t = Fr29::add_csub(t, Fr29::mul(u, tw29(wc.one_r)));   // back to the data domain
   }
   stf(q.out + i, Fr29::mul(t, c29(q.k.vinv[i & 7])).to_fr());
 }
@@ -733,10 +762,26 @@ int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag) {
 }
 int poly_quotient(Ctx* c, const QuotientArgs& q) {
   prof_begin(c, 3);
-  if (q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR])
-    hipLaunchKernelGGL(quotient_kernel<true>, grid1(q.n8, 128), dim3(128), 0, c->stream, q);
-  else
-    hipLaunchKernelGGL(quotient_kernel<false>, grid1(q.n8, 128), dim3(128), 0, c->stream, q);
+  WidgetConst wc{};
+  if (q.has[QS_RANGE] | q.has[QS_LOGIC] | q.has[QS_FIXED] | q.has[QS_VAR]) {
+    wc.conv = tw_of(Fr::from_u64(32));
+    wc.one_r = tw_plain(Fr::one());
+    wc.c1 = tw_of(Fr::one()); wc.c3 = tw_of(Fr::from_u64(3)); wc.c9 = tw_of(Fr::from_u64(9));
+    wc.c18 = tw_of(Fr::from_u64(18)); wc.c81 = tw_of(Fr::from_u64(81)); wc.c83 = tw_of(Fr::from_u64(83));
+    wc.ed = tw_of(q.edwards_d);
+    Fr k = q.range_ch.sqr(), w = q.range_ch;
+    for (int j = 0; j < 4; ++j) { wc.rg[j] = tw_of(w); w = w * k; }
+    k = q.logic_ch.sqr();
+    const Fr lk[5] = {k.sqr() * k, Fr::one(), k, k.sqr(), k.sqr().sqr()};   // k^3, 1, k, k^2, k^4
+    for (int j = 0; j < 5; ++j) wc.lg[j] = tw_of(lk[j] * q.logic_ch);
+    k = q.fixed_ch.sqr(); w = q.fixed_ch;
+    for (int j = 0; j < 4; ++j) { wc.fx[j] = tw_of(w); w = w * k; }
+    k = q.var_ch.sqr(); w = q.var_ch;
+    for (int j = 0; j < 3; ++j) { wc.vr[j] = tw_of(w); w = w * k; }
+    hipLaunchKernelGGL(quotient_kernel<true>, grid1(q.n8, 128), dim3(128), 0, c->stream, q, wc);
+  } else {
+    hipLaunchKernelGGL(quotient_kernel<false>, grid1(q.n8, 128), dim3(128), 0, c->stream, q, wc);
+  }
   prof_end(c, 3);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
