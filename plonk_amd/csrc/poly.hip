@@ -158,6 +158,7 @@ __device__ __forceinline__ Fr29 lds_get(uint32_t (*sh)[BI_T], int t) {
   for (int i = 0; i < 9; ++i) r.l[i] = sh[i][t];
   return r;
 }
+template <bool TW_IO>   // true: the array holds twiddle-form values (raw integers x * 2^261 mod q), in and out
 __global__ void __launch_bounds__(BI_T) batch_inverse_kernel(Fr* __restrict__ v, uint64_t n, BatchInvArgs a) {
   __shared__ uint32_t shp[9][BI_T], shs[9][BI_T], shinv[9];
   const int t = threadIdx.x;
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(BI_T) batch_inverse_kernel(Fr* __restrict__ v,
       const Fr x = ldf(v + i);
       if (!x.is_zero()) {
         nz |= 1u << k;
-        acc = Fr29::mul(acc, Fr29::mul(Fr29::from_fr(x), conv).csub_q());
+        acc = Fr29::mul(acc, TW_IO ? Fr29::from_fr(x) : Fr29::mul(Fr29::from_fr(x), conv).csub_q());
       }
     }
   }
@@ -225,9 +226,9 @@ __global__ void __launch_bounds__(BI_T) batch_inverse_kernel(Fr* __restrict__ v,
   for (int k = BI_E - 1; k >= 0; --k) {
     const uint64_t i = base + (uint64_t)k * BI_T;
     if ((nz >> k) & 1) {
-      const Fr29 xt = Fr29::mul(Fr29::from_fr(ldf(v + i)), conv).csub_q();
+      const Fr29 xt = TW_IO ? Fr29::from_fr(ldf(v + i)) : Fr29::mul(Fr29::from_fr(ldf(v + i)), conv).csub_q();
       const Fr29 inv_t = Fr29::mul(suf, pre[k]);
-      stf(v + i, Fr29::mul(inv_t, one_r).to_fr());
+      stf(v + i, TW_IO ? inv_t.to_fr() : Fr29::mul(inv_t, one_r).to_fr());
       suf = Fr29::mul(suf, xt);
     }
   }
@@ -347,41 +348,157 @@ static int scan_inplace(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
-int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals) { return scan_inplace<true, false>(c, data, n, totals); }
+// ---- prefix products of twiddle-form values (the grand product z): same three phases in Fr29, and the
+// last phase converts back to the data domain (x * 2^256) for the inverse FFT that follows
+struct PScanArgs {
+  Tw one_t, one_r;
+};
+__device__ __forceinline__ void ps_put(uint32_t (*sh)[SCAN_T], int t, const Fr29& v) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) sh[i][t] = v.l[i];
+}
+__device__ __forceinline__ Fr29 ps_get(uint32_t (*sh)[SCAN_T], int t) {
+  Fr29 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = sh[i][t];
+  return r;
+}
+// Hillis-Steele inclusive product scan of one value per lane; returns the exclusive prefix, total in *tot
+__device__ __forceinline__ Fr29 ps_lanes(Fr29 acc, uint32_t (*sh)[SCAN_T], int t, const Fr29& one_t, Fr29* tot) {
+  for (int d = 1; d < SCAN_T; d <<= 1) {
+    ps_put(sh, t, acc);
+    __syncthreads();
+    if (t >= d) acc = Fr29::mul(ps_get(sh, t - d), acc);
+    __syncthreads();
+  }
+  ps_put(sh, t, acc);
+  __syncthreads();
+  const Fr29 excl = t ? ps_get(sh, t - 1) : one_t;
+  *tot = ps_get(sh, SCAN_T - 1);
+  return excl;
+}
+template <bool FINAL>   // FINAL: single workgroup, results leave in the data domain
+__global__ void __launch_bounds__(SCAN_T) pscan_block_kernel(Fr* __restrict__ data, uint64_t n, Fr* __restrict__ totals, PScanArgs a) {
+  __shared__ uint32_t sh[9][SCAN_T];
+  const int t = threadIdx.x;
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)t * SCAN_E;
+  const Fr29 one_t = tw29(a.one_t);
+  Fr29 v[SCAN_E];
+  Fr29 acc = one_t;
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k) {
+    if (base + k < n) acc = Fr29::mul(acc, ld29_(data + base + k));
+    v[k] = acc;
+  }
+  Fr29 tot;
+  const Fr29 excl = ps_lanes(acc, sh, t, one_t, &tot);
+  if (t == 0) stf(totals + blockIdx.x, tot.to_fr());
+  const Fr29 post = FINAL ? Fr29::mul(excl, tw29(a.one_r)) : excl;   // (x R'') * R / R'' = x R
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k)
+    if (base + k < n) stf(data + base + k, Fr29::mul(post, v[k]).to_fr());
+}
+__global__ void __launch_bounds__(SCAN_T) pscan_totals_kernel(Fr* __restrict__ totals, uint32_t nb, uint32_t per, PScanArgs a) {
+  __shared__ uint32_t sh[9][SCAN_T];
+  const int t = threadIdx.x;
+  const Fr29 one_t = tw29(a.one_t);
+  Fr29 acc = one_t;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t i = t * per + k;
+    if (i < nb) acc = Fr29::mul(acc, ld29_(totals + i));
+  }
+  Fr29 tot;
+  acc = ps_lanes(acc, sh, t, one_t, &tot);
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t i = t * per + k;
+    if (i < nb) {
+      acc = Fr29::mul(acc, ld29_(totals + i));
+      stf(totals + i, acc.to_fr());
+    }
+  }
+}
+__global__ void __launch_bounds__(SCAN_T) pscan_apply_kernel(Fr* __restrict__ data, uint64_t n, const Fr* __restrict__ totals, PScanArgs a) {
+  // block 0 only converts; the others also multiply by the product of everything before them
+  Fr29 off = tw29(a.one_r);
+  if (blockIdx.x) off = Fr29::mul(ld29_(totals + blockIdx.x - 1), off);
+  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_E;
+#pragma unroll
+  for (int k = 0; k < SCAN_E; ++k)
+    if (base + k < n) stf(data + base + k, Fr29::mul(ld29_(data + base + k), off).to_fr());
+}
+// data: twiddle form in, data domain (Montgomery R = 2^256) out
+int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
+  const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  if (nb > SCAN_T * SCAN_MAXPER) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // n <= 2^25
+  PScanArgs a;
+  a.one_t = tw_of(Fr::one());
+  a.one_r = tw_plain(Fr::one());
+  if (nb == 1) {
+    hipLaunchKernelGGL(pscan_block_kernel<true>, dim3(1), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  } else {
+    hipLaunchKernelGGL(pscan_block_kernel<false>, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+    hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb, (nb + SCAN_T - 1) / SCAN_T, a);
+    hipLaunchKernelGGL(pscan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
 int scan_suffix_sum(Ctx* c, Fr* data, uint64_t n, Fr* totals) { return scan_inplace<false, true>(c, data, n, totals); }
 
 // ---------------------------------------------------------------------------
 // permutation grand product inputs (permutation.rs:251-294)
 //   s[0] = 1 ; s[i] = num[i-1] (numerators) ; den[i] = denominators[i-1] (inverted later)
 // ---------------------------------------------------------------------------
-__global__ void perm_terms_kernel(PermArgs a) {
+// Output in twiddle form (raw integers x * 2^261 mod q): the products below, the batch inversion, the
+// num/den product and the prefix-product scan all stay in that form; the scan converts back.
+struct PermConst {
+  Tw conv;       // 32 * R'': data -> twiddle form
+  Tw gamma_t;    // gamma
+  Tw bk_t[4];    // beta * {1, K1, K2, K3}
+  Tw b32_t;      // 32 * beta: sigma (data form) * this = beta * sigma in twiddle form
+  Tw one_t;
+};
+__device__ __forceinline__ Fr29 ld_slot(const void* base, uint64_t idx) {
+  const uint4* q = reinterpret_cast<const uint4*>(reinterpret_cast<const Fr29Slot*>(base) + idx);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t c = reinterpret_cast<const Fr29Slot*>(base)[idx].w[8];
+  Fr29 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c;
+  return r;
+}
+__global__ void __launch_bounds__(128) perm_terms_kernel(PermArgs a, PermConst k) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   if (i == 0) {
-    stf(a.num, Fr::one());
-    stf(a.den, Fr::one());
+    const Fr one = tw29(k.one_t).to_fr();
+    stf(a.num, one);
+    stf(a.den, one);
     return;
   }
   const uint64_t r = i - 1;
-  Fr root = ldf(a.tw_lo + (r & ((1ull << a.lobits) - 1)));
-  if (a.use_hi) root = root * ldf(a.tw_hi + (r >> a.lobits));
-  const Fr beta_root = a.beta * root;
-  Fr num = Fr::one(), den = Fr::one();
+  Fr29 root = ld_slot(a.tw_lo29, r & ((1ull << a.lobits) - 1));
+  if (a.use_hi) root = Fr29::mul(root, ld_slot(a.tw_hi29, r >> a.lobits));
+  const Fr29 conv = tw29(k.conv), gamma_t = tw29(k.gamma_t), b32 = tw29(k.b32_t);
+  Fr29 num, den;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const Fr w = ldf(a.wires[k] + r) + a.gamma;
-    num = num * (w + beta_root * a.ks[k]);
-    den = den * (w + a.beta * ldf(a.sigma[k] + r));
+  for (int j = 0; j < 4; ++j) {
+    const Fr29 wg = Fr29::add_csub(Fr29::mul(ld29_(a.wires[j] + r), conv), gamma_t);
+    const Fr29 nf = Fr29::add_csub(wg, Fr29::mul(root, tw29(k.bk_t[j])));
+    const Fr29 df = Fr29::add_csub(wg, Fr29::mul(ld29_(a.sigma[j] + r), b32));
+    num = j ? Fr29::mul(num, nf) : nf;
+    den = j ? Fr29::mul(den, df) : df;
   }
-  stf(a.num + i, num);
-  stf(a.den + i, den);
+  stf(a.num + i, num.to_fr());
+  stf(a.den + i, den.to_fr());
 }
 __global__ void mul_arrays_kernel(Fr* __restrict__ a, const Fr* __restrict__ b, uint64_t n, int* zero_flag) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Fr y = ldf(b + i);
   if (zero_flag && y.is_zero()) *zero_flag = 1;
-  stf(a + i, ldf(a + i) * y);
+  stf(a + i, Fr29::mul(ld29_(a + i), Fr29::from_fr(y)).to_fr());   // twiddle form is closed under the product
 }
 
 // ---------------------------------------------------------------------------
@@ -737,7 +854,7 @@ int poly_scatter_pi(Ctx* c, Fr* dense, const uint64_t* idx, const Fr* val, uint6
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
-int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n) {
+int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n, bool twiddle_form) {
   static const BatchInvArgs a = [] {
     BatchInvArgs r;
     r.one_t = tw_of(Fr::one());
@@ -746,12 +863,19 @@ int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n) {
     r.conv = tw_of(Fr::from_u64(32));
     return r;
   }();
-  hipLaunchKernelGGL(batch_inverse_kernel, grid1(n, BI_T * BI_E), dim3(BI_T), 0, c->stream, v, n, a);
+  if (twiddle_form) hipLaunchKernelGGL(batch_inverse_kernel<true>, grid1(n, BI_T * BI_E), dim3(BI_T), 0, c->stream, v, n, a);
+  else hipLaunchKernelGGL(batch_inverse_kernel<false>, grid1(n, BI_T * BI_E), dim3(BI_T), 0, c->stream, v, n, a);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
 int poly_perm_terms(Ctx* c, const PermArgs& a) {
-  hipLaunchKernelGGL(perm_terms_kernel, grid1(a.n, 128), dim3(128), 0, c->stream, a);
+  PermConst k;
+  k.conv = tw_of(Fr::from_u64(32));
+  k.gamma_t = tw_of(a.gamma);
+  for (int j = 0; j < 4; ++j) k.bk_t[j] = tw_of(a.beta * a.ks[j]);
+  k.b32_t = tw_of(a.beta * Fr::from_u64(32));
+  k.one_t = tw_of(Fr::one());
+  hipLaunchKernelGGL(perm_terms_kernel, grid1(a.n, 128), dim3(128), 0, c->stream, a, k);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

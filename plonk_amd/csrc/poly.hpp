@@ -20,8 +20,8 @@ struct PermArgs {
   const Fr* sigma[4];   // sigma_evaluations over the n-domain (prover.rs:95-100)
   Fr beta, gamma;
   Fr ks[4];             // 1, K1, K2, K3
-  const Fr* tw_lo;      // w_n^i two-level table (forward NTT tables of log n)
-  const Fr* tw_hi;
+  const void* tw_lo29;  // w_n^i two-level table in twiddle form (Fr29Slot, forward NTT tables of log n)
+  const void* tw_hi29;
   uint32_t lobits;
   int use_hi;
   Fr* num;
@@ -85,9 +85,9 @@ int poly_blind(Ctx* c, Fr* coeffs, uint64_t n, const BlindArgs& a);
 int poly_split_t(Ctx* c, Fr* t, uint64_t n, uint64_t np, Fr* out, const SplitArgs& a);
 int poly_trimmed_len(Ctx* c, const Fr* p, uint64_t n, unsigned long long* out_dev);
 int poly_scatter_pi(Ctx* c, Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count);
-int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n);
+int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n, bool twiddle_form = false);
 int poly_perm_terms(Ctx* c, const PermArgs& a);
-int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag);
+int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag);   // operands in twiddle form
 int poly_quotient(Ctx* c, const QuotientArgs& q);
 // de-aliasing of a quotient interpolated on the 4n coset (prover.hip)
 int poly_dealias(Ctx* c, Fr* t, uint64_t nq, const Fr low[7], const Fr& g_inv);

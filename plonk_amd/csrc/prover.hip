@@ -741,11 +741,12 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     for (int k = 0; k < 4; ++k) { pa.wires[k] = wires_dev + k * n; pa.sigma[k] = p->sigma_n + k * n; }
     pa.beta = beta; pa.gamma = gamma;
     pa.ks[0] = Fr::one(); pa.ks[1] = fr_small(7); pa.ks[2] = fr_small(13); pa.ks[3] = fr_small(17);
-    pa.tw_lo = tbn->tw_lo; pa.tw_hi = tbn->tw_hi; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
+    pa.tw_lo29 = tbn->tw_lo29; pa.tw_hi29 = tbn->tw_hi29; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
     pa.num = p->scratch; pa.den = p->scratch + np;
     HIP_TRY(hipMemsetAsync(p->flag_dev, 0, sizeof(int), c->stream));
     PTRY(poly_perm_terms(c, pa));
-    PTRY(poly_batch_inverse(c, pa.den, n));
+    // numerators / denominators stay in twiddle form (x * 2^261) from perm_terms to the end of the scan
+    PTRY(poly_batch_inverse(c, pa.den, n, true));
     PTRY(poly_mul_arrays(c, pa.num, pa.den, n, p->flag_dev));
     PTRY(scan_prefix_product(c, pa.num, n, p->totals));
     PTRY(ntt_device(c, pa.num, p->zpoly, p->tmp8, L, true, false, n));
