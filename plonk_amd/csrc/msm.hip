@@ -26,6 +26,7 @@
 // Algorithmic HBM bytes per MSM of m terms: 128 * m (32 B scalar + 96 B base).
 #include "plonk_internal.hpp"
 #include "curve28.cuh"
+#include "fr29.cuh"
 
 namespace plonk {
 
@@ -201,7 +202,10 @@ __global__ void msm_digits_kernel(MsmBatch bt, uint64_t srs_n, uint16_t* __restr
   uint32_t* __restrict__ vals = vals_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  const Fr s = ld_fr_g(scalars + i).from_mont();
+  // out of Montgomery form in reduced radix: (x * 2^256) * 32 / 2^261 = x, then exact canonicalisation
+  Fr29 c32 = Fr29::zero();
+  c32.l[0] = 32;
+  const Fr s = Fr29::mul(Fr29::from_fr(ld_fr_g(scalars + i)), c32).to_fr();
   uint32_t carry = 0;
 #pragma unroll
   for (int w = 0; w < MSM_W; ++w) {
