@@ -149,7 +149,11 @@ int plonk_prover_peek(plonk_prover* p, int which, uint64_t offset, uint64_t coun
  * blinders: 14 Fr in the reference's RNG draw order: a0 a1 b0 b1 c0 c1 d0 d1 (prover.rs:154-161),
  *           z0 z1 z2 (:133-135,503), b12 b13 b14 (:553-555).
  * proof: 1008 bytes = Proof::to_bytes (src/proof_system/proof.rs:137-162).
- * PLONK_ERR_UNSAT mirrors Error::CircuitUnsatisfied (quotient_poly.rs:132). */
+ * PLONK_ERR_UNSAT mirrors Error::CircuitUnsatisfied (quotient_poly.rs:132).  By default the quotient is
+ * interpolated on the 4n coset and de-aliased — the same t(X), hence the same proof
+ * bytes — and an unsatisfied witness is recognised by the quotient identity failing at the evaluation
+ * challenge (probability of missing it <= 5n/q); PLONK_QUOTIENT_DOMAIN=8 in the environment selects the
+ * reference's 8n evaluation with its exact degree test. */
 int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const uint64_t* pi_idx,
                        const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
                        uint8_t proof[1008]);
