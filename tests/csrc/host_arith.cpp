@@ -139,3 +139,24 @@ extern "C" void h_merlin_simple(uint8_t out[32]) {
   t.append_message("some label", (const uint8_t*)"some data", 9);
   t.challenge_bytes("challenge", out, 32);
 }
+
+// ---- widgets.hpp: lowest 7 coefficients of the quotient from the lowest 7 of every polynomial ----
+#include "../../plonk_amd/csrc/widgets.hpp"
+// key_low: 15 x 7 Fr (PolyId order), has: 11 flags, low: a b c d z pi (6 x 7 Fr),
+// ch: alpha beta gamma range logic fixed var edwards_d omega n_inv (10 Fr); out: 7 Fr.  All Montgomery limbs.
+extern "C" void h_quotient_low(const uint32_t* key_low, const uint8_t* has, const uint32_t* low, const uint32_t* ch, uint32_t* out) {
+  using namespace plonk;
+  Fr kl[P_COUNT][7];
+  memcpy(kl, key_low, sizeof kl);
+  bool hs[WQS_COUNT];
+  for (int i = 0; i < WQS_COUNT; ++i) hs[i] = has[i] != 0;
+  Fr lows[42], c[10], o[7];
+  memcpy(lows, low, sizeof lows);
+  memcpy(c, ch, sizeof c);
+  QuotientLowIn in;
+  in.low = lows;
+  in.alpha = c[0]; in.beta = c[1]; in.gamma = c[2]; in.range_ch = c[3]; in.logic_ch = c[4]; in.fixed_ch = c[5];
+  in.var_ch = c[6]; in.edwards_d = c[7]; in.omega = c[8]; in.n_inv = c[9];
+  quotient_low(kl, hs, in, o);
+  memcpy(out, o, sizeof o);
+}

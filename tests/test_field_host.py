@@ -14,14 +14,20 @@ SO = os.path.join(HERE, "_build", "libhost_arith.so")
 Q, P = E.Q, E.P
 
 
-@pytest.fixture(scope="module")
-def lib():
+def build_host_lib():
+    """g++ build of tests/csrc/host_arith.cpp: the device headers compiled for the host (HD macros)."""
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
-    hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h) for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh")]
+    hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
+            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return build_host_lib()
 
 
 def fr_limbs(x):

@@ -73,3 +73,38 @@ def test_hip_prover_bit_exact_on_semantic_widget_circuits(monkeypatch, domain, s
         gp.prove(wires_of(bad, prover.size), dict(bad.public_inputs), rec.drawn)
     gp.close()
     ctx.close()
+
+
+def test_host_quotient_low_matches_oracle_quotient():
+    """widgets.hpp `quotient_low` (the de-aliasing input of the 4n quotient domain): evaluating the whole
+    numerator formula — every widget included — in F[X]/(X^7) on the lowest 7 coefficients of each
+    polynomial must give the 7 lowest coefficients of the oracle's quotient t (computed the reference's
+    way, on the 8n coset).  Runs on the CPU through the host harness."""
+    import ctypes
+
+    import plonk_amd
+    from test_field_host import build_host_lib
+    lib = build_host_lib()
+    from oracle.fft import EvaluationDomain
+    from widget_circuits import EDWARDS_D
+    build, prover, pp, tau = _setup(3)
+    tr = {}
+    O.prove(prover, StdRng.seed_from_u64(77), build(), msm=E.msm_pippenger, trace=tr)
+    n = prover.size
+    ch = tr["challenges"]
+    dom = EvaluationDomain(n)
+
+    def low7(poly):
+        return (list(poly) + [0] * 7)[:7]
+
+    mont = plonk_amd.fr_to_bytes_mont
+    key_low = b"".join(mont(low7(prover.pk.polys[name])) for name in plonk_amd.POLY_ORDER)
+    has = bytes(1 if prover.pk.polys[name] else 0 for name in plonk_amd.POLY_ORDER[:11])
+    lows = b"".join(mont(low7(p)) for p in (*tr["wire_polys"], tr["z_poly"], tr["pi_poly"]))
+    chs = mont([ch["alpha"], ch["beta"], ch["gamma"], ch["range"], ch["logic"], ch["fixed"], ch["var"], EDWARDS_D,
+                dom.group_gen, pow(n, -1, Q)])
+    out = ctypes.create_string_buffer(7 * 32)
+    lib.h_quotient_low(key_low, has, lows, chs, out)
+    got = plonk_amd.fr_from_bytes_mont(out.raw)
+    assert got == low7(tr["t_polys"][0])
+    assert any(got)
