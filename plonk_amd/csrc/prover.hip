@@ -13,6 +13,7 @@
 
 #include "poly.hpp"
 #include "transcript.hpp"
+#include "hostg1.hpp"
 #include "widgets.hpp"
 
 static_assert(plonk::WQS_RANGE == plonk::QS_RANGE && plonk::WQS_LOGIC == plonk::QS_LOGIC && plonk::WQS_FIXED == plonk::QS_FIXED &&
@@ -88,29 +89,6 @@ static Fr omega_of(uint32_t L) {
   return g;
 }
 
-// G1Affine::to_bytes: 48-byte BE x, flags 0x80 | 0x40 inf | 0x20 y > -y  (commitment.rs:46-57)
-static void g1_compress97(const uint8_t in[97], uint8_t out[48]) {
-  if (in[96]) {
-    memset(out, 0, 48);
-    out[0] = 0xC0;
-    return;
-  }
-  Fp x, y;
-  memcpy(x.l, in, 48);
-  memcpy(y.l, in + 48, 48);
-  const Fp xc = x.from_mont(), yc = y.from_mont(), nyc = y.neg().from_mont();
-  for (int i = 0; i < 12; ++i) {
-    const uint32_t w = xc.l[11 - i];
-    out[4 * i] = (uint8_t)(w >> 24); out[4 * i + 1] = (uint8_t)(w >> 16);
-    out[4 * i + 2] = (uint8_t)(w >> 8); out[4 * i + 3] = (uint8_t)w;
-  }
-  bool greater = false;   // y > -y lexicographically (as integers)
-  for (int i = 11; i >= 0; --i) {
-    if (yc.l[i] != nyc.l[i]) { greater = yc.l[i] > nyc.l[i]; break; }
-  }
-  out[0] |= 0x80;
-  if (greater) out[0] |= 0x20;
-}
 
 
 #define PTRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
@@ -132,188 +110,6 @@ struct SideJoin {   // never leave side work in flight when prove() returns (buf
   Ctx* c;
   ~SideJoin() { (void)hipStreamSynchronize(c->side_stream); }
 };
-
-// ---- host-side affine normalisation of the MSM results ----------------------------------------
-// The transcript needs the commitments of a group before the next kernels can be queued, so this
-// sits on the critical path with the GPU idle: 64-bit-limb Montgomery arithmetic (the generic
-// 32-bit Field<> costs 130 us per Fp inversion on the host) and ONE shared inversion per group.
-struct Fp64 {
-  uint64_t l[6];
-};
-static uint64_t fp64_ninv() {   // -p^-1 mod 2^64 by Newton iteration
-  uint64_t p0 = (uint64_t)FpP::MOD[0] | ((uint64_t)FpP::MOD[1] << 32), inv = 1;
-  for (int i = 0; i < 6; ++i) inv *= 2 - p0 * inv;
-  return 0 - inv;
-}
-static Fp64 fp64_mod() {
-  Fp64 m;
-  for (int i = 0; i < 6; ++i) m.l[i] = (uint64_t)FpP::MOD[2 * i] | ((uint64_t)FpP::MOD[2 * i + 1] << 32);
-  return m;
-}
-static Fp64 fp64_mul(const Fp64& a, const Fp64& b) {   // CIOS, R = 2^384 (same Montgomery form as Fp)
-  static const uint64_t NINV = fp64_ninv();
-  static const Fp64 M = fp64_mod();
-  typedef unsigned __int128 u128;
-  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = 0; i < 6; ++i) {
-    u128 c = 0;
-    for (int j = 0; j < 6; ++j) {
-      c += (u128)a.l[j] * b.l[i] + t[j];
-      t[j] = (uint64_t)c;
-      c >>= 64;
-    }
-    c += t[6];
-    t[6] = (uint64_t)c;
-    t[7] = (uint64_t)(c >> 64);
-    const uint64_t m = t[0] * NINV;
-    c = ((u128)m * M.l[0] + t[0]) >> 64;
-    for (int j = 1; j < 6; ++j) {
-      c += (u128)m * M.l[j] + t[j];
-      t[j - 1] = (uint64_t)c;
-      c >>= 64;
-    }
-    c += t[6];
-    t[5] = (uint64_t)c;
-    t[6] = t[7] + (uint64_t)(c >> 64);
-  }
-  Fp64 r, d;
-  uint64_t borrow = 0;
-  for (int j = 0; j < 6; ++j) {
-    r.l[j] = t[j];
-    const u128 s = (u128)t[j] - M.l[j] - borrow;
-    d.l[j] = (uint64_t)s;
-    borrow = (uint64_t)(s >> 64) & 1;
-  }
-  return (t[6] || !borrow) ? d : r;
-}
-static Fp64 fp64_inv(const Fp64& a) {   // a^(p-2)
-  Fp64 e = fp64_mod();
-  e.l[0] -= 2;   // p is odd and p mod 2^64 > 2: no borrow
-  Fp64 acc = a;
-  bool started = false;
-  for (int w = 5; w >= 0; --w)
-    for (int b = 63; b >= 0; --b) {
-      const bool bit = (e.l[w] >> b) & 1;
-      if (!started) { started = bit; continue; }
-      acc = fp64_mul(acc, acc);
-      if (bit) acc = fp64_mul(acc, a);
-    }
-  return acc;
-}
-static Fp64 fp64_add(const Fp64& a, const Fp64& b) {
-  static const Fp64 M = fp64_mod();
-  typedef unsigned __int128 u128;
-  Fp64 r, d;
-  u128 c = 0;
-  for (int j = 0; j < 6; ++j) { c += (u128)a.l[j] + b.l[j]; r.l[j] = (uint64_t)c; c >>= 64; }
-  uint64_t borrow = 0;
-  for (int j = 0; j < 6; ++j) {
-    const u128 s = (u128)r.l[j] - M.l[j] - borrow;
-    d.l[j] = (uint64_t)s;
-    borrow = (uint64_t)(s >> 64) & 1;
-  }
-  return ((uint64_t)c || !borrow) ? d : r;
-}
-static Fp64 fp64_sub(const Fp64& a, const Fp64& b) {
-  static const Fp64 M = fp64_mod();
-  typedef unsigned __int128 u128;
-  Fp64 r;
-  uint64_t borrow = 0;
-  for (int j = 0; j < 6; ++j) {
-    const u128 s = (u128)a.l[j] - b.l[j] - borrow;
-    r.l[j] = (uint64_t)s;
-    borrow = (uint64_t)(s >> 64) & 1;
-  }
-  if (borrow) {
-    u128 c = 0;
-    for (int j = 0; j < 6; ++j) { c += (u128)r.l[j] + M.l[j]; r.l[j] = (uint64_t)c; c >>= 64; }
-  }
-  return r;
-}
-static bool fp64_is_zero(const Fp64& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3] | a.l[4] | a.l[5]) == 0; }
-
-// XYZZ group law on the host (same formulas as curve.cuh: EFD dbl-2008-s-1 / add-2008-s), canonical
-// coordinates; ZZ == 0 marks the identity.
-struct H1 {
-  Fp64 X, Y, ZZ, ZZZ;
-  bool inf() const { return fp64_is_zero(ZZ); }
-};
-static H1 h1_dbl(const H1& p) {
-  if (p.inf()) return p;
-  const Fp64 U = fp64_add(p.Y, p.Y), V = fp64_mul(U, U), W = fp64_mul(U, V), S = fp64_mul(p.X, V);
-  const Fp64 XX = fp64_mul(p.X, p.X), M = fp64_add(fp64_add(XX, XX), XX);
-  H1 r;
-  r.X = fp64_sub(fp64_mul(M, M), fp64_add(S, S));
-  r.Y = fp64_sub(fp64_mul(M, fp64_sub(S, r.X)), fp64_mul(W, p.Y));
-  r.ZZ = fp64_mul(V, p.ZZ);
-  r.ZZZ = fp64_mul(W, p.ZZZ);
-  return r;
-}
-static H1 h1_add(const H1& a, const H1& b) {
-  if (a.inf()) return b;
-  if (b.inf()) return a;
-  const Fp64 U1 = fp64_mul(a.X, b.ZZ), U2 = fp64_mul(b.X, a.ZZ), S1 = fp64_mul(a.Y, b.ZZZ), S2 = fp64_mul(b.Y, a.ZZZ);
-  const Fp64 P = fp64_sub(U2, U1), R = fp64_sub(S2, S1);
-  if (fp64_is_zero(P)) {
-    if (fp64_is_zero(R)) return h1_dbl(a);
-    H1 id;
-    memset(&id, 0, sizeof id);
-    return id;
-  }
-  const Fp64 PP = fp64_mul(P, P), PPP = fp64_mul(P, PP), Q = fp64_mul(U1, PP);
-  H1 r;
-  r.X = fp64_sub(fp64_sub(fp64_mul(R, R), PPP), fp64_add(Q, Q));
-  r.Y = fp64_sub(fp64_mul(R, fp64_sub(Q, r.X)), fp64_mul(S1, PPP));
-  r.ZZ = fp64_mul(fp64_mul(a.ZZ, b.ZZ), PP);
-  r.ZZZ = fp64_mul(fp64_mul(a.ZZZ, b.ZZZ), PPP);
-  return r;
-}
-// W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j  from the 16 bit sums of msm_bits_kernel
-// (rows T_0..T_7, columns T'_0..T'_6, C_128): Horner over U_0..U_14.
-static G1 finish_bit_sums(const G1* bits) {
-  H1 u[16];
-  for (int k = 0; k < 16; ++k) {
-    memcpy(u[k].X.l, bits[k].X.l, 48); memcpy(u[k].Y.l, bits[k].Y.l, 48);
-    memcpy(u[k].ZZ.l, bits[k].ZZ.l, 48); memcpy(u[k].ZZZ.l, bits[k].ZZZ.l, 48);
-  }
-  H1 U[15];
-  for (int j = 0; j < 7; ++j) U[j] = u[8 + j];
-  U[7] = h1_add(u[15], u[0]);
-  for (int j = 1; j < 8; ++j) U[7 + j] = u[j];
-  H1 acc = U[14];
-  for (int j = 13; j >= 0; --j) acc = h1_add(h1_dbl(acc), U[j]);
-  G1 r;
-  if (acc.inf()) return G1::identity();
-  memcpy(r.X.l, acc.X.l, 48); memcpy(r.Y.l, acc.Y.l, 48); memcpy(r.ZZ.l, acc.ZZ.l, 48); memcpy(r.ZZZ.l, acc.ZZZ.l, 48);
-  return r;
-}
-
-static Fp64 to64(const Fp& x) { Fp64 r; memcpy(r.l, x.l, 48); return r; }
-static Fp from64(const Fp64& x) { Fp r; memcpy(r.l, x.l, 48); return r; }
-
-// x = X / ZZ, y = Y / ZZZ for a group of XYZZ points -> 97-byte raw affine (x || y || infinity)
-static void batch_xyzz_to_affine97(const G1* pts, int count, uint8_t (*out)[97]) {
-  Fp64 den[16], pre[16];
-  int idx[16], m = 0;
-  for (int i = 0; i < count; ++i) {
-    memset(out[i], 0, 97);
-    if (pts[i].is_identity()) { out[i][96] = 1; continue; }
-    den[m] = fp64_mul(to64(pts[i].ZZ), to64(pts[i].ZZZ));
-    pre[m] = m ? fp64_mul(pre[m - 1], den[m]) : den[m];
-    idx[m++] = i;
-  }
-  if (!m) return;
-  Fp64 inv = fp64_inv(pre[m - 1]);
-  for (int k = m - 1; k >= 0; --k) {
-    const Fp64 dinv = k ? fp64_mul(inv, pre[k - 1]) : inv;
-    if (k) inv = fp64_mul(inv, den[k]);
-    const G1& p = pts[idx[k]];
-    const Fp x = from64(fp64_mul(to64(p.X), fp64_mul(dinv, to64(p.ZZZ))));
-    const Fp y = from64(fp64_mul(to64(p.Y), fp64_mul(dinv, to64(p.ZZ))));
-    memcpy(out[idx[k]], x.l, 48);
-    memcpy(out[idx[k]] + 48, y.l, 48);
-  }
-}
 
 static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 16 bit sums per commitment (msm_bits_kernel)
 

@@ -160,3 +160,37 @@ extern "C" void h_quotient_low(const uint32_t* key_low, const uint8_t* has, cons
   quotient_low(kl, hs, in, o);
   memcpy(out, o, sizeof o);
 }
+
+// ---- hostg1.hpp: MSM finishing (Horner over the 16 bit sums), group normalisation, compression ----
+#include "../../plonk_amd/csrc/hostg1.hpp"
+// pts: 16 affine points (96 B raw each; a point with x = y = 0 stands for the identity) -> XYZZ bit sums
+// -> finish_bit_sums -> batch affine -> 48-byte compressed.  out48: the commitment.
+extern "C" void h_finish_bit_sums(const uint8_t* pts96, uint8_t out48[48]) {
+  using namespace plonk;
+  G1 bits[16];
+  for (int k = 0; k < 16; ++k) {
+    G1Affine a;
+    memcpy(&a, pts96 + 96 * k, 96);
+    bits[k] = (a.x.is_zero() && a.y.is_zero()) ? G1::identity() : G1::from_affine(a);
+    if (k & 1) bits[k] = bits[k].dbl().add(bits[k].neg());   // a non-trivial ZZ: 2P - P
+  }
+  const G1 w = finish_bit_sums(bits);
+  uint8_t aff[1][97];
+  batch_xyzz_to_affine97(&w, 1, aff);
+  g1_compress97(aff[0], out48);
+}
+// count <= 16 XYZZ points given as affine (made projective with odd scalings) -> compressed encodings
+extern "C" void h_batch_compress(const uint8_t* pts96, int count, uint8_t* out48) {
+  using namespace plonk;
+  G1 p[16];
+  for (int k = 0; k < count; ++k) {
+    G1Affine a;
+    memcpy(&a, pts96 + 96 * k, 96);
+    if (a.x.is_zero() && a.y.is_zero()) { p[k] = G1::identity(); continue; }
+    p[k] = G1::from_affine(a);
+    for (int j = 0; j < k % 3; ++j) p[k] = p[k].dbl().add(p[k].neg()).add(G1::identity());
+  }
+  uint8_t aff[16][97];
+  batch_xyzz_to_affine97(p, count, aff);
+  for (int k = 0; k < count; ++k) g1_compress97(aff[k], out48 + 48 * k);
+}

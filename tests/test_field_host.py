@@ -19,7 +19,7 @@ def build_host_lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
     hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
-            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp")]
+            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -263,3 +263,37 @@ def test_host_transcript_matches_merlin_vector(lib):
     out = (ctypes.c_uint8 * 32)()
     lib.h_merlin_simple(out)
     assert bytes(out).hex() == MERLIN_SIMPLE
+
+
+def test_host_msm_finish_and_group_normalisation(lib):
+    """hostg1.hpp: W = sum_j 2^j U_j from the 16 bit sums of msm_bits_kernel (rows T_0..T_7, columns
+    T'_0..T'_6, C_128), the shared-inversion affine normalisation and the compressed encoding, in
+    64-bit-limb host arithmetic, against the oracle's group law."""
+    rnd = random.Random(64)
+    G = E.G1_GEN
+    for trial in range(4):
+        pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(16)]
+        if trial == 1:
+            pts[3] = None                         # an empty bit sum
+            pts[9] = None
+        if trial == 2:
+            pts = [None] * 16                     # all-zero polynomial: the commitment is the identity
+        if trial == 3:
+            pts = [pts[0]] * 16                   # equal points: the additions hit the doubling branch
+        raw = b"".join(E.g1_to_raw96(p) if p is not None else bytes(96) for p in pts)
+        out = (ctypes.c_uint8 * 48)()
+        lib.h_finish_bit_sums(raw, out)
+        # rows weigh 2^(7+j) (j = 0..7 -> indices 0..7), columns 2^j (indices 8..14), C_128 weighs 2^7 (index 15)
+        want = None
+        for k, p in enumerate(pts):
+            if p is None:
+                continue
+            w = (1 << (7 + k)) if k < 8 else ((1 << (k - 8)) if k < 15 else (1 << 7))
+            want = E.g1_add(want, E.g1_mul(p, w))
+        assert bytes(out) == E.g1_compress(want), trial
+    pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(15)]
+    pts[4] = None
+    raw = b"".join(E.g1_to_raw96(p) if p is not None else bytes(96) for p in pts)
+    out = (ctypes.c_uint8 * (48 * 15))()
+    lib.h_batch_compress(raw, 15, out)
+    assert bytes(out) == b"".join(E.g1_compress(p) for p in pts)
