@@ -26,14 +26,23 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    src = os.path.join(_DIR, "oracle.c")
+    srcs = [os.path.join(_DIR, "oracle_prove.c"), os.path.join(_DIR, "oracle.c")]   # oracle_prove.c includes oracle.c
     so = os.path.join(_DIR, f"liboracle_{_cpu_tag()}.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", src, "-o", so])
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", srcs[0], "-o", so])
     lib = ctypes.CDLL(so)
     lib.oracle_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
     lib.oracle_msm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]
     lib.oracle_max_threads.restype = ctypes.c_int
+    vp, u64 = ctypes.c_void_p, ctypes.c_uint64
+    lib.oracle_prover_new.restype = vp
+    lib.oracle_prover_new.argtypes = [u64, vp, u64, ctypes.POINTER(vp), ctypes.POINTER(u64), vp, u64, vp, ctypes.c_int]
+    lib.oracle_prover_free.argtypes = [vp]
+    lib.oracle_prover_free.restype = None
+    lib.oracle_prover_vk.argtypes = [vp, vp]
+    lib.oracle_prover_vk.restype = None
+    lib.oracle_srs_generate.argtypes = [vp, vp, u64, vp, ctypes.c_int]
+    lib.oracle_prover_prove.argtypes = [vp, ctypes.POINTER(vp), vp, vp, u64, vp, vp, vp]
     _lib = lib
     return lib
 
@@ -68,3 +77,90 @@ def max_threads() -> int:
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def srs_generate(tau_mont: bytes, g_scalar_mont: bytes, n: int, threads: int = 0) -> bytes:
+    """[g tau^i] G1 for i < n as n x 96 B raw points (PublicParameters::setup semantics, srs.rs:61-100)."""
+    out = ctypes.create_string_buffer(96 * max(n, 1))
+    rc = load().oracle_srs_generate(tau_mont, g_scalar_mont, n, out, threads)
+    assert rc == 0
+    return out.raw[:96 * n]
+
+
+# ---- whole prove() (oracle_prove.c) ------------------------------------------------------
+POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
+              "q_fixed_group_add", "q_variable_group_add", "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+
+
+class _Trace(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in
+                ("wire_polys", "z_poly", "t_poly", "w_z", "w_zw", "evals", "challenges", "seconds")]
+
+
+class CircuitUnsatisfied(Exception):
+    pass
+
+
+class CProver:
+    """oracle_prover_new / oracle_prover_prove: the C restatement of Prover::new + prove_inner.
+    polys: {name: bytes of Montgomery limbs (32 B per coefficient)} in coefficient form;
+    srs96: npoints x 96 B; vk48: 15 x 48 B in POLY_ORDER or None (commit here)."""
+
+    def __init__(self, constraints: int, label: bytes, polys: dict, srs96: bytes, vk48: bytes | None = None, threads: int = 0):
+        lib = load()
+        self.lib = lib
+        bufs = [bytes(polys.get(name, b"")) for name in POLY_ORDER]
+        arr = (ctypes.c_void_p * 15)(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p) for b in bufs])
+        lens = (ctypes.c_uint64 * 15)(*[len(b) // 32 for b in bufs])
+        n = 1
+        while n < constraints:
+            n *= 2
+        self.n = n
+        self.h = lib.oracle_prover_new(constraints, label, len(label), arr, lens, srs96, len(srs96) // 96, vk48, threads)
+        if not self.h:
+            raise ValueError("oracle_prover_new failed (polynomial longer than the domain, or degree > SRS)")
+
+    def vk(self) -> bytes:
+        out = ctypes.create_string_buffer(15 * 48)
+        self.lib.oracle_prover_vk(self.h, out)
+        return out.raw
+
+    def prove(self, wires, pi_idx, pi_val_mont: bytes, blinders_mont: bytes, trace: bool = False):
+        """wires: 4 x bytes (n x 32 B Montgomery); returns proof bytes (and a dict of stage arrays)."""
+        n = self.n
+        assert all(len(w) == 32 * n for w in wires) and len(blinders_mont) == 14 * 32
+        wb = [ctypes.create_string_buffer(bytes(w), 32 * n) for w in wires]
+        warr = (ctypes.c_void_p * 4)(*[ctypes.cast(b, ctypes.c_void_p) for b in wb])
+        idx = (ctypes.c_uint64 * max(len(pi_idx), 1))(*pi_idx)
+        proof = ctypes.create_string_buffer(1008)
+        tr = _Trace()
+        secs = (ctypes.c_double * 6)()
+        tr.seconds = ctypes.cast(secs, ctypes.c_void_p)
+        keep = {}
+        if trace:
+            for name, cnt in (("wire_polys", 4 * (n + 8)), ("z_poly", n + 8), ("t_poly", 8 * n), ("w_z", n + 8), ("w_zw", n + 8),
+                              ("evals", 15), ("challenges", 10)):
+                keep[name] = ctypes.create_string_buffer(32 * cnt)
+                setattr(tr, name, ctypes.cast(keep[name], ctypes.c_void_p))
+        rc = self.lib.oracle_prover_prove(self.h, warr, idx, pi_val_mont, len(pi_idx), blinders_mont, proof, ctypes.byref(tr))
+        self.seconds = dict(zip(("ntt", "msm", "quotient", "perm", "tail", "total"), secs))
+        if rc == -6:
+            raise CircuitUnsatisfied()
+        if rc == -3:
+            raise ValueError("PolynomialDegreeTooLarge")
+        if rc:
+            raise ValueError(f"oracle_prover_prove rc={rc}")
+        if trace:
+            return proof.raw, {k: v.raw for k, v in keep.items()}
+        return proof.raw
+
+    def close(self):
+        if self.h:
+            self.lib.oracle_prover_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,144 @@
+"""GPU parity at the BASELINE sizes: the 1008 Proof bytes of the HIP prover (through the C-ABI)
+must equal, byte for byte, those of the C restatement of the reference's prove_inner
+(oracle/c/oracle_prove.c — pinned to the reference KAT digest and to the big-int oracle by
+tests/test_oracle_c_prove.py) on the same SRS, circuit, witness and blinders.
+
+Circuits: every widget family (range, logic XOR/AND, fixed-base, curve addition) with honest
+non-trivial witnesses, random arithmetic gates and public inputs (tests/circuits.py), on both
+quotient domains.  Sizes 2^12 / 2^13 / 2^16 exercise the code paths a 256-gate circuit never reaches:
+multi-workgroup scans (scan_block / scan_totals / scan_apply), batch inversion over more than one
+4096-element workgroup, the tree combine of eval_kernel, 2- and 3-pass NTTs inside the prover
+(8n = 2^19 at 2^16 gates) and MSM buckets with more than one slice.  BASELINE config 2:
+"2^16 gates, 1xMI355X, HIP NTT + HIP Pippenger MSM, bit-exact Proof vs CPU"."""
+import hashlib
+
+import pytest
+
+from oracle import cbind
+from tests import circuits as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonk_amd
+    c = plonk_amd.Context(0)
+    yield c
+    c.close()
+
+
+_cases = {}
+
+
+def case_for(log_n):
+    """circuit + SRS + C-oracle prover, shared by the two quotient domains"""
+    if log_n not in _cases:
+        _cases.clear()   # one size resident at a time (the 8n key evaluations of the oracle are large)
+        case = C.compile_fast(C.big_widget_circuit(1 << log_n, seed=100 + log_n)(), b"size-parity")
+        assert case["size"] == 1 << log_n and len(case["pi_idx"]) >= 2
+        srs = C.synthetic_srs(case["size"] + 7)
+        cp = cbind.CProver(case["constraints"], case["label"], case["polys"], srs)
+        _cases[log_n] = (case, srs, cp)
+    return _cases[log_n]
+
+
+def gpu_proof(ctx, case, srs, blinders_mont, vk=None):
+    import plonk_amd
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], vk)
+    try:
+        got_vk = gp.vk_commitments()
+        wbuf = ctx.alloc(4 * 32 * case["size"])
+        for k in range(4):
+            wbuf.upload(case["wires"][k], 32 * case["size"] * k)
+        proof = gp.prove_dev(wbuf.ptr, case["pi"], blinders_mont)
+        wbuf.free()
+        return proof, got_vk
+    finally:
+        gp.close()
+
+
+@pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
+@pytest.mark.parametrize("log_n", [12, 13, 16])
+def test_proof_bytes_equal_c_oracle(ctx, monkeypatch, log_n, domain):
+    if domain == "quotient-8n":
+        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
+    else:
+        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    case, srs, cp = case_for(log_n)
+    for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
+        assert case["polys"][name], name          # every selector family is active
+    bl = C.blinders(7000 + log_n)
+    expected = cp.prove(case["wires"], case["pi_idx"], case["pi_val"], bl)
+    got, vk = gpu_proof(ctx, case, srs, bl)
+    assert vk == cp.vk()                           # Compiler::preprocess commitments (compiler.rs:213-232)
+    assert got == expected, (hashlib.blake2b(got).hexdigest()[:16], hashlib.blake2b(expected).hexdigest()[:16])
+
+
+@pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
+def test_unsatisfied_witness_is_circuit_unsatisfied_exactly(ctx, monkeypatch, domain):
+    """reference quotient_poly.rs:132 returns Error::CircuitUnsatisfied and nothing else; the shim maps
+    PLONK_ERR_UNSAT to it.  One corrupted wire value in a widget row and one in an arithmetic row."""
+    import plonk_amd
+    if domain == "quotient-8n":
+        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
+    else:
+        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    case, srs, cp = case_for(12)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], cp.vk())
+    n = case["size"]
+    wbuf = ctx.alloc(4 * 32 * n)
+    for col, row in ((2, 9), (0, n - 3), (3, 1000)):
+        for k in range(4):
+            w = bytearray(case["wires"][k])
+            if k == col:
+                w[32 * row] ^= 1
+            wbuf.upload(bytes(w), 32 * n * k)
+        with pytest.raises(plonk_amd.CircuitUnsatisfied):
+            gp.prove_dev(wbuf.ptr, case["pi"], C.blinders(3))
+    # a wrong public input is an unsatisfied circuit too
+    for k in range(4):
+        wbuf.upload(case["wires"][k], 32 * n * k)
+    bad_pi = dict(case["pi"])
+    bad_pi[case["pi_idx"][0]] = (bad_pi[case["pi_idx"][0]] + 1) % C.Q
+    with pytest.raises(plonk_amd.CircuitUnsatisfied):
+        gp.prove_dev(wbuf.ptr, bad_pi, C.blinders(3))
+    # and the prover still proves the honest witness bit-exactly afterwards
+    bl = C.blinders(4)
+    assert gp.prove_dev(wbuf.ptr, case["pi"], bl) == cp.prove(case["wires"], case["pi_idx"], case["pi_val"], bl)
+    wbuf.free()
+    gp.close()
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
+def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
+    """BASELINE config 3 (2^20 gates): the bench circuit of bench.py (dense arithmetic profile) and the
+    whole 1008-byte proof against the C oracle run on the host cores (about a minute)."""
+    import bench
+    import plonk_amd
+    if domain == "quotient-8n":
+        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
+    else:
+        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    log_n = 20
+    n = 1 << log_n
+    key = ("bench", log_n)
+    if key not in _cases:
+        _cases.clear()
+        wires, cols, trivial = bench.synth_circuit(log_n)
+        polys = {k: C.fr_bytes(v) for k, v in trivial.items()}
+        for name, raw in cols.items():
+            polys[name] = cbind.ntt_bytes(raw, log_n, True, False, n)
+        srs = C.synthetic_srs(n + 7)
+        _cases[key] = (wires, polys, srs)
+    wires, polys, srs = _cases[key]
+    case = dict(constraints=n, size=n, label=b"bench", polys=polys, wires=wires, pi={}, pi_idx=[], pi_val=b"")
+    bl = C.blinders(2020)
+    got, vk = gpu_proof(ctx, case, srs, bl)
+    cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk)   # VK commitments are compared at 2^12..2^16; here they seed both transcripts
+    expected = cp.prove(wires, [], b"", bl)
+    cp.close()
+    assert got == expected
