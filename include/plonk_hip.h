@@ -100,12 +100,15 @@ int plonk_dev_free(plonk_ctx* ctx, void* p);
 int plonk_dev_h2d(plonk_ctx* ctx, void* dst_dev, const void* src_host, uint64_t bytes);
 int plonk_dev_d2h(plonk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 int plonk_dev_sync(plonk_ctx* ctx);
-void* plonk_ctx_stream(plonk_ctx* ctx); /* hipStream_t the library launches on */
+void* plonk_ctx_stream(plonk_ctx* ctx); /* the hipStream_t of the context's main stream (prove() also uses a private side stream) */
 
 /* ---- device-resident Prover::prove (V3) -------------------------------------------
  * Replaces prove_inner (src/compiler/prover.rs:415-761) minus witness generation and the
  * RNG, which stay with the caller (Composer::prove, src/composer.rs:442; BlsScalar::random).
- * The context must hold the commit key (plonk_srs_load: >= size + 7 points).
+ * The context must hold the commit key (plonk_srs_load: >= size + 7 points).  A prover is bound to
+ * the key its context held at plonk_prover_create: after a later plonk_srs_load /
+ * plonk_prover_from_bytes on the same context, plonk_prover_prove on the older prover returns
+ * PLONK_ERR_STATE (its degree bounds and shard ranges describe a key that is gone) — rebuild it.
  *
  * desc.polys: the 15 ProverKey polynomials in coefficient form (Fr Montgomery limbs), order
  *   q_m q_l q_r q_o q_f q_c q_arith q_range q_logic q_fixed_group_add q_variable_group_add

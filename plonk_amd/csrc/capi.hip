@@ -160,7 +160,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   delete ctx;
 }
 
-void* plonk_ctx_stream(plonk_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+void* plonk_ctx_stream(plonk_ctx* ctx) { return ctx ? (void*)ctx->c.main_stream : nullptr; }   // never the side stream a running prove() may have swapped in
 
 // ---- device memory helpers ----------------------------------------------------
 int plonk_dev_alloc(plonk_ctx* ctx, uint64_t bytes, void** out) {
@@ -171,25 +171,33 @@ int plonk_dev_alloc(plonk_ctx* ctx, uint64_t bytes, void** out) {
 }
 int plonk_dev_free(plonk_ctx* ctx, void* p) {
   if (!ctx) return PLONK_ERR_ARG;
-  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   HIP_TRY(hipFree(p));
   return PLONK_OK;
 }
 int plonk_dev_h2d(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.stream));
-  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.main_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
 }
 int plonk_dev_d2h(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.stream));
-  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.main_stream));
+  HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
 }
 int plonk_dev_sync(plonk_ctx* ctx) {
   if (!ctx) return PLONK_ERR_ARG;
-  HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
 }
 

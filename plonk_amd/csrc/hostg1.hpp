@@ -215,5 +215,55 @@ static void batch_xyzz_to_affine97(const G1* pts, int count, uint8_t (*out)[97])
   }
 }
 
+// G1Affine::from_bytes on a 48-byte compressed encoding, as Commitment::from_reader applies it to the
+// VerifierKey commitments (widget.rs:113-134): compression flag set; infinity <=> every other bit clear;
+// x canonical (< p); x^3 + 4 a square; the point in the prime-order subgroup.  Validity only — the
+// bytes themselves seed the transcript.
+static Fp64 fp64_pow(const Fp64& a, const Fp64& e) {
+  Fp64 acc = to64(Fp::one());
+  for (int w = 5; w >= 0; --w)
+    for (int b = 63; b >= 0; --b) {
+      acc = fp64_mul(acc, acc);
+      if ((e.l[w] >> b) & 1) acc = fp64_mul(acc, a);
+    }
+  return acc;
+}
+static bool g1_compressed_valid(const uint8_t in[48]) {
+  const uint8_t flags = in[0];
+  if (!(flags & 0x80)) return false;
+  Fp64 raw;
+  for (int i = 0; i < 6; ++i) {
+    uint64_t v = 0;
+    for (int b = 0; b < 8; ++b) {
+      const int pos = 8 * (5 - i) + b;
+      v = (v << 8) | (pos == 0 ? (uint8_t)(in[0] & 0x1f) : in[pos]);
+    }
+    raw.l[i] = v;
+  }
+  if (flags & 0x40) return !(flags & 0x20) && fp64_is_zero(raw);
+  const Fp64 M = fp64_mod();
+  bool lt = false;
+  for (int i = 5; i >= 0; --i)
+    if (raw.l[i] != M.l[i]) { lt = raw.l[i] < M.l[i]; break; }
+  if (!lt) return false;
+  Fp r2;
+  for (int i = 0; i < 12; ++i) r2.l[i] = FpP::R2[i];
+  const Fp64 x = fp64_mul(raw, to64(r2));                       // Montgomery form
+  const Fp64 y2 = fp64_add(fp64_mul(fp64_mul(x, x), x), to64(Fp::from_u64(4)));
+  Fp64 e = M;                                                    // (p + 1) / 4  (p = 3 mod 4)
+  e.l[0] += 1;                                                   // p mod 2^64 is not all-ones: no carry
+  for (int i = 0; i < 6; ++i) e.l[i] = (e.l[i] >> 2) | (i < 5 ? e.l[i + 1] << 62 : 0);
+  const Fp64 y = fp64_pow(y2, e);
+  if (!fp64_is_zero(fp64_sub(fp64_mul(y, y), y2))) return false;   // not on the curve
+  H1 P, acc;
+  P.X = x; P.Y = y; P.ZZ = to64(Fp::one()); P.ZZZ = P.ZZ;
+  memset(&acc, 0, sizeof acc);
+  for (int b = 254; b >= 0; --b) {                               // [q]P == O  (is_torsion_free)
+    acc = h1_dbl(acc);
+    if ((FrP::MOD[b >> 5] >> (b & 31)) & 1) acc = h1_add(acc, P);
+  }
+  return acc.inf();
+}
+
 
 }  // namespace plonk

@@ -542,6 +542,7 @@ __global__ void msm_identity_kernel(G1* out) {
 // host side
 // ---------------------------------------------------------------------------
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
+  ++c->srs_gen;   // provers built on the previous key refuse to prove (prover.hip)
   if (c->srs_table) { HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
   if (n == 0) return PLONK_OK;
   if ((uint64_t)MSM_W * n >= (1ull << 31)) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // entry word: 31-bit table index
@@ -686,8 +687,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     hipLaunchKernelGGL(msm_bits_kernel, dim3(MSM_BIT_SUMS, count), dim3(128), 0, st, bt, (const G1RSlot*)w.chunk);
   } else {
     constexpr size_t smem = sizeof(G1R) * (RC_ROWS + RC_COLS);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)msm_final_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    smem_opt_in(c, (const void*)msm_final_kernel, smem);
     hipLaunchKernelGGL(msm_final_kernel, dim3(count), dim3(384), smem, st, bt, (const G1RSlot*)w.chunk);
   }
   prof_end(c, 2);

@@ -413,12 +413,10 @@ template <int RLOG>
 static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint32_t nblocks) {
   constexpr size_t smem = (size_t)Fr29::N * (1 << TILE_LOG) * sizeof(uint32_t);
   if (transpose) {
-    static bool attr_t = false;
-    if (!attr_t) { (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<RLOG, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_t = true; }
+    smem_opt_in(c, (const void*)ntt_pass_kernel<RLOG, true>, smem);
     hipLaunchKernelGGL((ntt_pass_kernel<RLOG, true>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
   } else {
-    static bool attr_n = false;
-    if (!attr_n) { (void)hipFuncSetAttribute((const void*)ntt_pass_kernel<RLOG, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_n = true; }
+    smem_opt_in(c, (const void*)ntt_pass_kernel<RLOG, false>, smem);
     hipLaunchKernelGGL((ntt_pass_kernel<RLOG, false>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
   }
 }

@@ -5,6 +5,7 @@
 
 #include <map>
 #include <mutex>
+#include <set>
 #include <vector>
 
 #include "../../include/plonk_hip.h"
@@ -76,6 +77,7 @@ struct Ctx {
   std::mutex mu;         // serialises entry points (reference calls concurrently from rayon)
   std::mutex table_mu;
   std::map<uint32_t, NttTables*> ntt_tables;
+  std::set<const void*> smem_opt_in;   // kernels whose dynamic-LDS limit was raised on THIS device (hipFuncSetAttribute is per device)
   // NTT staging for the host-pointer API
   Fr* ntt_buf = nullptr;
   Fr* ntt_tmp = nullptr;
@@ -83,6 +85,7 @@ struct Ctx {
   // SRS
   void* srs_table = nullptr;       // [MSM_W][npoints] 128-B affine entries (Fp28), 2^(16 w) * P_i
   uint64_t srs_n = 0;
+  uint64_t srs_gen = 0;            // bumped by every (re)load: provers remember the generation they were built on
   MsmWork msm;
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
@@ -94,6 +97,10 @@ struct Ctx {
 // ntt.hip
 int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len);
 int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out);
+// raise a kernel's dynamic shared-memory limit once per context (= per device)
+inline void smem_opt_in(Ctx* c, const void* fn, size_t bytes) {
+  if (c->smem_opt_in.insert(fn).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 void ntt_plan(uint32_t L, int r[3], int* npass);
 
 // msm.hip

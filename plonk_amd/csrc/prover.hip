@@ -69,6 +69,7 @@ struct Prover {
   // multi-GPU: this rank owns SRS points [shard_lo, shard_lo + c->srs_n) of srs_total
   int rank = 0, world = 1;
   uint64_t srs_total = 0, shard_lo = 0;
+  uint64_t srs_gen = 0;            // Ctx::srs_gen at creation: the SRS this prover's degree checks / slices refer to
   plonk_allgather_fn allgather = nullptr;
   void* allgather_user = nullptr;
   Fr* ev_host = nullptr;           // pinned 16 Fr
@@ -180,15 +181,24 @@ static void prover_free(Prover* p) {
   delete p;
 }
 
+struct BuildGuard {   // every early return of prover_build releases what was allocated so far
+  Prover* p;
+  ~BuildGuard() { if (p) prover_free(p); }
+};
+
 static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   if (!d || d->constraints == 0) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (d->label_len && !d->label) return (plonk::set_last_error("invalid argument: label", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  for (int k = 0; k < P_COUNT; ++k)
+    if (d->poly_len[k] && !d->polys[k]) return (plonk::set_last_error("invalid argument: polys", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   Prover* p = new Prover();
+  BuildGuard guard{p};
   p->c = c;
   p->constraints = d->constraints;
   uint64_t n = 1;
   uint32_t L = 0;
   while (n < d->constraints) { n <<= 1; ++L; }   // constraints.next_power_of_two() (compiler.rs:141)
-  if (L + 3 >= 28) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
+  if (L + 3 >= 28) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   {
     const char* qd = getenv("PLONK_QUOTIENT_DOMAIN");
     const bool force8 = qd && qd[0] == '8';
@@ -199,21 +209,25 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   p->label.assign((const char*)d->label, d->label_len);
   p->world = d->shard_world > 1 ? d->shard_world : 1;
   p->rank = p->world > 1 ? d->shard_rank : 0;
-  if (p->rank < 0 || p->rank >= p->world) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
+  if (p->rank < 0 || p->rank >= p->world) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   p->srs_total = p->world > 1 ? d->srs_total : c->srs_n;
+  p->srs_gen = c->srs_gen;
   {
     const uint64_t per = (p->srs_total + p->world - 1) / p->world;   // contiguous point ranges
     p->shard_lo = per * (uint64_t)p->rank;
     const uint64_t hi = p->shard_lo + per < p->srs_total ? p->shard_lo + per : p->srs_total;
     const uint64_t want = hi > p->shard_lo ? hi - p->shard_lo : 0;
-    if (p->world > 1 && c->srs_n != want) { delete p; return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }   // ctx must hold exactly this rank's slice
+    if (p->world > 1 && c->srs_n != want) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // ctx must hold exactly this rank's slice
   }
   p->allgather = d->allgather;
   p->allgather_user = d->allgather_user;
-  if (p->world > 1) p->gather_host = (uint8_t*)malloc((size_t)p->world * 16 * sizeof(G1));
+  if (p->world > 1) {
+    p->gather_host = (uint8_t*)malloc((size_t)p->world * 16 * sizeof(G1));
+    if (!p->gather_host) return (plonk::set_last_error("malloc", "gather_host", __FILE__, __LINE__), PLONK_ERR_HIP);
+  }
   const uint64_t np = p->np, n8 = p->n8;
 #define ALLOC(ptr, count) do { hipError_t _e = hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)); \
-    if (_e != hipSuccess) { set_last_error("hipMalloc " #ptr, hipGetErrorString(_e), __FILE__, __LINE__); prover_free(p); return PLONK_ERR_HIP; } } while (0)
+    if (_e != hipSuccess) { set_last_error("hipMalloc " #ptr, hipGetErrorString(_e), __FILE__, __LINE__); return PLONK_ERR_HIP; } } while (0)
   ALLOC(p->polys, P_COUNT * np);
   ALLOC(p->evals8, (P_COUNT + 2) * n8);
   ALLOC(p->sigma_n, 4 * n);
@@ -251,7 +265,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   PTRY(poly_fill_zero(c, p->polys, P_COUNT * np));
   for (int k = 0; k < P_COUNT; ++k) {
     uint64_t len = d->poly_len[k];
-    if (len > n) { prover_free(p); return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG); }
+    if (len > n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
     if (len) HIP_TRY(hipMemcpyAsync(p->polys + k * np, d->polys[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c->stream));
     // Polynomial::from_coefficients_vec trim (polynomial.rs:79): highest non-zero coefficient
     const Fr* hp = (const Fr*)d->polys[k];
@@ -317,6 +331,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
     PTRY(fetch_commitments(p, 0, 15, p->vk));
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  guard.p = nullptr;
   *out = p;
   return PLONK_OK;
 }
@@ -324,6 +339,9 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
 static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
                         const Fr* bl, uint8_t proof[1008]) {
   Ctx* c = p->c;
+  // the commit key of the context was replaced after this prover was built (plonk_srs_load /
+  // plonk_prover_from_bytes): its degree bounds and shard ranges no longer describe the tables
+  if (p->srs_gen != c->srs_gen) return (set_last_error("prover is bound to an SRS that was replaced on its context", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
   const uint64_t n = p->n, n8 = p->n8, np = p->np;
   const uint32_t L = p->logn;
   NttTables* tbn;
@@ -574,11 +592,20 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   Fr pi_eval = Fr::zero();
   if (pi_count) {
     const Fr omega_inv = p->omega_inv;
-    Fr acc = Fr::zero();
+    // one shared inversion for all denominators (Montgomery's trick); a zero denominator means
+    // z is a root of unity (probability n/q) and contributes nothing, like the reference's skip
+    std::vector<Fr> den(pi_count), pre(pi_count);
+    Fr run = one;
     for (uint64_t i = 0; i < pi_count; ++i) {
-      if (pi_val[i].is_zero()) continue;
-      const Fr den = omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
-      acc = acc + den.inv() * pi_val[i];
+      den[i] = omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
+      pre[i] = run;
+      if (!pi_val[i].is_zero() && !den[i].is_zero()) run = run * den[i];
+    }
+    Fr inv = run.inv(), acc = Fr::zero();
+    for (uint64_t i = pi_count; i-- > 0;) {
+      if (pi_val[i].is_zero() || den[i].is_zero()) continue;
+      acc = acc + inv * pre[i] * pi_val[i];
+      inv = inv * den[i];
     }
     pi_eval = acc * (zh * n_inv);
   }

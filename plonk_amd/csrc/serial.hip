@@ -26,6 +26,7 @@
 
 #include "../../include/plonk_hip.h"
 #include "plonk_internal.hpp"
+#include "hostg1.hpp"
 
 namespace plonk {
 namespace {
@@ -225,6 +226,10 @@ int blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob_info* info) 
   // from `constraints`, so a blob where they differ is refused rather than proved differently)
   if (le64(blob + ck_off + ck_len) != constraints) FAIL(PLONK_ERR_DATA, "verifier_key.n != constraints");
   info->vk_off = ck_off + ck_len + 8;
+  // Commitment::from_reader x 15 (widget.rs:113-134): G1Affine::from_bytes refuses a non-canonical,
+  // off-curve or out-of-subgroup encoding with dusk_bytes::Error::InvalidData
+  for (int k = 0; k < 15; ++k)
+    if (!g1_compressed_valid(blob + info->vk_off + 48 * k)) FAIL(PLONK_ERR_DATA, "verifier key commitment is not a valid compressed G1 point");
   return PLONK_OK;
 }
 

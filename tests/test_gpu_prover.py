@@ -182,3 +182,24 @@ def test_unsatisfied_circuit_is_rejected(ctx):
     comp.witnesses[comp.constraints[7].c] = cols[2][7]
     with pytest.raises((ValueError, AssertionError)):
         O.prove(oprover, FixedBlinders(StdRng.seed_from_u64(1)), comp, msm=E.msm_pippenger)
+
+
+def test_prover_refuses_to_prove_after_its_srs_was_replaced(ctx):
+    """A prover is bound to the commit key its context held when it was built: replacing the SRS
+    (plonk_srs_load) makes older provers return PLONK_ERR_STATE instead of a silently invalid proof."""
+    import plonk_amd
+    pp = O.srs_setup(64, StdRng.seed_from_u64(6), keep=64)
+    build = arithmetic_circuit(20, 9, with_pi=False)
+    oprover = O.compile_circuit(pp, b"stale", build(), msm=E.msm_pippenger)
+    gp = gpu_prover(ctx, oprover)
+    cols = wires_of(build(), oprover.size)
+    first = gp.prove(cols, {}, list(range(1, 15)))
+    other = O.srs_setup(64, StdRng.seed_from_u64(7), keep=64)
+    ctx.srs_load(other)
+    with pytest.raises(plonk_amd.PlonkError) as ei:
+        gp.prove(cols, {}, list(range(1, 15)))
+    assert ei.value.code == -7
+    gp.close()
+    gp2 = gpu_prover(ctx, oprover)          # rebuilt on the original key: same proof again
+    assert gp2.prove(cols, {}, list(range(1, 15))) == first
+    gp2.close()

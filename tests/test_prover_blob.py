@@ -125,6 +125,43 @@ def test_commit_key_validation(blob):
         plonk_amd.prover_blob_check(_patch(blob, ck + 8, b"\xff" * 48))
 
 
+def test_verifier_key_commitments_are_decoded_like_the_reference(blob):
+    """Commitment::from_reader -> G1Affine::from_bytes (widget.rs:113-134): a non-canonical, off-curve or
+    out-of-subgroup commitment is dusk_bytes::Error::InvalidData, never transcript input."""
+    pk, ck, vk = _sections(blob)
+    first = vk + 8                                   # q_m commitment
+    plonk_amd.prover_blob_check(blob)
+    enc = bytearray(blob[first:first + 48])
+    with pytest.raises(plonk_amd.InvalidData):       # compression flag cleared
+        plonk_amd.prover_blob_check(_patch(blob, first, bytes([enc[0] & 0x7F]) + bytes(enc[1:])))
+    with pytest.raises(plonk_amd.InvalidData):       # x >= p
+        plonk_amd.prover_blob_check(_patch(blob, first, bytes([0x9F]) + b"\xff" * 47))
+    with pytest.raises(plonk_amd.InvalidData):       # infinity flag with a non-zero x
+        plonk_amd.prover_blob_check(_patch(blob, first, bytes([0xC0]) + b"\x00" * 46 + b"\x01"))
+    for x in range(1, 400):                          # an x whose x^3 + 4 is not a square: off the curve
+        rhs = (x * x * x + 4) % P
+        if pow(rhs, (P - 1) // 2, P) != 1:
+            break
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, first, bytes([0x80]) + x.to_bytes(47, "big")))
+    for x in range(5, 400):                          # on the curve, outside the prime-order subgroup
+        rhs = (x * x * x + 4) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P == rhs:
+            acc = E.JAC_ID
+            for bit in bin(Q)[2:]:
+                acc = E.jac_double(acc)
+                if bit == "1":
+                    acc = E.jac_add(acc, E.to_jac((x, y)))
+            if E.to_affine(acc) is not None:
+                break
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.prover_blob_check(_patch(blob, first, bytes([0x80]) + x.to_bytes(47, "big")))
+    # the identity (a zero selector polynomial commits to it) and either sign of a valid point pass
+    plonk_amd.prover_blob_check(_patch(blob, first, bytes([0xC0]) + bytes(47)))
+    plonk_amd.prover_blob_check(_patch(blob, first, bytes([enc[0] ^ 0x20]) + bytes(enc[1:])))
+
+
 @pytest.mark.gpu
 def test_from_bytes_reproduces_reference_kat_digest(blob, kat_setup):
     """The whole chain through the serialized form: reference-format blob -> device prover ->
