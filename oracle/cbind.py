@@ -47,7 +47,14 @@ def load() -> ctypes.CDLL:
     return lib
 
 
+def _threads(threads: int) -> int:
+    """0 = every core this process may use (cgroup quota / affinity), never the machine's full core count:
+    OpenMP's own default oversubscribes a quota-limited container by an order of magnitude."""
+    return threads if threads > 0 else max_threads()
+
+
 def ntt_bytes(data: bytes, log_n: int, inverse: bool, coset: bool, in_len: int, threads: int = 0) -> bytes:
+    threads = _threads(threads)
     n = 1 << log_n
     buf = ctypes.create_string_buffer(32 * n)
     ctypes.memmove(buf, data, min(len(data), 32 * n))
@@ -58,7 +65,7 @@ def ntt_bytes(data: bytes, log_n: int, inverse: bool, coset: bool, in_len: int, 
 
 def msm_bytes(points96: bytes, scalars_mont: bytes, m: int, threads: int = 0) -> bytes:
     out = ctypes.create_string_buffer(97)
-    rc = load().oracle_msm(points96, scalars_mont, m, out, threads)
+    rc = load().oracle_msm(points96, scalars_mont, m, out, _threads(threads))
     assert rc == 0
     return out.raw
 
@@ -82,7 +89,7 @@ def max_threads() -> int:
 def srs_generate(tau_mont: bytes, g_scalar_mont: bytes, n: int, threads: int = 0) -> bytes:
     """[g tau^i] G1 for i < n as n x 96 B raw points (PublicParameters::setup semantics, srs.rs:61-100)."""
     out = ctypes.create_string_buffer(96 * max(n, 1))
-    rc = load().oracle_srs_generate(tau_mont, g_scalar_mont, n, out, threads)
+    rc = load().oracle_srs_generate(tau_mont, g_scalar_mont, n, out, _threads(threads))
     assert rc == 0
     return out.raw[:96 * n]
 
@@ -116,7 +123,8 @@ class CProver:
         while n < constraints:
             n *= 2
         self.n = n
-        self.h = lib.oracle_prover_new(constraints, label, len(label), arr, lens, srs96, len(srs96) // 96, vk48, threads)
+        self.threads = _threads(threads)
+        self.h = lib.oracle_prover_new(constraints, label, len(label), arr, lens, srs96, len(srs96) // 96, vk48, self.threads)
         if not self.h:
             raise ValueError("oracle_prover_new failed (polynomial longer than the domain, or degree > SRS)")
 

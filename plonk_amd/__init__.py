@@ -270,6 +270,31 @@ class Context:
         self._check(self.lib.plonk_ntt(self.handle, buf, log_n, int(inverse), int(coset), in_len))
         return buf.raw
 
+    def ntt_batch_bytes(self, datas, log_n: int, inverse: bool, coset: bool, in_lens=None) -> list[bytes]:
+        """compute_coset_evaluations' fan-out (quotient_poly.rs:139-157) as one plonk_ntt_batch call."""
+        n = 1 << log_n
+        bufs = []
+        for d in datas:
+            b = ctypes.create_string_buffer(32 * n)
+            ctypes.memmove(b, d, min(len(d), 32 * n))
+            bufs.append(b)
+        arr = (ctypes.c_void_p * max(len(bufs), 1))(*[ctypes.cast(b, ctypes.c_void_p) for b in bufs])
+        lens = None
+        if in_lens is not None:
+            lens = (ctypes.c_uint64 * max(len(bufs), 1))(*in_lens)
+        self._check(self.lib.plonk_ntt_batch(self.handle, arr, len(bufs), log_n, int(inverse), int(coset), lens))
+        return [b.raw for b in bufs]
+
+    def msm_batch_bytes(self, scalar_sets) -> list[bytes]:
+        """commit_polynomials' fan-out (prover.rs:187-210) as one plonk_msm_batch call: list of
+        Montgomery scalar byte strings -> list of 97-byte raw results."""
+        keep = [ctypes.create_string_buffer(bytes(s), max(len(s), 1)) for s in scalar_sets]
+        arr = (ctypes.c_void_p * max(len(keep), 1))(*[ctypes.cast(b, ctypes.c_void_p) for b in keep])
+        ms = (ctypes.c_uint64 * max(len(keep), 1))(*[len(s) // 32 for s in scalar_sets])
+        out = ctypes.create_string_buffer(97 * max(len(keep), 1))
+        self._check(self.lib.plonk_msm_batch(self.handle, arr, ms, len(keep), out))
+        return [out.raw[97 * i:97 * i + 97] for i in range(len(keep))]
+
     def ntt(self, values: Sequence[int], log_n: int, inverse: bool = False, coset: bool = False) -> list[int]:
         """fft / ifft / coset_fft / coset_ifft on Python ints: zero-pads or truncates to
         2^log_n exactly like Vec::resize at reference domain.rs:174."""

@@ -2,9 +2,12 @@
 // reference interfaces each entry point replaces).
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <string>
+#include <thread>
 
 #include "plonk_internal.hpp"
+#include "hostg1.hpp"
 
 namespace plonk {
 
@@ -86,8 +89,13 @@ static int prof_collect(Ctx* c) {
 
 static int ensure_ntt_staging(Ctx* c, uint64_t n) {
   if (n <= c->ntt_cap) return PLONK_OK;
-  if (c->ntt_buf) { HIP_TRY(hipFree(c->ntt_buf)); HIP_TRY(hipFree(c->ntt_tmp)); c->ntt_buf = c->ntt_tmp = nullptr; c->ntt_cap = 0; }
+  if (c->ntt_buf) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(c->ntt_buf)); HIP_TRY(hipFree(c->ntt_buf2)); HIP_TRY(hipFree(c->ntt_tmp));
+    c->ntt_buf = c->ntt_buf2 = c->ntt_tmp = nullptr; c->ntt_cap = 0;
+  }
   HIP_TRY(hipMalloc((void**)&c->ntt_buf, sizeof(Fr) * n));
+  HIP_TRY(hipMalloc((void**)&c->ntt_buf2, sizeof(Fr) * n));
   HIP_TRY(hipMalloc((void**)&c->ntt_tmp, sizeof(Fr) * n));
   c->ntt_cap = n;
   return PLONK_OK;
@@ -149,10 +157,11 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
     (void)hipFree(t->w512_29); (void)hipFree(t->g_lo29); (void)hipFree(t->g_hi29);
     delete t;
   }
-  (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_tmp); (void)hipFree(c.srs_table);
+  (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_buf2); (void)hipFree(c.ntt_tmp);
+  if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream); (void)hipFree(c.srs_table);
   MsmWork& w = c.msm;
-  (void)hipFree(w.digits); (void)hipFree(w.entries); (void)hipFree(w.keys_out); (void)hipFree(w.vals_in); (void)hipFree(w.sort_tmp); (void)hipFree(w.counts); (void)hipFree(w.offsets);
-  (void)hipFree(w.cursors); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
+  (void)hipFree(w.tmp_words); (void)hipFree(w.entries); (void)hipFree(w.coarse_cnt); (void)hipFree(w.coarse_off); (void)hipFree(w.coarse_cur);
+  (void)hipFree(w.offsets); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
   (void)hipFree(w.chunk); (void)hipFree(w.result); (void)hipFree(w.scalars_stage);
   if (w.result_host) (void)hipHostFree(w.result_host);
   (void)hipStreamDestroy(c.main_stream);
@@ -231,14 +240,68 @@ int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int cose
   return PLONK_OK;
 }
 
+// The 5-way fan-out of compute_coset_evaluations (quotient_poly.rs:139-157) / the 4 wire iFFTs
+// (prover.rs:464) as ONE call: the transforms of a batch are pipelined over two device buffers —
+// an uploader thread feeds buffer k+1 over the copy stream while the main stream transforms and
+// downloads buffer k, so both PCIe directions are busy instead of strictly alternating.
 int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_n, int inverse, int coset,
                     const uint64_t* in_len) {
-  if (!ctx || !a || count < 0) return PLONK_ERR_ARG;
-  for (int i = 0; i < count; ++i) {
-    int rc = plonk_ntt(ctx, a[i], log_n, inverse, coset, in_len ? in_len[i] : (1ull << log_n));
-    if (rc) return rc;
+  if (!ctx || !a || count < 0 || log_n >= 28) return PLONK_ERR_ARG;
+  for (int i = 0; i < count; ++i) if (!a[i]) return PLONK_ERR_ARG;
+  if (count == 0) return PLONK_OK;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  const uint64_t n = 1ull << log_n;
+  int rc = ensure_ntt_staging(&c, n);
+  if (rc) return rc;
+  if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+  Fr* buf[2] = {c.ntt_buf, c.ntt_buf2};
+  std::mutex mu;
+  std::condition_variable cv;
+  int uploaded = 0, released = 0;     // transforms whose input is on the device / whose buffer is free again
+  int up_rc = PLONK_OK;
+  bool abort = false;
+  std::thread uploader([&] {
+    if (hipSetDevice(c.device) != hipSuccess) { std::lock_guard<std::mutex> g(mu); up_rc = PLONK_ERR_HIP; cv.notify_all(); return; }
+    for (int k = 0; k < count; ++k) {
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return abort || released >= k - 1; });   // buffer k % 2 was last used by transform k - 2
+        if (abort) return;
+      }
+      uint64_t len = in_len ? in_len[k] : n;
+      if (len > n) len = n;
+      hipError_t e = hipMemcpyAsync(buf[k & 1], a[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c.copy_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c.copy_stream);
+      std::lock_guard<std::mutex> g(mu);
+      if (e != hipSuccess) { up_rc = PLONK_ERR_HIP; cv.notify_all(); return; }
+      uploaded = k + 1;
+      cv.notify_all();
+    }
+  });
+  for (int k = 0; k < count && rc == PLONK_OK; ++k) {
+    {
+      std::unique_lock<std::mutex> g(mu);
+      cv.wait(g, [&] { return up_rc != PLONK_OK || uploaded > k; });
+      if (up_rc != PLONK_OK) { rc = up_rc; break; }
+    }
+    uint64_t len = in_len ? in_len[k] : n;
+    if (len > n) len = n;
+    rc = ntt_device(&c, buf[k & 1], buf[k & 1], c.ntt_tmp, log_n, inverse != 0, coset != 0, len);
+    if (rc == PLONK_OK && hipMemcpyAsync(a[k], buf[k & 1], sizeof(Fr) * n, hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+    if (rc == PLONK_OK && hipStreamSynchronize(c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+    std::lock_guard<std::mutex> g(mu);
+    released = k + 1;
+    cv.notify_all();
   }
-  return PLONK_OK;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (rc != PLONK_OK) abort = true;
+    cv.notify_all();
+  }
+  uploader.join();
+  return rc;
 }
 
 // ---- SRS / MSM ---------------------------------------------------------------------
@@ -330,11 +393,45 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
   return PLONK_OK;
 }
 
+// Prover::commit_polynomials' 4-way rayon::join fan-out (prover.rs:187-210) as ONE call: up to
+// MSM_MAX_BATCH scalar sets over the shared commit key go through the pipeline as one group (one
+// launch of every kernel, one latency-bound reduction tail), the 16 bit sums per commitment come back
+// in one copy and the host finishes them with one shared Fp inversion.
 int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64_t* m, int count, uint8_t* out) {
   if (!ctx || !scalars || !m || !out || count < 0) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  uint64_t mmax = 0;
   for (int i = 0; i < count; ++i) {
-    int rc = plonk_msm(ctx, scalars[i], m[i], out + 97 * (size_t)i);
+    if (!scalars[i] && m[i]) return PLONK_ERR_ARG;
+    if (m[i] && !c.srs_table) return PLONK_ERR_NO_SRS;
+    if (m[i] > c.srs_n) return PLONK_ERR_DEGREE;
+    if (m[i] > mmax) mmax = m[i];
+  }
+  int rc = msm_reserve(&c, mmax ? mmax : 1);
+  if (rc) return rc;
+  rc = ensure_scalar_staging(&c, (mmax ? mmax : 1) * MSM_MAX_BATCH);
+  if (rc) return rc;
+  for (int k0 = 0; k0 < count; k0 += MSM_MAX_BATCH) {
+    const int cnt = count - k0 < MSM_MAX_BATCH ? count - k0 : MSM_MAX_BATCH;
+    const Fr* sc[MSM_MAX_BATCH];
+    uint64_t ms[MSM_MAX_BATCH];
+    G1* res[MSM_MAX_BATCH];
+    for (int k = 0; k < cnt; ++k) {
+      Fr* dst = c.msm.scalars_stage + (uint64_t)k * (mmax ? mmax : 1);
+      HIP_TRY(hipMemcpyAsync(dst, scalars[k0 + k], sizeof(Fr) * m[k0 + k], hipMemcpyHostToDevice, c.stream));
+      sc[k] = dst;
+      ms[k] = m[k0 + k];
+      res[k] = (G1*)c.msm.result + (size_t)k * MSM_BIT_SUMS;
+    }
+    rc = msm_batch_device(&c, sc, ms, cnt, res, true);
     if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, sizeof(G1) * MSM_BIT_SUMS * cnt, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    G1 sums[MSM_MAX_BATCH];
+    for (int k = 0; k < cnt; ++k) sums[k] = finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host) + (size_t)k * MSM_BIT_SUMS);
+    batch_xyzz_to_affine97(sums, cnt, reinterpret_cast<uint8_t (*)[97]>(out + 97 * (size_t)k0));
   }
   return PLONK_OK;
 }

@@ -9,12 +9,10 @@
 //     (16 x 96 B per SRS point; 1.5 GiB at 2^20 points).  All windows then share
 //     ONE set of 2^15 signed-digit buckets, so there is no per-window bucket
 //     reduction and no Horner doubling chain at the end.
-//   * msm_digits   : scalars -> canonical form -> 16 signed 16-bit digits, emitted as
-//                    (bucket, table index | sign) pairs.
-//   * radix sort   : pairs grouped by bucket (rocPRIM, msm_sort.hip).
-//   * msm_counts / msm_scan : bucket sizes by binary search in the sorted keys, exclusive
-//                    scans -> bucket offsets and slice offsets (a slice = at most MSM_KSL
-//                    entries of one bucket).
+//   * bucket grouping (msm_sort.hip): scalars -> 16 signed 16-bit digits -> table entries
+//                    (index | sign) grouped by bucket with a hand-written two-level counting
+//                    sort; bucket offsets and slice offsets (a slice = at most MSM_KSL entries
+//                    of one bucket) fall out of it.
 //   * msm_accumulate (dominant): one lane per slice; gathers affine table points
 //                    (128-byte entries, one cache line each) and folds them into an
 //                    XYZZ accumulator.  Field arithmetic is the reduced-radix, lazily
@@ -30,14 +28,6 @@
 
 namespace plonk {
 
-struct MsmBatch {
-  const Fr* scalars[MSM_MAX_BATCH];
-  uint64_t m[MSM_MAX_BATCH];
-  G1* out[MSM_MAX_BATCH];
-  int count;
-  uint32_t ksl;   // entries per slice of this launch
-  uint64_t cap_m, cap_slices;
-};
 
 static constexpr uint32_t MSM_KSL = 32;   // entries per slice for m >= 2^20 (msm_ksl: shorter slices keep ~2^19 lanes busy for smaller m)
 static constexpr uint32_t MSM_CHUNK = 16; // buckets per chunk in the weighted reduction
@@ -185,106 +175,6 @@ __global__ void srs_generate_kernel(Fr tau, Fr g_scalar, uint64_t n, G1Affine* _
   G1Affine a;
   acc.to_affine(&a);
   st_aff(out + i, a);
-}
-
-// ---------------------------------------------------------------------------
-// digits, histogram, scatter
-// ---------------------------------------------------------------------------
-// Emits one (key, value) pair per window: key = bucket index |d| - 1 (MSM_NB for a zero
-// digit, which sorts behind every real bucket), value = (w * srs_n + i) | sign << 31.
-// Pair index = w * m + i.
-__global__ void msm_digits_kernel(MsmBatch bt, uint64_t srs_n, uint16_t* __restrict__ keys_all,
-                                  uint32_t* __restrict__ vals_all) {
-  const int kb = blockIdx.y;
-  const uint64_t m = bt.m[kb];
-  const Fr* __restrict__ scalars = bt.scalars[kb];
-  uint16_t* __restrict__ keys = keys_all + (uint64_t)kb * MSM_W * bt.cap_m;   // 0..MSM_NB fits 16 bits: 25 % less sort traffic
-  uint32_t* __restrict__ vals = vals_all + (uint64_t)kb * MSM_W * bt.cap_m;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  // out of Montgomery form in reduced radix: (x * 2^256) * 32 / 2^261 = x, then exact canonicalisation
-  Fr29 c32 = Fr29::zero();
-  c32.l[0] = 32;
-  const Fr s = Fr29::mul(Fr29::from_fr(ld_fr_g(scalars + i)), c32).to_fr();
-  uint32_t carry = 0;
-#pragma unroll
-  for (int w = 0; w < MSM_W; ++w) {
-    const uint32_t raw = (s.l[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-    const uint32_t v = raw + carry;
-    uint32_t key = MSM_NB, sign = 0;
-    carry = 0;
-    if (v > MSM_NB) {          // negative digit d = v - 65536
-      carry = 1;
-      const uint32_t mag = 65536u - v;
-      if (mag) { key = mag - 1; sign = 0x80000000u; }
-    } else if (v) {
-      key = v - 1;
-    }
-    keys[(uint64_t)w * m + i] = (uint16_t)key;
-    vals[(uint64_t)w * m + i] = (uint32_t)((uint64_t)w * srs_n + i) | sign;
-  }
-}
-
-// counts[b] = number of sorted keys equal to b (binary searches in the sorted key array)
-__global__ void msm_counts_kernel(MsmBatch bt, const uint16_t* __restrict__ keys_sorted_all,
-                                  uint32_t* __restrict__ counts_all) {
-  const int kb = blockIdx.y;
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= MSM_NB) return;
-  const uint16_t* __restrict__ keys = keys_sorted_all + (uint64_t)kb * MSM_W * bt.cap_m;
-  const uint64_t n = (uint64_t)MSM_W * bt.m[kb];
-  uint64_t lo0 = 0, hi0 = n;           // first index with key >= b
-  while (lo0 < hi0) { const uint64_t mid = (lo0 + hi0) >> 1; if (keys[mid] < b) lo0 = mid + 1; else hi0 = mid; }
-  uint64_t lo1 = lo0, hi1 = n;         // first index with key >= b + 1
-  while (lo1 < hi1) { const uint64_t mid = (lo1 + hi1) >> 1; if (keys[mid] < b + 1) lo1 = mid + 1; else hi1 = mid; }
-  counts_all[(uint64_t)kb * MSM_NB + b] = (uint32_t)(lo1 - lo0);
-}
-
-// exclusive scans over NB entries, single workgroup of 1024 threads:
-//   offsets[b]   = sum_{b' < b} counts[b']
-//   slice_off[b] = sum_{b' < b} ceil(counts[b'] / KSL)
-__global__ void __launch_bounds__(1024) msm_scan_kernel(const uint32_t* __restrict__ counts_all,
-                                                        uint32_t* __restrict__ offsets_all,
-                                                        uint32_t* __restrict__ slice_off_all,
-                                                        uint32_t* __restrict__ cursors_all, uint32_t ksl) {
-  const uint32_t* __restrict__ counts = counts_all + (uint64_t)blockIdx.x * MSM_NB;
-  uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
-  uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
-  uint32_t* __restrict__ cursors = cursors_all + (uint64_t)blockIdx.x * MSM_NB;
-  __shared__ uint32_t sa[1024], sb[1024];
-  constexpr uint32_t PER = MSM_NB / 1024;
-  const uint32_t t = threadIdx.x;
-  uint32_t a = 0, b = 0;
-  for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t c = counts[t * PER + k];
-    a += c;
-    b += (c + ksl - 1) / ksl;
-  }
-  sa[t] = a;
-  sb[t] = b;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t xa = 0, xb = 0;
-    if (t >= d) { xa = sa[t - d]; xb = sb[t - d]; }
-    __syncthreads();
-    sa[t] += xa;
-    sb[t] += xb;
-    __syncthreads();
-  }
-  uint32_t ra = sa[t] - a, rb = sb[t] - b;   // exclusive prefix of this thread's chunk
-  for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t idx = t * PER + k;
-    const uint32_t c = counts[idx];
-    offsets[idx] = ra;
-    slice_off[idx] = rb;
-    cursors[idx] = 0;
-    ra += c;
-    rb += (c + ksl - 1) / ksl;
-  }
-  if (t == 1023) {
-    offsets[MSM_NB] = ra;
-    slice_off[MSM_NB] = rb;
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -585,15 +475,14 @@ static uint64_t msm_slice_cap(uint64_t cap) {
 int msm_reserve(Ctx* c, uint64_t m) {
   MsmWork& w = c->msm;
   constexpr int KB = MSM_MAX_BATCH;
-  if (!w.counts) {
-    HIP_TRY(hipMalloc((void**)&w.counts, sizeof(uint32_t) * MSM_NB * KB));
+  if (!w.offsets) {
     HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1) * KB));
-    HIP_TRY(hipMalloc((void**)&w.cursors, sizeof(uint32_t) * MSM_NB * KB));
     HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
+    { const int rc_s = msm_sort_reserve_fixed(c); if (rc_s) return rc_s; }
     HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB * KB));
     HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK) * KB));
-    HIP_TRY(hipMalloc((void**)&w.result, 256));
-    HIP_TRY(hipHostMalloc((void**)&w.result_host, 256, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&w.result, sizeof(G1) * MSM_BIT_SUMS * KB));          // one point, or 16 bit sums per commitment of a group
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(G1) * MSM_BIT_SUMS * KB, hipHostMallocDefault));
   }
   if (m > w.cap_m) {
     const uint64_t cap = m;
@@ -601,16 +490,11 @@ int msm_reserve(Ctx* c, uint64_t m) {
     // that a failed reallocation cannot leave a stale cap_m pointing at freed memory
     HIP_TRY(hipStreamSynchronize(c->stream));
     w.cap_m = 0;
-    for (void** q : {(void**)&w.digits, (void**)&w.entries, (void**)&w.partial, (void**)&w.keys_out, (void**)&w.vals_in, &w.sort_tmp}) {
+    for (void** q : {(void**)&w.tmp_words, (void**)&w.entries, (void**)&w.partial}) {
       if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     }
-    HIP_TRY(hipMalloc((void**)&w.digits, sizeof(uint16_t) * MSM_W * cap * KB));     // keys, unsorted
-    HIP_TRY(hipMalloc((void**)&w.keys_out, sizeof(uint16_t) * MSM_W * cap * KB));   // keys, sorted
-    HIP_TRY(hipMalloc((void**)&w.vals_in, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, unsorted
-    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries, grouped by bucket
-    int rc_t = msm_sort_temp_bytes((size_t)MSM_W * cap, &w.sort_tmp_bytes);
-    if (rc_t) return rc_t;
-    HIP_TRY(hipMalloc((void**)&w.sort_tmp, w.sort_tmp_bytes));
+    HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint32_t) * MSM_W * cap * KB));  // words grouped by coarse bin
+    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
     w.cap_slices = msm_slice_cap(cap);
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
     w.cap_m = cap;
@@ -650,18 +534,9 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   bt.cap_slices = w.cap_slices;
   for (int k = 0; k < count; ++k) { bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k]; }
   prof_begin(c, 2);
-  const uint32_t gb = (uint32_t)((mmax + 255) / 256);
-  hipLaunchKernelGGL(msm_digits_kernel, dim3(gb, count), dim3(256), 0, st, bt, c->srs_n, w.digits, w.vals_in);
-  for (int k = 0; k < count; ++k) {
-    if (!m[k]) continue;
-    const uint64_t off = (uint64_t)k * MSM_W * w.cap_m;
-    rc = msm_sort_pairs(c, w.sort_tmp, w.sort_tmp_bytes, w.digits + off, w.keys_out + off, w.vals_in + off,
-                        w.entries + off, (size_t)MSM_W * m[k]);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(msm_counts_kernel, dim3(MSM_NB / 256, count), dim3(256), 0, st, bt, w.keys_out, w.counts);
-  hipLaunchKernelGGL(msm_scan_kernel, dim3(count), dim3(1024), 0, st, w.counts, w.offsets, w.slice_off, w.cursors, bt.ksl);
+  rc = msm_group_sort(c, bt, mmax);
   prof_end(c, 2);
+  if (rc) return rc;
   // upper bound on slices known on the host: no device->host sync on the path
   const uint64_t max_slices = (MSM_W * mmax) / bt.ksl + MSM_NB + 1;
   prof_begin(c, 1);

@@ -1,26 +1,297 @@
-// Bucket grouping for the MSM: sort (bucket, table-entry) pairs by bucket with rocPRIM's
-// radix sort (16-bit keys -> two 8-bit passes; 0.31 ms for 16.8 M pairs on MI355X versus
-// 1.5 ms for a global-atomic histogram + scatter).  Kept in its own translation unit: the
-// rocPRIM templates are the slowest thing to compile in the library.
-#include <cstring>
-#include <string.h>
-
-#include <rocprim/rocprim.hpp>
-
+// Bucket grouping for the Pippenger MSM (msm.hip): from the scalars of a commitment group straight to
+// table entries grouped by bucket — a hand-written two-level counting sort for gfx950, no library
+// primitive.  Order inside a bucket is irrelevant to a sum, which is what makes this cheaper than a
+// general (stable) radix sort:
+//
+//   msm_hist_kernel       scalars -> signed 16-bit digits -> histogram of the COARSE bin (top 11 of the
+//                         15 bucket bits) in LDS, flushed with one global atomic per (workgroup, bin).
+//                         Zero digits are dropped here and never touched again.
+//   msm_coarse_scan       2048 counts -> coarse offsets (one workgroup per commitment).
+//   msm_partition_kernel  scalars again (32 B per term instead of a 6-byte key/value pair per window):
+//                         a workgroup owns a tile of 2048 scalars = 32768 entries, ranks them per coarse
+//                         bin with LDS atomics, reserves its run in every bin with one global atomic,
+//                         regroups the tile in LDS (128 KiB of the CU's 160 KiB) and writes runs of
+//                         ~16 consecutive 4-byte words.  The word carries what the second level needs:
+//                         fine bucket (4 bits) | sign | table index (27 bits).
+//   msm_fine_kernel       one workgroup per coarse bin (~8192 entries, L2-resident): histogram of the
+//                         16 fine buckets, then scatter into the final entry array; writes the bucket
+//                         offsets on the way, so no pass over 32768 counters is needed for them.
+//   msm_slices_kernel     bucket offsets -> slice offsets (prefix sum of ceil(count / KSL)).
+//
+// HBM traffic per commitment of m terms: 2 x 32m (scalars, read twice) + 64m written and read back
+// (coarse-partitioned words) + 64m written (entries) = 256m bytes, against 560m for digits + key/value
+// pairs + a two-pass onesweep.  A bucket that attracts a large share of the digits (equal
+// coefficients) only makes one workgroup loop longer; nothing overflows.
 #include "plonk_internal.hpp"
+#include "fr29.cuh"
 
 namespace plonk {
 
-int msm_sort_temp_bytes(size_t n, size_t* bytes) {
-  uint16_t* knul = nullptr;
-  uint32_t* nul = nullptr;
-  HIP_TRY(rocprim::radix_sort_pairs(nullptr, *bytes, knul, knul, nul, nul, n, 0, 16));
+static constexpr uint32_t FINE_BITS = 4;
+static constexpr uint32_t COARSE = MSM_NB >> FINE_BITS;          // 2048 coarse bins
+static constexpr uint32_t TILE = 2048;                           // scalars per workgroup (hist / partition)
+static constexpr uint32_t SORT_T = 1024;                         // threads per workgroup
+static constexpr uint32_t PER_T = TILE / SORT_T;                 // scalars per thread
+static constexpr uint32_t IDX_BITS = 27;                         // table index field of the intermediate word
+static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
+static_assert(COARSE == 2 * SORT_T, "scan / reservation loops assume two coarse bins per thread");
+static_assert(IDX_BITS + 1 + FINE_BITS == 32, "intermediate word layout");
+
+__device__ __forceinline__ Fr ld_scalar(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+
+// Montgomery scalar -> canonical integer: (x * 2^256) * 32 / 2^261 = x in reduced radix, exact canonicalisation
+__device__ __forceinline__ Fr scalar_canonical(const Fr& mont) {
+  Fr29 c32 = Fr29::zero();
+  c32.l[0] = 32;
+  return Fr29::mul(Fr29::from_fr(mont), c32).to_fr();
+}
+
+// Signed 16-bit recoding, least significant window first.  f(w, bucket, sign) is called for every
+// NON-ZERO digit: bucket = |d| - 1 in [0, MSM_NB), sign = 1 for a negative digit.
+template <class F>
+__device__ __forceinline__ void for_each_digit(const Fr& s, F&& f) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < MSM_W; ++w) {
+    const uint32_t raw = (s.l[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+    const uint32_t v = raw + carry;
+    carry = 0;
+    if (v > MSM_NB) {            // negative digit d = v - 65536
+      carry = 1;
+      const uint32_t mag = 65536u - v;
+      if (mag) f(w, mag - 1, 1u);
+    } else if (v) {
+      f(w, v - 1, 0u);
+    }
+  }
+}
+
+// ---- level 1a: coarse histogram -------------------------------------------------------------------
+__global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t* __restrict__ coarse_cnt_all) {
+  __shared__ uint32_t hist[COARSE];
+  const int kb = blockIdx.y;
+  const uint64_t m = bt.m[kb];
+  const uint64_t base = (uint64_t)blockIdx.x * TILE;
+  if (base >= m) return;
+  const uint32_t t = threadIdx.x;
+  hist[t] = 0;
+  hist[t + SORT_T] = 0;
+  __syncthreads();
+  const Fr* __restrict__ scalars = bt.scalars[kb];
+#pragma unroll
+  for (uint32_t k = 0; k < PER_T; ++k) {
+    const uint64_t i = base + t + (uint64_t)k * SORT_T;
+    if (i < m) {
+      const Fr s = scalar_canonical(ld_scalar(scalars + i));
+      for_each_digit(s, [&](int, uint32_t bucket, uint32_t) { atomicAdd(&hist[bucket >> FINE_BITS], 1u); });
+    }
+  }
+  __syncthreads();
+  uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)kb * COARSE;
+  const uint32_t a = hist[t], b = hist[t + SORT_T];
+  if (a) atomicAdd(&cnt[t], a);
+  if (b) atomicAdd(&cnt[t + SORT_T], b);
+}
+
+// exclusive scan of `v` over the SORT_T threads of a workgroup (Hillis-Steele in LDS); returns the
+// exclusive prefix of this thread's value, *total = sum of all
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* sh /* SORT_T */, uint32_t* total) {
+  const uint32_t t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < SORT_T; d <<= 1) {
+    const uint32_t x = t >= d ? sh[t - d] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  const uint32_t incl = sh[t];
+  *total = sh[SORT_T - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+// ---- level 1b: coarse offsets; also clears the run cursors of the partition pass ------------------
+__global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t* __restrict__ coarse_cnt_all,
+                                                                 uint32_t* __restrict__ coarse_off_all,
+                                                                 uint32_t* __restrict__ coarse_cur_all) {
+  __shared__ uint32_t sh[SORT_T];
+  const uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)blockIdx.x * COARSE;
+  uint32_t* __restrict__ off = coarse_off_all + (uint64_t)blockIdx.x * (COARSE + 1);
+  uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)blockIdx.x * COARSE;
+  const uint32_t t = threadIdx.x;
+  const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
+  uint32_t total;
+  const uint32_t ex = block_exclusive_scan(c0 + c1, sh, &total);
+  off[2 * t] = ex;
+  off[2 * t + 1] = ex + c0;
+  cur[2 * t] = 0;
+  cur[2 * t + 1] = 0;
+  if (t == SORT_T - 1) off[COARSE] = total;
+}
+
+// ---- level 1c: partition into the coarse bins -----------------------------------------------------
+// dynamic LDS: stage[TILE * MSM_W] words, then hist / loff / gbase [COARSE] each
+static constexpr size_t PARTITION_LDS = ((size_t)TILE * MSM_W + 3 * COARSE) * sizeof(uint32_t);
+
+__global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint64_t srs_n,
+                                                               const uint32_t* __restrict__ coarse_off_all,
+                                                               uint32_t* __restrict__ coarse_cur_all,
+                                                               uint32_t* __restrict__ tmp_all) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* stage = lds;                          // TILE * MSM_W
+  uint32_t* hist = lds + TILE * MSM_W;            // COARSE: entries of this tile per bin
+  uint32_t* loff = hist + COARSE;                 // COARSE: start of the bin's run inside `stage`
+  uint32_t* gbase = loff + COARSE;                // COARSE: start of the run in the global array
+  __shared__ uint32_t sh[SORT_T];
+  const int kb = blockIdx.y;
+  const uint64_t m = bt.m[kb];
+  const uint64_t base = (uint64_t)blockIdx.x * TILE;
+  if (base >= m) return;
+  const uint32_t t = threadIdx.x;
+  hist[t] = 0;
+  hist[t + SORT_T] = 0;
+  __syncthreads();
+  const Fr* __restrict__ scalars = bt.scalars[kb];
+  // words and (bin << 16 | rank) of this thread's entries stay in registers until the runs are known
+  uint32_t word[PER_T][MSM_W], where[PER_T][MSM_W];
+#pragma unroll
+  for (uint32_t k = 0; k < PER_T; ++k) {
+#pragma unroll
+    for (int w = 0; w < MSM_W; ++w) where[k][w] = 0xffffffffu;
+    const uint64_t i = base + t + (uint64_t)k * SORT_T;
+    if (i < m) {
+      const Fr s = scalar_canonical(ld_scalar(scalars + i));
+      for_each_digit(s, [&](int w, uint32_t bucket, uint32_t sign) {
+        const uint32_t bin = bucket >> FINE_BITS;
+        const uint32_t rank = atomicAdd(&hist[bin], 1u);          // < TILE * MSM_W = 2^15
+        where[k][w] = (bin << 16) | rank;
+        word[k][w] = ((bucket & ((1u << FINE_BITS) - 1)) << (IDX_BITS + 1)) | (sign << IDX_BITS) |
+                     (uint32_t)((uint64_t)w * srs_n + i);
+      });
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(c0 + c1, sh, &total);
+    loff[2 * t] = ex;
+    loff[2 * t + 1] = ex + c0;
+    const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
+    uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)kb * COARSE;
+    gbase[2 * t] = c0 ? coff[2 * t] + atomicAdd(&cur[2 * t], c0) : 0;
+    gbase[2 * t + 1] = c1 ? coff[2 * t + 1] + atomicAdd(&cur[2 * t + 1], c1) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < PER_T; ++k)
+#pragma unroll
+    for (int w = 0; w < MSM_W; ++w)
+      if (where[k][w] != 0xffffffffu) stage[loff[where[k][w] >> 16] + (where[k][w] & 0xffffu)] = word[k][w];
+  __syncthreads();
+  // write the runs: 16 lanes per bin, 64 bins per sweep of the workgroup
+  uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint32_t sub = t & 15;
+  for (uint32_t bin = t >> 4; bin < COARSE; bin += SORT_T / 16) {
+    const uint32_t cnt = hist[bin], lo = loff[bin], gb = gbase[bin];
+    for (uint32_t j = sub; j < cnt; j += 16) tmp[gb + j] = stage[lo + j];
+  }
+}
+
+// ---- level 2: fine buckets inside a coarse bin ----------------------------------------------------
+static constexpr uint32_t FINE_T = 256;
+__global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
+                                                          const uint32_t* __restrict__ tmp_all,
+                                                          uint32_t* __restrict__ entries_all,
+                                                          uint32_t* __restrict__ offsets_all) {
+  __shared__ uint32_t cnt[1u << FINE_BITS], start[1u << FINE_BITS], cur[1u << FINE_BITS];
+  const int kb = blockIdx.y;
+  const uint32_t bin = blockIdx.x, t = threadIdx.x;
+  const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
+  const uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t beg = coff[bin], end = coff[bin + 1];
+  if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
+  __syncthreads();
+  for (uint32_t j = beg + t; j < end; j += FINE_T) atomicAdd(&cnt[tmp[j] >> (IDX_BITS + 1)], 1u);
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = beg;
+    for (uint32_t f = 0; f < (1u << FINE_BITS); ++f) {
+      start[f] = run;
+      offsets[(bin << FINE_BITS) + f] = run;
+      run += cnt[f];
+    }
+    if (bin == COARSE - 1) offsets[MSM_NB] = run;
+  }
+  __syncthreads();
+  for (uint32_t j = beg + t; j < end; j += FINE_T) {
+    const uint32_t e = tmp[j];
+    const uint32_t f = e >> (IDX_BITS + 1);
+    const uint32_t pos = start[f] + atomicAdd(&cur[f], 1u);
+    entries[pos] = (e & IDX_MASK) | (((e >> IDX_BITS) & 1u) << 31);   // accumulate's format: index | sign << 31
+  }
+}
+
+// ---- slice offsets: slice_off[b] = sum_{b' < b} ceil(count[b'] / ksl), one workgroup per commitment
+__global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __restrict__ offsets_all,
+                                                            uint32_t* __restrict__ slice_off_all, uint32_t ksl) {
+  __shared__ uint32_t sh[SORT_T];
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  constexpr uint32_t PER = MSM_NB / SORT_T;
+  const uint32_t t = threadIdx.x;
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
+    mine += (c + ksl - 1) / ksl;
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(mine, sh, &total);
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
+    slice_off[t * PER + k] = run;
+    run += (c + ksl - 1) / ksl;
+  }
+  if (t == SORT_T - 1) slice_off[MSM_NB] = total;
+}
+
+// Host side: everything between the scalars and msm_accumulate for one commitment group.
+int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
+  MsmWork& w = c->msm;
+  hipStream_t st = c->stream;
+  // intermediate word: 27-bit table index (MSM_W * srs_n entries)
+  if ((uint64_t)MSM_W * c->srs_n > (uint64_t)IDX_MASK + 1)
+    return (set_last_error("commit key too large for the bucket sort", "MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
+  const uint32_t tiles = (uint32_t)((mmax + TILE - 1) / TILE);
+  HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
+  hipLaunchKernelGGL(msm_hist_kernel, dim3(tiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
+  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur);
+  smem_opt_in(c, (const void*)msm_partition_kernel, PARTITION_LDS);
+  hipLaunchKernelGGL(msm_partition_kernel, dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, c->srs_n,
+                     w.coarse_off, w.coarse_cur, w.tmp_words);
+  hipLaunchKernelGGL(msm_fine_kernel, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, w.tmp_words,
+                     w.entries, w.offsets);
+  hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl);
+  HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
 
-int msm_sort_pairs(Ctx* c, void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
-                   const uint32_t* vals_in, uint32_t* vals_out, size_t n) {
-  HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 16, c->stream));
+int msm_sort_reserve_fixed(Ctx* c) {
+  MsmWork& w = c->msm;
+  constexpr int KB = MSM_MAX_BATCH;
+  HIP_TRY(hipMalloc((void**)&w.coarse_cnt, sizeof(uint32_t) * COARSE * KB));
+  HIP_TRY(hipMalloc((void**)&w.coarse_off, sizeof(uint32_t) * (COARSE + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.coarse_cur, sizeof(uint32_t) * COARSE * KB));
   return PLONK_OK;
 }
 

@@ -47,25 +47,31 @@ static constexpr int MSM_W = 16;
 static constexpr uint32_t MSM_NB = 1u << (MSM_C - 1);   // buckets 1..32768
 static constexpr int MSM_MAX_BATCH = 4;                  // commitments per group launch
 
-struct MsmWork {   // per-stream scratch, grown on demand
+struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the same bases, launched together
+  const Fr* scalars[MSM_MAX_BATCH];
+  uint64_t m[MSM_MAX_BATCH];
+  G1* out[MSM_MAX_BATCH];
+  int count;
+  uint32_t ksl;   // entries per slice of this launch
+  uint64_t cap_m, cap_slices;
+};
+
+struct MsmWork {   // per-context scratch, grown on demand
   uint64_t cap_m = 0;
-  uint16_t* digits = nullptr;      // W * m bucket keys (unsorted)
-  uint16_t* keys_out = nullptr;    // W * m bucket keys (sorted)
-  uint32_t* vals_in = nullptr;     // W * m entries (unsorted)
+  uint32_t* tmp_words = nullptr;   // W * m words grouped by coarse bin (msm_sort.hip)
   uint32_t* entries = nullptr;     // W * m entries grouped by bucket
-  void* sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
-  uint32_t* counts = nullptr;      // NB
+  uint32_t* coarse_cnt = nullptr;  // 2048 per commitment
+  uint32_t* coarse_off = nullptr;  // 2049
+  uint32_t* coarse_cur = nullptr;  // 2048
   uint32_t* offsets = nullptr;     // NB + 1
-  uint32_t* cursors = nullptr;     // NB
   uint32_t* slice_off = nullptr;   // NB + 1
   uint64_t cap_slices = 0;
   void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
   void* buckets = nullptr;         // NB
-  void* chunk = nullptr;           // NB / 16
+  void* chunk = nullptr;           // row / column sums
   uint8_t* result = nullptr;       // 97 B device
   uint8_t* result_host = nullptr;  // pinned
-  Fr* scalars_stage = nullptr;     // H2D staging for host-pointer API
+  Fr* scalars_stage = nullptr;     // H2D staging for the host-pointer API
   uint64_t cap_stage = 0;
 };
 
@@ -80,6 +86,8 @@ struct Ctx {
   std::set<const void*> smem_opt_in;   // kernels whose dynamic-LDS limit was raised on THIS device (hipFuncSetAttribute is per device)
   // NTT staging for the host-pointer API
   Fr* ntt_buf = nullptr;
+  Fr* ntt_buf2 = nullptr;          // second transform buffer of plonk_ntt_batch's upload/compute/download pipeline
+  hipStream_t copy_stream = nullptr;
   Fr* ntt_tmp = nullptr;
   uint64_t ntt_cap = 0;
   // SRS
@@ -116,10 +124,9 @@ int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
 // host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);
 int msm_reserve(Ctx* c, uint64_t m);
-// msm_sort.hip
-int msm_sort_temp_bytes(size_t n, size_t* bytes);
-int msm_sort_pairs(Ctx* c, void* temp, size_t temp_bytes, const uint16_t* keys_in, uint16_t* keys_out,
-                   const uint32_t* vals_in, uint32_t* vals_out, size_t n);
+// msm_sort.hip: scalars of a commitment group -> entries grouped by bucket, bucket offsets, slice offsets
+int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax);
+int msm_sort_reserve_fixed(Ctx* c);
 
 }  // namespace plonk
 

@@ -54,6 +54,29 @@ def test_edge_scalars(ctx, srs300):
     assert ctx.msm([5, Q - 5]) == E.msm_naive(srs300, [5, Q - 5])
 
 
+def test_msm_batch_entry_point(ctx, srs300):
+    """plonk_msm_batch = Prover::commit_polynomials' 4-way fan-out (prover.rs:187-210) as one grouped
+    launch over the shared commit key: 4 sets, then 6 (two groups), unequal lengths, an empty set
+    and an all-zero set; every result equals the single-call commitment and the oracle's."""
+    import plonk_amd
+    from oracle import cbind
+    r = random.Random(77)
+    ctx.srs_load(srs300)
+    raw_srs = b"".join(E.g1_to_raw96(p) for p in srs300)
+    for lens in ((300, 300, 300, 300), (300, 1, 0, 17, 299, 64), (5,), ()):
+        sets = [[r.randrange(Q) for _ in range(m)] for m in lens]
+        if len(sets) > 3:
+            sets[3] = [0] * len(sets[3])
+        raw = [plonk_amd.fr_to_bytes_mont(s) for s in sets]
+        got = ctx.msm_batch_bytes(raw)
+        assert len(got) == len(sets)
+        for k, s in enumerate(sets):
+            assert got[k] == ctx.msm_bytes(raw[k], len(s)), (lens, k)
+            assert got[k] == cbind.msm_bytes(raw_srs, raw[k], len(s)), (lens, k)
+    with pytest.raises(plonk_amd.PolynomialDegreeTooLarge):
+        ctx.msm_batch_bytes([plonk_amd.fr_to_bytes_mont([1] * 301)])
+
+
 def test_repeated_bases_hit_doubling_branch(ctx):
     G2 = E.g1_mul(E.G1_GEN, 2)
     pts = [E.G1_GEN, E.G1_GEN, E.G1_GEN, G2, E.g1_mul(E.G1_GEN, Q - 1)]

@@ -74,6 +74,32 @@ def test_batch_of_five_coset_ffts(ctx):
         assert ctx.ntt(poly, L, coset=True) == d.coset_fft(poly)
 
 
+def test_ntt_batch_entry_point_five_coset_ffts(ctx):
+    """The same five polynomials (quotient_poly.rs:315-349) through ONE plonk_ntt_batch call — the
+    replacement of compute_coset_evaluations' rayon fan-out (:139-157): results in input order, equal
+    to the single-call transforms; also an inverse batch with unequal in_len and a batch of one."""
+    import plonk_amd
+    from oracle import cbind
+    L = 12
+    n = 1 << L
+    polys = [plonk_amd.fr_to_bytes_mont([idx * n + i + 1 for i in range(n)]) for idx in range(5)]
+    got = ctx.ntt_batch_bytes(polys, L, False, True)
+    for idx in range(5):
+        assert got[idx] == cbind.ntt_bytes(polys[idx], L, False, True, n), idx
+    # the quotient-domain shape: 8n transform of n + 2 / n + 3 coefficients (in_len per element)
+    L8 = 15
+    lens = [n + 2, n + 3, n, 1, n + 2, 0, n + 2]
+    short = [polys[i % 5][:32 * min(l, n)] + bytes(32 * max(0, l - n)) for i, l in enumerate(lens)]
+    got = ctx.ntt_batch_bytes(short, L8, False, True, lens)
+    for i, l in enumerate(lens):
+        assert got[i] == cbind.ntt_bytes(short[i], L8, False, True, l), i
+    back = ctx.ntt_batch_bytes(got[:3], L8, True, True)
+    for i in range(3):
+        assert back[i][:32 * lens[i]] == short[i][:32 * lens[i]] and not any(back[i][32 * lens[i]:])
+    assert ctx.ntt_batch_bytes([polys[2]], L, True, False) == [cbind.ntt_bytes(polys[2], L, True, False, n)]
+    assert ctx.ntt_batch_bytes([], L, False, False) == []
+
+
 def test_truncates_longer_input(ctx):
     """Vec::resize truncation (domain.rs:174)."""
     L = 11

@@ -113,7 +113,7 @@ def test_unsatisfied_witness_is_circuit_unsatisfied_exactly(ctx, monkeypatch, do
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
+@pytest.mark.parametrize("domain", ["quotient-4n"])   # the 8n domain is compared at 2^12 .. 2^16 above
 def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     """BASELINE config 3 (2^20 gates): the bench circuit of bench.py (dense arithmetic profile) and the
     whole 1008-byte proof against the C oracle run on the host cores (about a minute)."""
