@@ -1,19 +1,26 @@
 #!/usr/bin/env python
 """Headline benchmark: Prover::prove wall-clock on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W [--log-gates G]
+  python bench.py --gpus N --steps K --warmup W [--log-gates G] [--profile dense|bench-like|widgets]
 
-A step = one full prove() (V3) of a synthetic 2^G-gate circuit: 6 iNTT(n) + 6 coset-NTT(8n) +
-1 coset-iNTT(8n) + 11 MSM(~n) + every O(n) pass in between, all on the GPU, producing the
-1008 Proof bytes.  Wire columns, ProverKey and SRS tables are resident in HBM when the timed
-region starts (they are produced by witness generation / Compiler::compile, outside prove()).
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); every MSM is sharded by
-SRS point range and the 192-byte partial sums are all-gathered over xGMI (strong scaling:
-one proof, N GPUs).  Rank 0 prints ONE JSON line.
+A step = one full prove() (V3) of a synthetic 2^G-gate circuit: 5 iNTT(n) (a, b, c, d, z; +1 for the
+public-input polynomial when the circuit has public inputs) + 5 coset-NTT(4n) (+1) + 1 coset-iNTT(4n)
++ 11 MSM(~n) + every O(n) pass in between, all on the GPU, producing the 1008 Proof bytes.  Wire
+columns, ProverKey and SRS tables are resident in HBM when the timed region starts (they are produced
+by witness generation / Compiler::compile, outside prove()).
+
+N > 1: one process per GPU.  The data path is RCCL INSIDE the library (plonk_comm_init: ncclAllGather /
+ncclAllToAll on the library's stream over xGMI) — torch.distributed (gloo) is only the out-of-band
+channel that hands the ncclUniqueId to the ranks and runs the barriers around the timed region.
+Every MSM is sharded by SRS point range, the quotient by residue class of the coset, evaluations /
+linearisation / openings by coefficient range (strong scaling: one proof, N GPUs).  If RCCL cannot be
+brought up (e.g. several ranks sharing one device in the tests) all ranks agree on the host-callback
+transport over gloo.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -22,128 +29,142 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import bench_circuits as BC  # noqa: E402
 import plonk_amd  # noqa: E402
 from plonk_amd import Q  # noqa: E402
 
-R = (1 << 256) % Q
-RINV = pow(R, -1, Q)
-K1, K2, K3 = 7, 13, 17
-ROOT_OF_UNITY = pow(7, (Q - 1) >> 32, Q)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+TAU, G_SCALAR = 0x5EED0000 * 0x9E3779B97F4A7C15 % Q, 0xA5A5A5A5DEADBEEF   # "random SRS" [g tau^i] G
 
 
-def synth_circuit(log_n: int, seed: int = 0x5EED0001):
-    """Dense synthetic circuit of n = 2^log_n arithmetic gates (SURVEY §8d `dense` profile):
-        q_M a b + q_L a + q_R b + q_O c + q_F d + q_C = 0
-    with q_M, q_L, q_R, q_F, q_C uniformly random per gate (full-length selector polynomials, as
-    a compiled circuit has), q_O = -1, q_arith = 1; random a_0, b_i, d_i; the output of gate i is
-    wired to input a of gate i+1, so the copy permutation is non-trivial (sigma_1, sigma_3).
-    Everything is kept in Montgomery representation (x~ = x R) so rows can be emitted as raw limb
-    bytes without conversion.
-    Returns (wires_bytes[4], key columns {name: bytes}, trivial polys {name: [ints]})."""
-    import random
+def synth_circuit(log_n: int):
+    """the headline `dense` workload (kept under this name for the tests)"""
+    return BC.arithmetic_circuit(log_n, "dense")
+
+
+def circuit_polys(ctx, log_n, profile):
+    """(wires[4] bytes, {name: coefficient-form polynomial}, public inputs) of a profile; the selector /
+    sigma columns are interpolated on the GPU (compiler.rs:179-211)."""
     n = 1 << log_n
-    rnd = random.Random(seed)
-    rb = rnd.getrandbits
-    a = [0] * n
-    b = [rb(254) % Q for _ in range(n)]
-    d = [rb(254) % Q for _ in range(n)]
-    qm = [rb(254) % Q for _ in range(n)]
-    ql = [rb(254) % Q for _ in range(n)]
-    qr = [rb(254) % Q for _ in range(n)]
-    qf = [rb(254) % Q for _ in range(n)]
-    qc = [rb(254) % Q for _ in range(n)]
-    c = [0] * n
-    cur = rb(254) % Q
-    for i in range(n):
-        a[i] = cur
-        bi = b[i]
-        # c~ = (qm~ a~ b~ R^-2 + ql~ a~ R^-1 + qr~ b~ R^-1 + qf~ d~ R^-1 + qc~)   (q_O = -1)
-        cur = ((qm[i] * cur % Q * bi % Q * RINV + ql[i] * cur + qr[i] * bi + qf[i] * d[i]) % Q * RINV + qc[i]) % Q
-        c[i] = cur
-    tb = int.to_bytes
-    wires = [b"".join(tb(x, 32, "little") for x in col) for col in (a, b, c, d)]
-    omega = pow(ROOT_OF_UNITY, 1 << (32 - log_n), Q)
-    t = R
-    T = [0] * n
-    for i in range(n):
-        T[i] = t
-        t = t * omega % Q
-    # sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_1[0] = w^0 ; sigma_3[i] = w^(i+1) (Left(i+1)), last = itself
-    s1 = [T[0]] + [K2 * T[i - 1] % Q for i in range(1, n)]
-    s3 = [T[i + 1] for i in range(n - 1)] + [K2 * T[n - 1] % Q]
-    cols = {"s_sigma_1": b"".join(tb(x, 32, "little") for x in s1),
-            "s_sigma_3": b"".join(tb(x, 32, "little") for x in s3)}
-    for name, col in (("q_m", qm), ("q_l", ql), ("q_r", qr), ("q_f", qf), ("q_c", qc)):
-        cols[name] = b"".join(tb(x, 32, "little") for x in col)
-    trivial = {"q_o": [Q - 1], "q_arith": [1], "s_sigma_2": [0, K1], "s_sigma_4": [0, K3]}
-    return wires, cols, trivial
-
-
-def build_prover(ctx, log_n, rank, world, allgather):
-    n = 1 << log_n
-    srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
-    lo, hi = plonk_amd.shard_range(srs_total, rank, world)
-    tau, g = 0x5EED0000 * 0x9E3779B97F4A7C15 % Q, 0xA5A5A5A5DEADBEEF
-    pts = ctx.alloc(96 * max(hi - lo, 1))
-    ctx.srs_generate_dev(tau, g * pow(tau, lo, Q) % Q, hi - lo, pts.ptr)   # "random SRS": [g tau^i] G
-    ctx.srs_load_dev(pts.ptr, hi - lo)
-    pts.free()
-    wires, cols, trivial = synth_circuit(log_n)
-    polys = dict(trivial)
+    if profile == "widgets":
+        wires, cols, pi = BC.widget_circuit(log_n)
+        polys = {}
+    else:
+        wires, cols, trivial = BC.arithmetic_circuit(log_n, profile)
+        polys, pi = dict(trivial), {}
     buf, tmp = ctx.alloc(32 * n), ctx.alloc(32 * n)
-    for name, raw in cols.items():          # selector / sigma columns -> coefficient form (compiler.rs:179-211)
+    for name, raw in cols.items():
         buf.upload(raw)
         ctx.ntt_dev(buf.ptr, buf.ptr, tmp.ptr, log_n, inverse=True)
         polys[name] = buf.download()
     buf.free()
     tmp.free()
+    return wires, polys, pi
+
+
+def build_prover(ctx, log_n, rank, world, allgather, profile="dense"):
+    n = 1 << log_n
+    srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
+    lo, hi = plonk_amd.shard_range(srs_total, rank, world)
+    pts = ctx.alloc(96 * max(hi - lo, 1))
+    ctx.srs_generate_dev(TAU, G_SCALAR * pow(TAU, lo, Q) % Q, hi - lo, pts.ptr)
+    ctx.srs_load_dev(pts.ptr, hi - lo)
+    pts.free()
+    wires, polys, pi = circuit_polys(ctx, log_n, profile)
     prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather)
     wbuf = ctx.alloc(4 * 32 * n)
     for k in range(4):
         wbuf.upload(wires[k], 32 * n * k)
+    prover.public_inputs = pi
     return prover, wbuf, srs_total
 
 
-def cpu_baseline(log_n: int):
-    """NTT + MSM share of one prove() on the host CPU with the C restatement (oracle/c), all
-    cores, at a bounded size; reported scaled linearly to 2^log_n gates."""
+def time_profile(ctx, log_n, profile, steps, blinders):
+    """ms per prove() of another workload on this (single) GPU"""
+    prover, wbuf, _ = build_prover(ctx, log_n, 0, 1, None, profile)
+    prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+    ctx.sync()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    prover.close()
+    wbuf.free()
+    return round(ms, 3)
+
+
+def leaf_costs(ctx, log_n):
+    """Seam-level drop-in cost, PCIe included (host buffers in, host buffers out): one plonk_ntt of the
+    8n quotient-domain size and one plonk_msm_batch of 4 scalar sets — what a Rust shim at the two
+    crate-private seams (domain.rs:173-232, key.rs:384) would pay per call."""
     import numpy as np
-    from oracle import cbind
-    sample_log = min(log_n, 20)   # 2^20: every transform / MSM size is measured directly (a few seconds on 16 cores), no extrapolation
-    n = 1 << sample_log
-    threads = cbind.max_threads()
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(3)
+    n = 1 << log_n
 
     def rand_fr(cnt):
         a = rng.integers(0, 256, size=(cnt, 32), dtype=np.uint8)
         a[:, 31] &= 0x3F
         return a.tobytes()
-    def best_of(k, fn):
-        best = 1e30
-        for _ in range(k):
-            t0 = time.perf_counter()
-            fn()
-            best = min(best, time.perf_counter() - t0)
-        return best
-    cbind.ntt_bytes(rand_fr(1 << 12), 12, False, False, 1 << 12, threads)      # spin up the OpenMP pool
-    d = rand_fr(n)
-    t_ntt_n = best_of(2, lambda: cbind.ntt_bytes(d, sample_log, True, False, n, threads))
-    d8 = rand_fr(n + 3)
-    t_ntt_8n = best_of(2, lambda: cbind.ntt_bytes(d8, sample_log + 3, False, True, n + 3, threads))
-    # distinct bases: [g tau^i]G is expensive on the CPU; tile 256 real points (timing only)
-    from oracle import bls12_381 as E
-    base = b"".join(E.g1_to_raw96(E.g1_mul(E.G1_GEN, 3 + 7 * i)) for i in range(256))
-    pts = base * (n // 256 + 1)
-    sc = rand_fr(n + 6)
-    t_msm = best_of(1, lambda: cbind.msm_bytes(pts, sc, n + 6, threads))
-    share_ms = (6 * t_ntt_n + 7 * t_ntt_8n + 11 * t_msm) * 1e3
+    out = {}
+    L8 = min(log_n + 3, 23)
+    d = rand_fr(1 << L8)
+    ctx.ntt_bytes(d, L8, False, True, 1 << L8)
+    t0 = time.perf_counter()
+    ctx.ntt_bytes(d, L8, False, True, 1 << L8)
+    out["plonk_ntt_2p%d_ms" % L8] = round((time.perf_counter() - t0) * 1e3, 2)
+    five = [d] * 5
+    t0 = time.perf_counter()
+    ctx.ntt_batch_bytes(five, L8, False, True)
+    out["plonk_ntt_batch5_2p%d_ms" % L8] = round((time.perf_counter() - t0) * 1e3, 2)
+    sets = [rand_fr(n + 2) for _ in range(4)]
+    ctx.msm_batch_bytes(sets)
+    t0 = time.perf_counter()
+    ctx.msm_batch_bytes(sets)
+    out["plonk_msm_batch4_2p%d_ms" % log_n] = round((time.perf_counter() - t0) * 1e3, 2)
+    out["note"] = "host buffers in and out through ctypes (includes the Python-side buffer copies)"
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(log_n: int, vk48: bytes):
+    """One WHOLE prove() on the host CPU with the C restatement of the reference's algorithm
+    (oracle/c/oracle_prove.c: best_fft, arkworks-style Pippenger, 8n quotient, OpenMP in place of rayon),
+    every core the container may use.  Sizes above 2^20 are measured at 2^20 and scaled linearly."""
+    from oracle import cbind
+    sample_log = min(log_n, 20)
+    n = 1 << sample_log
+    threads = cbind.max_threads()
+    wires, cols, trivial = BC.arithmetic_circuit(sample_log, "dense")
+    mont = plonk_amd.fr_to_bytes_mont
+    polys = {k: mont(v) for k, v in trivial.items()}
+    for name, raw in cols.items():
+        polys[name] = cbind.ntt_bytes(raw, sample_log, True, False, n, threads)
+    srs = cbind.srs_generate(mont([TAU]), mont([G_SCALAR]), n + 7, threads)
+    cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk48 if sample_log == log_n else None, threads=threads)
+    bl = mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
+    t0 = time.perf_counter()
+    proof = cp.prove(wires, [], b"", bl)
+    dt = time.perf_counter() - t0
+    sec = dict(cp.seconds)
+    cp.close()
     scale = float(1 << (log_n - sample_log))
-    return {"value": round(share_ms * scale, 1), "unit": "ms", "cores": threads, "kind": "port",
-            "sample": (f"C restatement (oracle/c, OpenMP) of the NTT+MSM share of one prove() = 6 iNTT(n) + 7 NTT(8n) + "
-                       f"11 MSM(n+6), measured once at n=2^{sample_log} ({share_ms:.0f} ms: iNTT(n) {t_ntt_n * 1e3:.1f}, "
-                       f"NTT(8n) {t_ntt_8n * 1e3:.1f}, MSM {t_msm * 1e3:.1f} ms) and scaled x{scale:g} linearly to "
-                       f"n=2^{log_n}; excludes the O(n) passes, so it is a LOWER bound on CPU prove()")}
+    return {"value": round(dt * 1e3 * scale, 1), "unit": "ms", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "proof_blake2b": hashlib.blake2b(proof).hexdigest()[:32],
+            "sample": (f"one whole prove() of the bench circuit at 2^{sample_log} gates with the C restatement of the "
+                       f"reference algorithm (oracle/c, OpenMP, {threads} threads): {dt * 1e3:.0f} ms = NTT {sec['ntt'] * 1e3:.0f} + "
+                       f"MSM {sec['msm'] * 1e3:.0f} + quotient {sec['quotient'] * 1e3:.0f} + grand product {sec['perm'] * 1e3:.0f} + "
+                       f"round 4-5 {sec['tail'] * 1e3:.0f} ms" + (f", scaled x{scale:g}" if scale != 1 else "") +
+                       "; not the Rust binary (no cargo in this image)")}, proof
 
 
 def main():
@@ -152,78 +173,80 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-gates", type=int, default=20)
+    ap.add_argument("--profile", default="dense", choices=["dense", "bench-like", "widgets"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads / leaf costs of the N=1 line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":   # several ranks on ONE GPU (functional test on a 1-GPU box)
+        local_rank = 0
+    log_n = args.log_gates
+    ctx = plonk_amd.Context(local_rank)
     dist = None
     allgather = None
-    collective_backend = None
+    collective = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        # PLONK_BENCH_BACKEND=gloo + PLONK_BENCH_SHARE_GPU=1: several ranks on ONE GPU (functional test of
-        # the sharded path on a 1-GPU box; RCCL itself refuses two ranks per device)
-        backend = os.environ.get("PLONK_BENCH_BACKEND", "nccl")
-        if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        # RCCL carries the data-path collective (CUDA tensors); gloo (CPU tensors) carries the agreement
-        # below and is the fallback if RCCL cannot be brought up on this node
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl" if backend == "nccl" else backend, rank=rank, world_size=world)
-        use_rccl = backend == "nccl"
-        if use_rccl:   # self-test, then a unanimous decision so that no rank is left waiting in the other backend
-            ok = 1
-            try:
-                probe = torch.full((8,), rank + 1, dtype=torch.uint8, device="cuda")
-                got = torch.empty(8 * world, dtype=torch.uint8, device="cuda")
-                dist.all_gather_into_tensor(got, probe)
-                torch.cuda.synchronize()
-                ok = int(got.cpu().tolist() == [r + 1 for r in range(world) for _ in range(8)])
-            except Exception as e:   # noqa: BLE001
-                print(f"[bench rank {rank}] RCCL self-test failed ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr)
-                ok = 0
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+        want_rccl = os.environ.get("PLONK_BENCH_BACKEND", "nccl") == "nccl"
+        ok = 0
+        if want_rccl:
+            # rank 0 creates the ncclUniqueId, gloo broadcasts it, every rank joins with its context
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = plonk_amd.Context.comm_unique_id()
+                except Exception as e:   # noqa: BLE001
+                    print(f"[bench] ncclGetUniqueId failed: {e}", file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is not None:
+                try:
+                    ctx.comm_init(box[0], rank, world)
+                    ctx.comm_selftest()
+                    ok = 1
+                except Exception as e:   # noqa: BLE001
+                    print(f"[bench rank {rank}] RCCL bring-up failed ({type(e).__name__}: {e})", file=sys.stderr)
             flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            use_rccl = bool(flag.item())
-        collective_backend = "rccl" if use_rccl else "gloo"
-        dev = "cuda" if use_rccl else "cpu"
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # unanimous, so that no rank waits in the other transport
+            ok = int(flag.item())
+            if not ok:
+                try:
+                    ctx.comm_destroy()
+                except Exception:   # noqa: BLE001
+                    pass
+        collective = "rccl" if ok else "gloo"
+        if not ok:
+            def allgather(send: bytes) -> bytes:   # host-callback transport (tests / fallback)
+                t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
+                out = torch.empty(world * t.numel(), dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, t)
+                return out.numpy().tobytes()
 
-        def allgather(send: bytes) -> bytes:   # all-gather of the MSM partial sums (RCCL over xGMI)
-            t = torch.frombuffer(bytearray(send), dtype=torch.uint8).to(dev)
-            out = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
-            dist.all_gather_into_tensor(out, t)
-            return out.cpu().numpy().tobytes()
-
-    log_n = args.log_gates
-    ctx = plonk_amd.Context(local_rank)
     t_setup = time.perf_counter()
-    prover, wbuf, srs_total = build_prover(ctx, log_n, rank, world, allgather)
+    prover, wbuf, srs_total = build_prover(ctx, log_n, rank, world, allgather, args.profile)
     t_setup = time.perf_counter() - t_setup
+    pi = prover.public_inputs
     blinders = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
 
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            tok = torch.zeros(1, dtype=torch.int32, device=dev)   # barrier on the backend that is known to work
-            dist.all_reduce(tok)
-            if dev == "cuda":
-                torch.cuda.synchronize()
+            dist.barrier()
 
     proof = None
     for _ in range(args.warmup):
-        proof = prover.prove_dev(wbuf.ptr, {}, blinders)
+        proof = prover.prove_dev(wbuf.ptr, pi, blinders)
     # timed region: exactly K proofs, hipEvent pairs recorded around the dominant kernels
     ctx.profile(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proof = prover.prove_dev(wbuf.ptr, {}, blinders)
+        proof = prover.prove_dev(wbuf.ptr, pi, blinders)
     barrier()
     elapsed = time.perf_counter() - t0
     acc_ms, acc_n = ctx.profile_read(1)     # msm_accumulate launches inside the timed region
@@ -232,11 +255,10 @@ def main():
     ctx.profile(False)
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        # all ranks must have produced the identical proof
-        ph = torch.frombuffer(bytearray(proof), dtype=torch.uint8).to(dev).to(torch.int32)
+        ph = torch.frombuffer(bytearray(proof), dtype=torch.uint8).to(torch.int32)   # all ranks must hold the identical proof
         ref = ph.clone()
         dist.broadcast(ref, 0)
         assert bool((ref == ph).all()), "ranks disagree on the proof bytes"
@@ -252,8 +274,9 @@ def main():
         avg_acc = acc_ms / max(acc_n, 1)
         acc_ms_per_prove = acc_ms / args.steps
         achieved = alg_bytes_per_prove / (acc_ms_per_prove * 1e-3) / 1e9 if acc_ms_per_prove > 0 else 0.0
-        valu_busy = None   # SQ_ACTIVE_INST_VALU / SIMD time of the same kernel, same PMC passes
-        traffic = None   # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc, profiles/*/pmc.json)
+        # HBM traffic / VALU utilisation of the same kernel come from PMC passes (rocprofv3 --pmc, separate runs):
+        # NOT measured by this run — the latest committed profile is quoted with its source
+        valu_busy = traffic = pmc_src = None
         if world == 1 and log_n == 20:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json"))):
@@ -261,24 +284,39 @@ def main():
                     pj = json.load(open(f))
                     traffic = round(pj["traffic_bytes_per_launch"])
                     valu_busy = pj.get("valu_busy_frac")
-                except Exception:
+                    pmc_src = os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of an earlier run, not this run)"
+                except Exception:   # noqa: BLE001
                     pass
+        qd8 = os.environ.get("PLONK_QUOTIENT_DOMAIN", "")[:1] == "8" or world == 8
+        npoly = 6 if pi else 5
         out = {
             "metric": "prove() wall-clock (ms) at 2^%d gates" % log_n,
             "value": round(ms_per_step, 3), "unit": "ms", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": False,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (Fr 256-bit / Fp 384-bit Montgomery)",
             "data": "synthetic",
-            "config": {"workload": "Prover::prove V3, synthetic dense 2^%d-gate arithmetic circuit, random SRS of "
-                                   "n+7 points, wires/ProverKey/SRS tables resident in HBM" % log_n,
-                       "gates": n, "ntt": "6 iNTT(n) + 6 cosetNTT(4n) + 1 cosetiNTT(4n) [quotient interpolated on 4n + de-aliasing; reference: 8n]" if os.environ.get("PLONK_QUOTIENT_DOMAIN", "")[:1] != "8" else "6 iNTT(n) + 6 cosetNTT(8n) + 1 cosetiNTT(8n)", "msm": "11 x ~n terms",
-                       "parallelism": "msm-point-range-shard x%d" % world, "collective": collective_backend, "setup_s": round(t_setup, 1)},
+            "config": {"workload": "Prover::prove V3, synthetic 2^%d-gate circuit, profile `%s` (%s), random SRS of n+7 points, "
+                                   "wires/ProverKey/SRS tables resident in HBM" % (
+                                       log_n, args.profile,
+                                       {"dense": "arithmetic gates, uniformly random selectors and wires, no public inputs",
+                                        "bench-like": "arithmetic gates, half of the wire values < 4, no public inputs",
+                                        "widgets": "range + logic + fixed-base + curve-addition + arithmetic gates, 2 public inputs"}[args.profile]),
+                       "gates": n,
+                       "ntt": ("%d iNTT(n) + %d cosetNTT(%dn) + 1 cosetiNTT(%dn)" % (npoly, npoly, 8 if qd8 else 4, 8 if qd8 else 4)) +
+                              ("" if qd8 else " [quotient interpolated on the 4n coset + de-aliasing; reference: 8n]") +
+                              (" — per rank: the coset transforms as size-n transforms on its residue classes" if world in (2, 4, 8) else ""),
+                       "msm": "11 x ~n terms",
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       "x%d: MSM by SRS point range; quotient by coset residue class; rounds 4-5 by coefficient range" % world
+                                       if world in (2, 4, 8) else "x%d: MSM by SRS point range" % world),
+                       "collective": collective, "setup_s": round(t_setup, 1)},
             # whole-job MSM rate: all 11 x (n + 6) terms of a proof over the time rank 0 spends in its (sharded) MSM kernels
             "msm_mscalar_per_s": round(11 * (n + 6) / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),
-            "proof_blake2b": __import__("hashlib").blake2b(proof).hexdigest()[:32],
+            "proof_blake2b": hashlib.blake2b(proof).hexdigest()[:32],
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3), "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
+                         "traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
+                         "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
                          "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
                          "launch_groups_per_prove": list(groups),
                          "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; see DESIGN.md"},
@@ -286,9 +324,24 @@ def main():
                                     "msm_other": round(oth_ms / args.steps, 3),
                                     "quotient_pointwise": round(q_ms / args.steps, 3)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        vk48 = prover.vk_commitments()
+        prover.close()
+        wbuf.free()
+        if world == 1 and not args.no_extras and args.profile == "dense":
+            try:   # the other workloads of SURVEY §8(d) and the seam-level cost; never a reason to lose the line
+                k = max(2, min(args.steps, 5))
+                out["prove_ms_bench_like"] = time_profile(ctx, log_n, "bench-like", k, blinders)
+                out["prove_ms_all_widgets_pi"] = time_profile(ctx, log_n, "widgets", k, blinders)
+                if log_n != 16:
+                    out["prove_ms_2p16"] = time_profile(ctx, 16, "dense", 2 * k, blinders)
+                out["leaf_ms"] = leaf_costs(ctx, log_n)
+            except Exception as e:   # noqa: BLE001
+                out["extras_error"] = repr(e)
+        if world == 1 and not args.no_cpu_baseline and args.profile == "dense":
             try:
-                out["cpu_baseline"] = cpu_baseline(log_n)
+                out["cpu_baseline"], cpu_proof = cpu_baseline(log_n, vk48)
+                if log_n <= 20:   # same SRS, circuit, witness and blinders: the CPU port must produce the same bytes
+                    out["cpu_baseline"]["proof_matches_gpu"] = bool(cpu_proof == proof)
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)

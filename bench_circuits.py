@@ -1,0 +1,267 @@
+"""Synthetic circuits for bench.py / the tests: deterministic, seed-stamped, satisfied by
+construction.  Pure Python big-int arithmetic; nothing here touches the GPU library or the oracle.
+
+Profiles (all of size n = 2^log_n, every row an active gate, non-trivial copy permutation):
+  dense        arithmetic gates q_M a b + q_L a + q_R b + q_O c + q_F d + q_C = 0 with uniformly random
+               selectors and wire values (seed 0x5eed0001) — the headline workload
+  bench-like   the same gates with the §8(d) value mix: half of the wire values < 4 (bits / quads as range,
+               logic and decomposition gadgets produce them), half uniform (seed 0x5eed0002)
+  widgets      BenchCircuit-shaped (reference benches/plonk.rs:33-82): every selector family active — range
+               (composer/range.rs:68-130), logic XOR / AND (composer/logic.rs:42-170), fixed-base scalar
+               multiplication rounds (composer/fixed_base.rs:160-290), curve addition (composer/point.rs:356-408)
+               with honest witnesses (bit quads, truth tables, JubJub points), arithmetic gates in between
+               and two public inputs; a block of 256 rows tiled over the domain, tiles linked by copy
+               constraints (seed 0x5eed0003)
+
+Everything is returned in Montgomery representation (x~ = x R mod q, R = 2^256) as raw little-endian
+limb bytes — the in-memory form of BlsScalar.0 that the C-ABI takes."""
+from __future__ import annotations
+
+import random
+
+Q = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+R = (1 << 256) % Q
+RINV = pow(R, -1, Q)
+K1, K2, K3 = 7, 13, 17
+ROOT_OF_UNITY = pow(7, (Q - 1) >> 32, Q)
+EDWARDS_D = (-10240 * pow(10241, -1, Q)) % Q      # dusk_jubjub::EDWARDS_D:  -x^2 + y^2 = 1 + d x^2 y^2
+SELECTORS = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
+             "q_fixed_group_add", "q_variable_group_add"]
+
+
+def _bytes(col):
+    tb = int.to_bytes
+    return b"".join(tb(x, 32, "little") for x in col)
+
+
+def _omega_table(log_n):
+    """w^i * R for i < n (Montgomery form)."""
+    n = 1 << log_n
+    omega = pow(ROOT_OF_UNITY, 1 << (32 - log_n), Q)
+    t, T = R, [0] * n
+    for i in range(n):
+        T[i] = t
+        t = t * omega % Q
+    return T
+
+
+def arithmetic_circuit(log_n: int, profile: str = "dense"):
+    """Chain of n arithmetic gates: the output of gate i is wired to input a of gate i + 1 (sigma_1, sigma_3
+    non-trivial), q_O = -1, q_arith = 1.  `dense`: random selectors, the output follows.  `bench-like`: the
+    wire values are drawn first (half of them < 4), q_C is solved for so that each gate holds.
+    Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, trivial polys {name: [ints]})."""
+    n = 1 << log_n
+    if profile == "dense":
+        rnd = random.Random(0x5EED0001)
+        rb = rnd.getrandbits
+        a = [0] * n
+        b = [rb(254) % Q for _ in range(n)]
+        d = [rb(254) % Q for _ in range(n)]
+        qm = [rb(254) % Q for _ in range(n)]
+        ql = [rb(254) % Q for _ in range(n)]
+        qr = [rb(254) % Q for _ in range(n)]
+        qf = [rb(254) % Q for _ in range(n)]
+        qc = [rb(254) % Q for _ in range(n)]
+        c = [0] * n
+        cur = rb(254) % Q
+        for i in range(n):
+            a[i] = cur
+            bi = b[i]
+            # all values are Montgomery forms: c~ = (qm~ a~ b~ R^-2 + ql~ a~ R^-1 + qr~ b~ R^-1 + qf~ d~ R^-1 + qc~)
+            cur = ((qm[i] * cur % Q * bi % Q * RINV + ql[i] * cur + qr[i] * bi + qf[i] * d[i]) % Q * RINV + qc[i]) % Q
+            c[i] = cur
+    elif profile == "bench-like":
+        rnd = random.Random(0x5EED0002)
+        rb = rnd.getrandbits
+
+        def val():      # half small (< 4), half uniform — Montgomery form of the value
+            return (rb(2) * R) % Q if rb(1) else rb(254) % Q
+        b = [val() for _ in range(n)]
+        d = [val() for _ in range(n)]
+        c = [val() for _ in range(n)]
+        a = [val()] + c[:-1]
+        qm = [rb(254) % Q for _ in range(n)]
+        ql = [rb(254) % Q for _ in range(n)]
+        qr = [rb(254) % Q for _ in range(n)]
+        qf = [rb(254) % Q for _ in range(n)]
+        qc = [0] * n
+        for i in range(n):
+            lhs = (qm[i] * a[i] % Q * b[i] % Q * RINV + ql[i] * a[i] + qr[i] * b[i] + qf[i] * d[i]) % Q * RINV % Q
+            qc[i] = (c[i] - lhs) % Q
+    else:
+        raise ValueError(profile)
+    wires = [_bytes(col) for col in (a, b, c, d)]
+    T = _omega_table(log_n)
+    # sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_1[0] = w^0 ; sigma_3[i] = w^(i+1) (Left(i+1)), last = itself
+    s1 = [T[0]] + [K2 * T[i - 1] % Q for i in range(1, n)]
+    s3 = [T[i + 1] for i in range(n - 1)] + [K2 * T[n - 1] % Q]
+    cols = {"s_sigma_1": _bytes(s1), "s_sigma_3": _bytes(s3)}
+    for name, col in (("q_m", qm), ("q_l", ql), ("q_r", qr), ("q_f", qf), ("q_c", qc)):
+        cols[name] = _bytes(col)
+    trivial = {"q_o": [Q - 1], "q_arith": [1], "s_sigma_2": [0, K1], "s_sigma_4": [0, K3]}
+    return wires, cols, trivial
+
+
+# ---- JubJub (the widgets only need the curve equation, not the subgroup) -----------------------------
+def _fr_sqrt(a):
+    a %= Q
+    if a == 0:
+        return 0
+    if pow(a, (Q - 1) // 2, Q) != 1:
+        return None
+    s, t = 32, (Q - 1) >> 32
+    z = pow(7, t, Q)
+    m, c, r, b = s, z, pow(a, (t + 1) // 2, Q), pow(a, t, Q)
+    while b != 1:
+        i, x = 0, b
+        while x != 1:
+            x = x * x % Q
+            i += 1
+        f = pow(c, 1 << (m - i - 1), Q)
+        m, c, r, b = i, f * f % Q, r * f % Q, b * f * f % Q
+    return r
+
+
+def jj_add(p1, p2):
+    (x1, y1), (x2, y2) = p1, p2
+    k = EDWARDS_D * x1 % Q * x2 % Q * y1 % Q * y2 % Q
+    return ((x1 * y2 + y1 * x2) * pow(1 + k, -1, Q) % Q, (y1 * y2 + x1 * x2) * pow(1 - k, -1, Q) % Q)
+
+
+def jj_point():
+    y = 2
+    while True:
+        x = _fr_sqrt((y * y - 1) * pow(EDWARDS_D * y * y + 1, -1, Q))
+        if x:
+            return (x, y)
+        y += 1
+
+
+class _Rows:
+    """Row-by-row layout: wire VALUES (a, b, c, d) and selector values per gate."""
+
+    def __init__(self):
+        self.rows = []
+
+    def gate(self, a=0, b=0, c=0, d=0, **sel):
+        self.rows.append(((a % Q, b % Q, c % Q, d % Q), {k: v % Q for k, v in sel.items()}))
+
+    def arith(self, a=0, b=0, c=0, d=0, **sel):
+        sel["q_arith"] = 1
+        self.gate(a, b, c, d, **sel)
+
+    # range gadget: accumulators of 2-bit quads, (d, c, b, a) per row, the next row's d continues
+    def range(self, value, quads):
+        digits = [(value >> (2 * (quads - 1 - i))) & 3 for i in range(quads)]
+        accs, acc = [0], 0
+        for q in digits:
+            acc = 4 * acc + q
+            accs.append(acc)
+        assert len(accs) % 4 == 1
+        for r in range((len(accs) - 1) // 4):
+            self.gate(a=accs[4 * r + 3], b=accs[4 * r + 2], c=accs[4 * r + 1], d=accs[4 * r], q_range=1)
+        self.arith(d=accs[-1])                                         # carries the final accumulator as d_next
+
+    # logic gadget: rows (a_i, b_i, w_{i+1}, d_i), q_c = q_logic = -1 (XOR) / +1 (AND); closing row
+    def logic(self, x, y, quads, xor):
+        sel = Q - 1 if xor else 1
+        a = b = d = 0
+        for i in range(quads):
+            qa = (x >> (2 * (quads - 1 - i))) & 3
+            qb = (y >> (2 * (quads - 1 - i))) & 3
+            self.gate(a=a, b=b, c=qa * qb, d=d, q_c=sel, q_logic=sel)
+            a, b = 4 * a + qa, 4 * b + qb
+            d = 4 * d + ((qa ^ qb) if xor else (qa & qb))
+        self.gate(a=a, b=b, d=d)
+
+    # fixed-base rounds: (acc_x, acc_y, xy_alpha, scalar_acc), q_l = x_beta, q_r = y_beta, q_c = xy_beta
+    def fixed_base(self, base, digits):
+        mult = [base]
+        for _ in range(1, len(digits)):
+            mult.append(jj_add(mult[-1], mult[-1]))
+        mult.reverse()
+        acc_pt, acc_sc = (0, 1), 0
+        for i, dg in enumerate(digits):
+            pt = (0, 1) if dg == 0 else (mult[i] if dg == 1 else ((-mult[i][0]) % Q, mult[i][1]))
+            xb, yb = mult[i]
+            self.gate(a=acc_pt[0], b=acc_pt[1], c=pt[0] * pt[1], d=acc_sc, q_l=xb, q_r=yb, q_c=xb * yb,
+                      q_fixed_group_add=1)
+            acc_pt, acc_sc = jj_add(acc_pt, pt), (2 * acc_sc + dg) % Q
+        self.arith(a=acc_pt[0], b=acc_pt[1], d=acc_sc)
+        return acc_pt
+
+    # curve addition: (x1, y1, x2, y2) with the selector, then (x3, y3, 0, x1 y2)
+    def curve_add(self, p1, p2):
+        p3 = jj_add(p1, p2)
+        self.gate(a=p1[0], b=p1[1], c=p2[0], d=p2[1], q_variable_group_add=1)
+        self.gate(a=p3[0], b=p3[1], d=p1[0] * p2[1])
+        return p3
+
+    def mul_gate(self, r, a, b, d):
+        qm, qf, qc = r.randrange(1, Q), r.randrange(Q), r.randrange(Q)
+        self.arith(a=a, b=b, c=qm * a * b + qf * d + qc, d=d, q_m=qm, q_f=qf, q_c=qc, q_o=Q - 1)
+
+
+def widget_block(blk: int, seed: int = 0x5EED0003) -> _Rows:
+    """`blk` rows with every widget family, ending on a plain arithmetic row (so a tile never looks into
+    the next one through the X -> omega X rotation with anything but closing-row zeros)."""
+    r = random.Random(seed)
+    rows = _Rows()
+    base = jj_point()
+    pts = []
+    order, step = (2, 0, 1, 2, 3, 4, 3), 0      # fixed base twice before the first curve addition
+    while len(rows.rows) < blk - 48:
+        kind = order[step % len(order)]
+        step += 1
+        if kind == 0:
+            rows.range(r.getrandbits(32), 16)
+        elif kind == 1:
+            rows.logic(r.getrandbits(20), r.getrandbits(20), 10, xor=bool(r.getrandbits(1)))
+        elif kind == 2:
+            pts.append(rows.fixed_base(base, [r.choice((-1, 0, 1)) for _ in range(12)]))
+        elif kind == 3:
+            pts.append(rows.curve_add(r.choice(pts), r.choice(pts)))
+            pts = pts[-6:]
+        else:
+            for _ in range(6):
+                rows.mul_gate(r, r.randrange(Q), r.randrange(Q), r.randrange(Q))
+    while len(rows.rows) < blk:
+        rows.mul_gate(r, r.randrange(Q), r.randrange(Q), r.randrange(Q))
+    assert len(rows.rows) == blk
+    return rows
+
+
+def widget_circuit(log_n: int, blk_log: int = 8):
+    """n = 2^log_n rows: a block of 2^blk_log rows tiled over the domain.  Position (column, row) of tile t is
+    copy-constrained to the same position of tile t + 1 (equal values by construction), so the permutation
+    is a product of n / blk-cycles; two public inputs sit on the last two rows of tile 0.
+    Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, public inputs {row: value})."""
+    n = 1 << log_n
+    blk = 1 << min(blk_log, log_n)
+    tiles = n // blk
+    rows = widget_block(blk).rows
+    mont = lambda v: v % Q * R % Q   # noqa: E731
+    wires = []
+    for col in range(4):
+        wires.append(_bytes([mont(rw[0][col]) for rw in rows]) * tiles)
+    cols = {}
+    for name in SELECTORS:
+        vals = [mont(rw[1].get(name, 0)) for rw in rows]
+        if any(vals):
+            cols[name] = bytearray(_bytes(vals) * tiles)
+    # public inputs: rows blk-2, blk-1 of tile 0 are `-a + PI = 0` (q_l = -1, q_arith = 1, PI = a); the same
+    # rows of the other tiles keep their multiplication gate — the wire values are identical either way
+    pi = {}
+    for row in (blk - 2, blk - 1):
+        a_val = rows[row][0][0]
+        for name in SELECTORS:
+            if name in cols:
+                v = {"q_l": Q - 1, "q_arith": 1}.get(name, 0)
+                cols[name][32 * row:32 * row + 32] = int.to_bytes(mont(v), 32, "little")
+        pi[row] = a_val
+    T = _omega_table(log_n)
+    ks = (1, K1, K2, K3)
+    for k in range(4):   # sigma_k[i] = K_k * w^((i + blk) mod n)
+        rot = T[blk:] + T[:blk]
+        cols[f"s_sigma_{k + 1}"] = _bytes([ks[k] * t % Q for t in rot]) if tiles > 1 else _bytes([ks[k] * t % Q for t in T])
+    return wires, {k: bytes(v) for k, v in cols.items()}, pi

@@ -119,12 +119,18 @@ void* plonk_ctx_stream(plonk_ctx* ctx); /* the hipStream_t of the context's main
  * The 8n coset evaluations, sigma evaluations and vanishing inverses (compiler.rs:310-425,
  * prover.rs:78-100) are rebuilt on the device. */
 typedef struct plonk_prover plonk_prover;
-/* Multi-GPU (one process per GPU): every MSM is sharded by contiguous SRS point range; rank r
- * loads only points [r*S, (r+1)*S), S = ceil(srs_total / world), into its context and the
- * per-rank partial sums (192-byte XYZZ points) are exchanged through this callback — an
- * all-gather (EC addition is not an RCCL reduce op), `recv` laid out rank-major.  bench.py
- * backs it with torch.distributed (RCCL over xGMI); a Rust shim would call ncclAllGather.
- * Return 0 on success. */
+/* Multi-GPU (one process per GPU): rank r loads only SRS points [r*S, (r+1)*S), S = ceil(srs_total / world),
+ * into its context (srs_total >= size + 7) and owns the same range of polynomial COEFFICIENTS:
+ *   - every MSM runs on the rank's point range; the per-rank partial sums (192-byte XYZZ points) are
+ *     all-gathered and added locally (EC addition is not an RCCL reduce op);
+ *   - world in {2, 4, 8}: the quotient is computed per residue class of the quotient coset (rank r owns
+ *     the size-n cosets g w^j H_n with j = r mod world), one all-to-all turns the per-class remainders into
+ *     the coefficient range of t the rank commits to, and evaluations / linearisation / opening quotients
+ *     work on that range with two more small all-gathers;
+ *   - other world sizes (or PLONK_SHARD_QUOTIENT=0): only the MSMs are sharded.
+ * Transport: RCCL on the library's stream when the context has a communicator (plonk_comm_init below);
+ * otherwise this host callback — an all-gather, `recv` laid out rank-major — which is how the tests run
+ * several ranks on one device.  Return 0 on success. */
 typedef int (*plonk_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes_per_rank);
 typedef struct {
   uint64_t constraints;          /* gate count; domain size = next power of two        */
@@ -164,6 +170,20 @@ int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const ui
 int plonk_prover_prove_dev(plonk_prover* p, const void* wires_dev, const uint64_t* pi_idx,
                            const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
                            uint8_t proof[1008]);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------
+ * Rank 0 calls plonk_comm_unique_id and hands the 128 bytes (an ncclUniqueId) to the other ranks by
+ * whatever out-of-band channel the host program has; every rank then calls plonk_comm_init on its
+ * context (collective: it returns when all `world` ranks have joined).  A context with a communicator
+ * runs every exchange of a sharded prover (plonk_prover_desc.shard_world > 1) as ncclAllGather /
+ * ncclAllToAll on its own stream — no host callback is involved and desc.allgather may be NULL.
+ * RCCL is loaded with dlopen at the first of these calls, so the library itself does not depend on it.
+ * plonk_comm_selftest runs both collectives once with a rank-dependent pattern and checks the result.
+ * What is exchanged and why EC partial sums are all-gathered rather than all-reduced: DESIGN.md §5. */
+int plonk_comm_unique_id(uint8_t out[128]);
+int plonk_comm_init(plonk_ctx* ctx, const uint8_t unique_id[128], int rank, int world);
+int plonk_comm_selftest(plonk_ctx* ctx);
+int plonk_comm_destroy(plonk_ctx* ctx);
 
 /* ---- serialized Prover ---------------------------------------------------------------
  * plonk_prover_from_bytes replaces Prover::try_from_bytes (src/compiler/prover.rs:266-345): `blob`

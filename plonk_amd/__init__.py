@@ -46,6 +46,7 @@ EXPORTS = [
     "plonk_prover_create", "plonk_prover_destroy", "plonk_prover_vk", "plonk_prover_size",
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
+    "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -152,6 +153,10 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_prover_blob_check.argtypes = [vp, u64, ctypes.POINTER(_BlobInfo)]
     lib.plonk_prover_from_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
     lib.plonk_srs_validate.argtypes = [vp, vp, u64]
+    lib.plonk_comm_unique_id.argtypes = [vp]
+    lib.plonk_comm_init.argtypes = [vp, vp, ci, ci]
+    lib.plonk_comm_selftest.argtypes = [vp]
+    lib.plonk_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -352,6 +357,27 @@ class Context:
 
     def sync(self):
         self._check(self.lib.plonk_dev_sync(self.handle))
+
+    # ---- multi-GPU (RCCL inside the library) -----------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId on rank 0; hand the 128 bytes to the other ranks out of band."""
+        lib = load_library()
+        out = ctypes.create_string_buffer(128)
+        rc = lib.plonk_comm_unique_id(out)
+        if rc != PLONK_OK:
+            raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
+        return out.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        assert len(unique_id) == 128
+        self._check(self.lib.plonk_comm_init(self.handle, unique_id, rank, world))
+
+    def comm_selftest(self):
+        self._check(self.lib.plonk_comm_selftest(self.handle))
+
+    def comm_destroy(self):
+        self._check(self.lib.plonk_comm_destroy(self.handle))
 
     def profile(self, on: bool):
         self._check(self.lib.plonk_profile_enable(self.handle, int(on)))

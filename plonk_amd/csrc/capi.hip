@@ -146,6 +146,7 @@ int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
 
 void plonk_ctx_destroy(plonk_ctx* ctx) {
   if (!ctx) return;
+  (void)plonk_comm_destroy(ctx);
   Ctx& c = ctx->c;
   (void)hipSetDevice(c.device);
   (void)hipStreamSynchronize(c.stream);

@@ -1,0 +1,216 @@
+// Multi-GPU exchange layer of libplonk_hip.so: one process per GPU, RCCL over xGMI.
+//
+// The prover needs two collectives:
+//   * all-gather of a few hundred bytes per rank (MSM partial sums, partial evaluations, suffix-sum
+//     carries) — EC addition / field addition is done locally after the gather, because a group
+//     element is not an RCCL reduction type;
+//   * one all-to-all of the per-class quotient remainders before the coefficient recombination
+//     (the transpose of a four-step transform), 32 * n / world bytes per peer.
+// Both run on the context's main stream.  RCCL is resolved with dlopen at plonk_comm_init, so the
+// library loads (and the single-GPU path runs) on hosts without librccl.  A context without a
+// communicator falls back to the caller-supplied host all-gather callback of plonk_prover_desc
+// (tests drive several ranks on ONE device through it, which RCCL itself refuses).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <vector>
+
+#include "plonk_internal.hpp"
+
+namespace plonk {
+
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllToAll)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi* rccl_api() {
+  static RcclApi api;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (api.lib) return &api;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* nm : names)
+    if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) { set_last_error("dlopen(librccl)", dlerror(), __FILE__, __LINE__); return nullptr; }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+  api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+  api.AllToAll = (decltype(api.AllToAll))dlsym(h, "ncclAllToAll");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllToAll) {
+    set_last_error("dlsym(librccl)", "missing RCCL entry point", __FILE__, __LINE__);
+    dlclose(h);
+    return nullptr;
+  }
+  api.lib = h;
+  return &api;
+}
+
+#define RCCL_TRY(api, expr)                                                                         \
+  do {                                                                                              \
+    ncclResult_t _r = (expr);                                                                       \
+    if (_r != ncclSuccess) {                                                                        \
+      set_last_error(#expr, (api)->GetErrorString ? (api)->GetErrorString(_r) : "rccl error", __FILE__, __LINE__); \
+      return PLONK_ERR_HIP;                                                                         \
+    }                                                                                               \
+  } while (0)
+
+static constexpr size_t COMM_STAGE = 16384;   // bytes per rank of a small (host-value) all-gather
+
+// All-gather of `bytes` host bytes per rank; recv is rank-major.  RCCL when the context has a
+// communicator (staged through device buffers on the main stream), else the host callback.
+int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes) {
+  if (l.world <= 1) { memcpy(recv, send, bytes); return PLONK_OK; }
+  if (c->nccl_comm) {
+    RcclApi* api = rccl_api();
+    if (!api || bytes > COMM_STAGE) return (set_last_error("comm_allgather_host", "message too large / no rccl", __FILE__, __LINE__), PLONK_ERR_ARG);
+    HIP_TRY(hipMemcpyAsync(c->comm_send, send, bytes, hipMemcpyHostToDevice, c->main_stream));
+    RCCL_TRY(api, api->AllGather(c->comm_send, c->comm_recv, bytes, ncclUint8, (ncclComm_t)c->nccl_comm, c->main_stream));
+    HIP_TRY(hipMemcpyAsync(recv, c->comm_recv, bytes * (size_t)l.world, hipMemcpyDeviceToHost, c->main_stream));
+    HIP_TRY(hipStreamSynchronize(c->main_stream));
+    return PLONK_OK;
+  }
+  if (!l.fn) return (set_last_error("comm_allgather_host", "no communicator and no all-gather callback", __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (l.fn(l.user, send, recv, bytes) != 0) return (set_last_error("all-gather callback", "returned non-zero", __FILE__, __LINE__), PLONK_ERR_STATE);
+  return PLONK_OK;
+}
+
+// All-to-all of device buffers: send = [peer][bytes_per_peer], recv = [source][bytes_per_peer].
+// Callback transport: every rank contributes its whole send buffer to an all-gather and keeps the
+// pieces addressed to it (world x the traffic — it is the functional fallback, not the fast path).
+int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* recv_dev, size_t bytes_per_peer) {
+  if (l.world <= 1) {
+    HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, bytes_per_peer, hipMemcpyDeviceToDevice, c->main_stream));
+    return PLONK_OK;
+  }
+  if (c->nccl_comm) {
+    RcclApi* api = rccl_api();
+    if (!api) return PLONK_ERR_STATE;
+    RCCL_TRY(api, api->AllToAll(send_dev, recv_dev, bytes_per_peer, ncclUint8, (ncclComm_t)c->nccl_comm, c->main_stream));
+    return PLONK_OK;
+  }
+  if (!l.fn) return (set_last_error("comm_alltoall_dev", "no communicator and no all-gather callback", __FILE__, __LINE__), PLONK_ERR_STATE);
+  const size_t mine = bytes_per_peer * (size_t)l.world;
+  std::vector<uint8_t> hs(mine), hr(mine * (size_t)l.world);
+  HIP_TRY(hipMemcpyAsync(hs.data(), send_dev, mine, hipMemcpyDeviceToHost, c->main_stream));
+  HIP_TRY(hipStreamSynchronize(c->main_stream));
+  if (l.fn(l.user, hs.data(), hr.data(), mine) != 0) return (set_last_error("all-gather callback", "returned non-zero", __FILE__, __LINE__), PLONK_ERR_STATE);
+  for (int src = 0; src < l.world; ++src)
+    HIP_TRY(hipMemcpyAsync((uint8_t*)recv_dev + bytes_per_peer * (size_t)src,
+                           hr.data() + mine * (size_t)src + bytes_per_peer * (size_t)l.rank, bytes_per_peer, hipMemcpyHostToDevice, c->main_stream));
+  HIP_TRY(hipStreamSynchronize(c->main_stream));   // hr leaves scope
+  return PLONK_OK;
+}
+
+}  // namespace plonk
+
+using namespace plonk;
+
+extern "C" {
+
+int plonk_comm_unique_id(uint8_t out[128]) {
+  if (!out) return PLONK_ERR_ARG;
+  RcclApi* api = rccl_api();
+  if (!api) return PLONK_ERR_STATE;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  RCCL_TRY(api, api->GetUniqueId(&id));
+  memcpy(out, &id, 128);
+  return PLONK_OK;
+}
+
+int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int world) {
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  if (c.nccl_comm) return (set_last_error("plonk_comm_init", "context already has a communicator", __FILE__, __LINE__), PLONK_ERR_STATE);
+  RcclApi* api = rccl_api();
+  if (!api) return PLONK_ERR_STATE;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  ncclComm_t comm = nullptr;
+  RCCL_TRY(api, api->CommInitRank(&comm, world, id, rank));
+  hipError_t e = hipMalloc((void**)&c.comm_send, COMM_STAGE);
+  if (e == hipSuccess) e = hipMalloc((void**)&c.comm_recv, COMM_STAGE * (size_t)world);
+  if (e != hipSuccess) {
+    (void)api->CommDestroy(comm);
+    (void)hipFree(c.comm_send);
+    c.comm_send = nullptr;
+    set_last_error("hipMalloc(comm staging)", hipGetErrorString(e), __FILE__, __LINE__);
+    return PLONK_ERR_HIP;
+  }
+  c.nccl_comm = comm;
+  c.comm_rank = rank;
+  c.comm_world = world;
+  return PLONK_OK;
+}
+
+int plonk_comm_destroy(plonk_ctx* ctx) {
+  if (!ctx) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.nccl_comm) return PLONK_OK;
+  (void)hipSetDevice(c.device);
+  (void)hipStreamSynchronize(c.main_stream);
+  RcclApi* api = rccl_api();
+  if (api) (void)api->CommDestroy((ncclComm_t)c.nccl_comm);
+  c.nccl_comm = nullptr;
+  (void)hipFree(c.comm_send);
+  (void)hipFree(c.comm_recv);
+  c.comm_send = c.comm_recv = nullptr;
+  c.comm_world = 1;
+  c.comm_rank = 0;
+  return PLONK_OK;
+}
+
+// Both collectives once, with a rank-dependent pattern, checked on every rank.
+int plonk_comm_selftest(plonk_ctx* ctx) {
+  if (!ctx) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  if (!c.nccl_comm) return (set_last_error("plonk_comm_selftest", "no communicator", __FILE__, __LINE__), PLONK_ERR_STATE);
+  CommLink l;
+  l.rank = c.comm_rank;
+  l.world = c.comm_world;
+  const int W = l.world, R = l.rank;
+  uint8_t send[64];
+  for (int i = 0; i < 64; ++i) send[i] = (uint8_t)(R * 7 + i);
+  std::vector<uint8_t> recv(64 * (size_t)W);
+  int rc = comm_allgather_host(&c, l, send, recv.data(), 64);
+  if (rc) return rc;
+  for (int r = 0; r < W; ++r)
+    for (int i = 0; i < 64; ++i)
+      if (recv[64 * r + i] != (uint8_t)(r * 7 + i)) return (set_last_error("plonk_comm_selftest", "all-gather returned wrong bytes", __FILE__, __LINE__), PLONK_ERR_STATE);
+  const size_t per = 4096;
+  uint8_t *ds = nullptr, *dr = nullptr;
+  HIP_TRY(hipMalloc((void**)&ds, per * W));
+  if (hipMalloc((void**)&dr, per * W) != hipSuccess) { (void)hipFree(ds); return PLONK_ERR_HIP; }
+  std::vector<uint8_t> hs(per * W), hr(per * W);
+  for (int p = 0; p < W; ++p)
+    for (size_t i = 0; i < per; ++i) hs[per * p + i] = (uint8_t)(R * 31 + p * 5 + i);
+  rc = PLONK_OK;
+  if (hipMemcpyAsync(ds, hs.data(), per * W, hipMemcpyHostToDevice, c.main_stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  if (!rc) rc = comm_alltoall_dev(&c, l, ds, dr, per);
+  if (!rc && hipMemcpyAsync(hr.data(), dr, per * W, hipMemcpyDeviceToHost, c.main_stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  if (hipStreamSynchronize(c.main_stream) != hipSuccess) rc = rc ? rc : PLONK_ERR_HIP;
+  (void)hipFree(ds);
+  (void)hipFree(dr);
+  if (rc) return rc;
+  for (int src = 0; src < W; ++src)
+    for (size_t i = 0; i < per; ++i)
+      if (hr[per * src + i] != (uint8_t)(src * 31 + R * 5 + i)) return (set_last_error("plonk_comm_selftest", "all-to-all returned wrong bytes", __FILE__, __LINE__), PLONK_ERR_STATE);
+  return PLONK_OK;
+}
+
+}  // extern "C"

@@ -372,6 +372,24 @@ static int build_pow_table29(Ctx* c, Fr29Slot** out, const Fr& base, const Fr& f
   return PLONK_OK;
 }
 
+// Coset tables for an arbitrary shift s (forward: s^i ; inverse: s^-i), i < 2^L, in both table forms.
+// Used by the class decomposition of the quotient coset (prover.hip, multi-GPU): the quotient coset
+// {g w_N^i} is the union of the size-n cosets (g w_N^j) H_n, so a class needs shift g w_N^j.
+int ntt_coset_tables(Ctx* c, uint32_t L, const Fr& shift, bool inverse, NttCoset* out) {
+  const Fr g = inverse ? shift.inv() : shift;
+  const uint32_t ghi_n = L > (uint32_t)GLO_BITS ? (1u << (L - GLO_BITS)) : 1u;
+  int rc;
+  if ((rc = build_pow_table(c, &out->g_lo, g, Fr::one(), 1u << GLO_BITS))) return rc;
+  if ((rc = build_pow_table(c, &out->g_hi, g.pow_u64(1ull << GLO_BITS), Fr::one(), ghi_n))) return rc;
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&out->g_lo29, g, Fr::one(), 1u << GLO_BITS))) return rc;
+  if ((rc = build_pow_table29(c, (Fr29Slot**)&out->g_hi29, g.pow_u64(1ull << GLO_BITS), Fr::one(), ghi_n))) return rc;
+  return PLONK_OK;
+}
+void ntt_coset_free(NttCoset* t) {
+  (void)hipFree(t->g_lo); (void)hipFree(t->g_hi); (void)hipFree(t->g_lo29); (void)hipFree(t->g_hi29);
+  *t = NttCoset{};
+}
+
 int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
   std::lock_guard<std::mutex> lk(c->table_mu);
   const uint32_t key = (L << 1) | (inverse ? 1u : 0u);
@@ -437,7 +455,8 @@ static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, ui
 
 // Device-resident transform: src (in_len valid elements) -> dst (N elements).
 // src == dst is allowed.  `tmp` must hold N elements (N > 1024 only).
-int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len) {
+int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len,
+               const NttCoset* shift) {
   if (L >= 28) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // 3 passes of <= 2^9; reference limit is 2^32 (domain.rs:132)
   const uint64_t N = 1ull << L;
   if (in_len > N) in_len = N;          // Vec::resize truncation, domain.rs:174
@@ -446,13 +465,18 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
   if (rc) return rc;
   int r[3], np;
   ntt_plan(L, r, &np);
+  // coset tables: the generator's (reference domain.rs:198-232), or the caller's for another shift
+  const Fr* g_lo = shift ? shift->g_lo : tb->g_lo;
+  const Fr* g_hi = shift ? shift->g_hi : tb->g_hi;
+  const Fr29Slot* g_lo29 = (const Fr29Slot*)(shift ? shift->g_lo29 : tb->g_lo29);
+  const Fr29Slot* g_hi29 = (const Fr29Slot*)(shift ? shift->g_hi29 : tb->g_hi29);
   const int post = inverse ? (coset ? 2 : 1) : 0;
   if (np == 1) {
     NttSmall s{};
     s.src = src; s.dst = dst; s.logN = L; s.in_len = in_len;
     s.pre_coset = (coset && !inverse) ? 1 : 0;
     s.post_mode = post; s.scale = tb->n_inv;
-    s.tw_lo = tb->tw_lo; s.g_lo = tb->g_lo; s.g_hi = tb->g_hi;
+    s.tw_lo = tb->tw_lo; s.g_lo = g_lo; s.g_hi = g_hi;
     hipLaunchKernelGGL(ntt_small_kernel, dim3(1), dim3(NTT_THREADS), 0, c->stream, s);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
@@ -469,7 +493,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.tw_lo = (const Fr29Slot*)(inverse ? tb->tw_lo_scaled29 : tb->tw_lo29);   // n^-1 folded into pass A's twiddles
     p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
     p.in_len = in_len; p.pre_coset = (coset && !inverse) ? 1 : 0;
-    p.post_mode = 0; p.g_lo = (const Fr29Slot*)tb->g_lo29; p.g_hi = (const Fr29Slot*)tb->g_hi29;
+    p.post_mode = 0; p.g_lo = g_lo29; p.g_hi = g_hi29;
     p.w512 = (const Fr29Slot*)tb->w512_29;
     const uint32_t nb = (uint32_t)((N >> r[0]) >> (TILE_LOG - r[0]));
     if ((rc = launch_pass_rt(c, r[0], p, true, nb))) return rc;
@@ -483,7 +507,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.tw_mode = 1; p.tw_shr = (uint32_t)r[0];
     p.tw_lo = (const Fr29Slot*)tb->tw_lo29; p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
     p.in_len = N; p.pre_coset = 0; p.post_mode = 0; p.w512 = (const Fr29Slot*)tb->w512_29;
-    p.g_lo = (const Fr29Slot*)tb->g_lo29; p.g_hi = (const Fr29Slot*)tb->g_hi29;
+    p.g_lo = g_lo29; p.g_hi = g_hi29;
     const uint32_t nb = (uint32_t)((N >> r[1]) >> (TILE_LOG - r[1]));
     if ((rc = launch_pass_rt(c, r[1], p, false, nb))) return rc;
   }
@@ -496,7 +520,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.tw_mode = 0; p.tw_shr = 0; p.tw_lo = (const Fr29Slot*)tb->tw_lo29; p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
     p.in_len = N; p.pre_coset = 0;
     p.post_mode = (inverse && coset) ? 2 : 0;   // n^-1 already folded in pass A
-    p.scale = Fr29::zero(); p.g_lo = (const Fr29Slot*)tb->g_lo29; p.g_hi = (const Fr29Slot*)tb->g_hi29;
+    p.scale = Fr29::zero(); p.g_lo = g_lo29; p.g_hi = g_hi29;
     p.w512 = (const Fr29Slot*)tb->w512_29;
     const uint32_t nb = (uint32_t)((N >> rl) >> (TILE_LOG - rl));
     if ((rc = launch_pass_rt(c, rl, p, false, nb))) return rc;

@@ -95,6 +95,11 @@ struct Ctx {
   uint64_t srs_n = 0;
   uint64_t srs_gen = 0;            // bumped by every (re)load: provers remember the generation they were built on
   MsmWork msm;
+  // multi-GPU (comm.hip): RCCL communicator of this rank, staging for small all-gathers
+  void* nccl_comm = nullptr;
+  uint8_t* comm_send = nullptr;
+  uint8_t* comm_recv = nullptr;
+  int comm_rank = 0, comm_world = 1;
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -103,13 +108,32 @@ struct Ctx {
 };
 
 // ntt.hip
-int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len);
+struct NttCoset {   // powers of an arbitrary coset shift (two-level tables, both forms) — see ntt_coset_tables
+  Fr* g_lo = nullptr;
+  Fr* g_hi = nullptr;
+  void* g_lo29 = nullptr;
+  void* g_hi29 = nullptr;
+};
+int ntt_coset_tables(Ctx* c, uint32_t L, const Fr& shift, bool inverse, NttCoset* out);
+void ntt_coset_free(NttCoset* t);
+// shift == nullptr: the multiplicative generator 7 (the reference's coset)
+int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse, bool coset, uint64_t in_len,
+               const NttCoset* shift = nullptr);
 int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out);
 // raise a kernel's dynamic shared-memory limit once per context (= per device)
 inline void smem_opt_in(Ctx* c, const void* fn, size_t bytes) {
   if (c->smem_opt_in.insert(fn).second) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 void ntt_plan(uint32_t L, int r[3], int* npass);
+
+// comm.hip: who this rank is and, when the context has no RCCL communicator, the host all-gather to use
+struct CommLink {
+  int rank = 0, world = 1;
+  plonk_allgather_fn fn = nullptr;
+  void* user = nullptr;
+};
+int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes);
+int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
 
 // msm.hip
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);

@@ -800,6 +800,7 @@ __global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgsD a) {
 static constexpr int MP_E = 16;
 struct MulPowArgs {
   Tw xt, one_t;
+  Fr addend;   // added to every source element before the multiplication (the suffix-sum carry of the ranks above)
 };
 __global__ void __launch_bounds__(256) mul_powers_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n,
                                                          MulPowArgs a, uint64_t src_off, uint64_t exp_off) {
@@ -807,7 +808,7 @@ __global__ void __launch_bounds__(256) mul_powers_kernel(const Fr* __restrict__ 
   const uint64_t wave = g >> 6, lane = g & 63;
   const uint64_t first = wave * (64 * MP_E) + lane;
   if (first >= n) return;
-  const Fr29 xt = tw29(a.xt), one_t = tw29(a.one_t);
+  const Fr29 xt = tw29(a.xt), one_t = tw29(a.one_t), add = Fr29::from_fr(a.addend);
   Fr29 p = pow_tw(xt, first + exp_off, one_t);
   Fr29 step = xt;
 #pragma unroll
@@ -816,8 +817,86 @@ __global__ void __launch_bounds__(256) mul_powers_kernel(const Fr* __restrict__ 
   for (int k = 0; k < MP_E; ++k) {
     const uint64_t i = first + 64ull * k;
     if (i >= n) break;
-    stf(dst + i, Fr29::mul(ld29_(src + i + src_off), p).to_fr());
+    stf(dst + i, Fr29::mul(Fr29::add_csub(ld29_(src + i + src_off), add), p).to_fr());
     p = Fr29::mul(p, step);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU: the quotient coset split into residue classes (prover.hip, SURVEY §8e ii)
+// ---------------------------------------------------------------------------
+// dst[i] = src[i] + c * src[n + i] for i < extra, else src[i]: a polynomial of n + extra coefficients
+// reduced mod (X^n - c), which is what it looks like on a size-n coset whose points satisfy x^n = c.
+__global__ void fold_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n, uint32_t extra, Fr c) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr v = ldf(src + i);
+  if (i < extra) v = v + c * ldf(src + n + i);
+  stf(dst + i, v);
+}
+
+// send[(p * cpr + k) * stride + i] = F_k[p * per + i] (zero beyond n) for i < per, then F_k[0..8)
+__global__ void shard_pack_kernel(ShardPackArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = blockIdx.y, peer = blockIdx.z;
+  if (i >= a.stride) return;
+  const Fr* F = a.F[k];
+  Fr v = Fr::zero();
+  if (i < a.per) {
+    const uint64_t idx = (uint64_t)peer * a.per + i;
+    if (idx < a.n) v = ldf(F + idx);
+  } else {
+    v = ldf(F + (i - a.per));
+  }
+  stf(a.send + ((uint64_t)peer * a.cpr + k) * a.stride + i, v);
+}
+
+// Per coefficient index i0 of this rank's range: the Q-point inverse DFT across the classes,
+//   c_{i0 + n i1} = g^(-n i1) / Q * sum_j w_Q^(-j i1) F_j[i0]      (coef[i1][j] holds the factor),
+// written to parts[i1][i0] (t_low, t_mid, t_high, t_fourth).  The last 8 lanes do the same for the
+// lowest coefficients every rank received (de-aliasing / the coefficients of t beyond 4n).
+__global__ void __launch_bounds__(128) shard_combine_kernel(ShardCombineArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.cnt + 8) return;
+  const bool extra = i >= a.cnt;
+  const uint64_t off = extra ? a.per + (i - a.cnt) : i;            // position inside a message
+  Fr F[8];
+  for (uint32_t j = 0; j < a.Q; ++j)
+    F[j] = ldf(a.recv + ((uint64_t)(j % a.W) * a.cpr + j / a.W) * a.stride + off);
+  auto dft = [&](uint32_t i1) {
+    Fr acc = Fr::zero();
+    for (uint32_t j = 0; j < a.Q; ++j) acc = acc + a.coef[i1][j] * F[j];
+    return acc;
+  };
+  if (!extra) {
+    const uint64_t idx = a.lo + i;
+    for (uint32_t i1 = 0; i1 < 4; ++i1) {
+      if (i1 == 0 && a.Q == 4 && idx < 7) continue;               // aliased: restored by the extra lanes
+      stf(a.parts[i1] + idx, dft(i1));
+    }
+  } else {
+    const uint64_t k = i - a.cnt;
+    if (k >= 7) return;
+    Fr top;                                                       // t[4n + k]
+    if (a.Q == 4) {
+      top = (dft(0) - a.low[k]) * a.g4n_inv;                      // A[k] = t[k] + g^4n t[4n + k]
+      if (k >= a.lo && k < a.hi) stf(a.parts[0] + k, a.low[k]);
+    } else {
+      top = dft(4);
+    }
+    if (a.n + k >= a.lo && a.n + k < a.hi) stf(a.parts[3] + a.n + k, top);
+  }
+}
+
+// blinding of the split quotient (prover.rs:547-574) restricted to the indices a rank owns
+__global__ void shard_split_fix_kernel(ShardSplitFix a) {
+  if (threadIdx.x != 0) return;
+  auto own = [&](uint64_t idx) { return idx >= a.lo && idx < a.hi; };
+  if (own(a.n)) { stf(a.parts[0] + a.n, a.b[0]); stf(a.parts[1] + a.n, a.b[1]); stf(a.parts[2] + a.n, a.b[2]); }
+  if (own(0)) {
+    stf(a.parts[1], ldf(a.parts[1]) - a.b[0]);
+    stf(a.parts[2], ldf(a.parts[2]) - a.b[1]);
+    stf(a.parts[3], ldf(a.parts[3]) - a.b[2]);
   }
 }
 
@@ -973,10 +1052,13 @@ int poly_lincomb(Ctx* c, const LinCombArgs& a) {
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
-static void launch_mul_powers(Ctx* c, const Fr* src, Fr* dst, uint64_t n, const Fr& x, uint64_t src_off, uint64_t exp_off) {
+static void launch_mul_powers(Ctx* c, const Fr* src, Fr* dst, uint64_t n, const Fr& x, uint64_t src_off, uint64_t exp_off,
+                              const Fr& addend = Fr::zero()) {
+  if (!n) return;
   MulPowArgs a;
   a.xt = tw_of(x);
   a.one_t = tw_of(Fr::one());
+  a.addend = addend;
   hipLaunchKernelGGL(mul_powers_kernel, grid1((n + MP_E - 1) / MP_E, 256), dim3(256), 0, c->stream, src, dst, n, a, src_off, exp_off);
 }
 // quotient of src[0..len) by (X - z) -> dst[0..len-1); dst[len-1] = 0.  scratch: len Fr + totals.
@@ -989,6 +1071,43 @@ int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, cons
   rc = poly_fill_zero(c, dst + (len - 1), 1);
   HIP_TRY(hipGetLastError());
   return rc;
+}
+
+int poly_fold(Ctx* c, const Fr* src, Fr* dst, uint64_t n, uint32_t extra, const Fr& cn) {
+  hipLaunchKernelGGL(fold_kernel, grid1(n, 256), dim3(256), 0, c->stream, src, dst, n, extra, cn);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_shard_pack(Ctx* c, const ShardPackArgs& a, uint32_t world) {
+  hipLaunchKernelGGL(shard_pack_kernel, dim3((uint32_t)((a.stride + 255) / 256), a.cpr, world), dim3(256), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_shard_combine(Ctx* c, const ShardCombineArgs& a) {
+  hipLaunchKernelGGL(shard_combine_kernel, grid1(a.cnt + 8, 128), dim3(128), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_shard_split_fix(Ctx* c, const ShardSplitFix& a) {
+  hipLaunchKernelGGL(shard_split_fix_kernel, dim3(1), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+// Range-sharded ruffini, part 1: scratch[i] = src[i] * z^(lo + i), suffix sums in place, scratch[len] = 0;
+// scratch[0] is then this range's contribution to sum_j c_j z^j.
+int poly_ruffini_local(Ctx* c, const Fr* src, uint64_t lo, uint64_t len, const Fr& z, Fr* scratch, Fr* totals) {
+  int rc = poly_fill_zero(c, scratch + len, 1);
+  if (rc || !len) return rc;
+  launch_mul_powers(c, src, scratch, len, z, 0, lo);
+  return scan_suffix_sum(c, scratch, len, totals);
+}
+// part 2: dst[lo + i] = (scratch[i + 1] + carry) * zinv^(lo + i + 1) for i < len, where carry = the
+// contributions of all higher ranges; index `last` (the dropped remainder slot) is set to zero.
+int poly_ruffini_finish(Ctx* c, const Fr* scratch, Fr* dst, uint64_t lo, uint64_t len, const Fr& zinv, const Fr& carry, uint64_t last) {
+  launch_mul_powers(c, scratch, dst + lo, len, zinv, 1, lo + 1, carry);
+  if (last >= lo && last < lo + len) return poly_fill_zero(c, dst + last, 1);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
 }
 
 }  // namespace plonk

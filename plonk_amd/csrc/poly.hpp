@@ -77,6 +77,34 @@ struct LinCombArgs {
   Fr* out;
 };
 
+// ---- multi-GPU: residue classes of the quotient coset (prover.hip) -------------------------------
+struct ShardPackArgs {
+  const Fr* F[8];      // per owned class: n coefficients of t mod (X^n - s_j^n)
+  Fr* send;            // [peer][class][stride]
+  uint64_t n, per, stride;   // stride = per + 8
+  uint32_t cpr;
+};
+struct ShardCombineArgs {
+  const Fr* recv;      // [source rank][class of that rank][stride]
+  uint64_t stride, per, lo, hi, cnt, n;   // this rank owns coefficient indices [lo, hi); cnt = those below n
+  uint32_t W, cpr, Q;
+  Fr coef[5][8];       // g^(-n i1) w_Q^(-j i1) / Q
+  Fr low[7];           // true lowest coefficients of t (quotient_low), Q == 4 only
+  Fr g4n_inv;
+  Fr* parts[4];        // t_low, t_mid, t_high, t_fourth (indexed by global coefficient)
+};
+struct ShardSplitFix {
+  Fr* parts[4];
+  uint64_t lo, hi, n;
+  Fr b[3];
+};
+int poly_fold(Ctx* c, const Fr* src, Fr* dst, uint64_t n, uint32_t extra, const Fr& cn);
+int poly_shard_pack(Ctx* c, const ShardPackArgs& a, uint32_t world);
+int poly_shard_combine(Ctx* c, const ShardCombineArgs& a);
+int poly_shard_split_fix(Ctx* c, const ShardSplitFix& a);
+int poly_ruffini_local(Ctx* c, const Fr* src, uint64_t lo, uint64_t len, const Fr& z, Fr* scratch, Fr* totals);
+int poly_ruffini_finish(Ctx* c, const Fr* scratch, Fr* dst, uint64_t lo, uint64_t len, const Fr& zinv, const Fr& carry, uint64_t last);
+
 void prof_begin(Ctx* c, int slot);
 void prof_end(Ctx* c, int slot);
 

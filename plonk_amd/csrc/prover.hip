@@ -70,6 +70,26 @@ struct Prover {
   int rank = 0, world = 1;
   uint64_t srs_total = 0, shard_lo = 0;
   uint64_t srs_gen = 0;            // Ctx::srs_gen at creation: the SRS this prover's degree checks / slices refer to
+  CommLink link;                   // rank / world / host all-gather callback (comm.hip picks RCCL when the ctx has a communicator)
+  // ---- sharded quotient (multi-GPU, world in {2, 4, 8}; SURVEY §8e ii).  The quotient coset {g w_N^i}, N = Q n,
+  // is the union of Q size-n cosets (g w_N^j) H_n ("classes"); rank r owns classes r, r + world, ...: its
+  // key / wire evaluations, the point-wise pass and a size-n inverse transform per class are local, one
+  // all-to-all + a Q-point inverse DFT per coefficient turn the per-class remainders into the coefficient
+  // range [lo, hi) of t this rank's MSM shard needs; rounds 4-5 work on the same coefficient range.
+  bool sharded = false;
+  uint32_t Q = 0, cpr = 0;         // classes in total (4, or 8 for world == 8) / per rank
+  uint32_t cls[8] = {0};           // owned class indices
+  NttCoset cs_fwd[8], cs_inv[8];   // coset tables for the class shifts (forward / inverse)
+  Fr sigma_j[8];                   // x^n on the class: g^n w_Q^j
+  uint64_t qn = 0;                 // elements per evaluation array: cpr * n (sharded) or n8
+  uint64_t per = 0, lo = 0, hi = 0, stride = 0;   // coefficient range owned: [lo, hi), hi <= np - 1; message stride
+  Fr coef[5][8];                   // inverse-DFT factors, ShardCombineArgs::coef
+  Fr* fold = nullptr;              // [2][n] folded polynomials (main / side stream)
+  Fr* Fbuf = nullptr;              // [cpr][n] per-class quotient evaluations -> remainders
+  Fr* send = nullptr;              // [world][cpr][stride]
+  Fr* recv = nullptr;
+  Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
+  Fr* scratch2 = nullptr;          // [np + 1]
   plonk_allgather_fn allgather = nullptr;
   void* allgather_user = nullptr;
   Fr* ev_host = nullptr;           // pinned 16 Fr
@@ -144,9 +164,8 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
   std::vector<G1> sums(count);
   for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)));
   if (p->world > 1) {
-    if (!p->allgather) return PLONK_ERR_STATE;
     const size_t bytes = sizeof(G1) * (size_t)count;
-    if (p->allgather(p->allgather_user, sums.data(), p->gather_host, bytes) != 0) return PLONK_ERR_STATE;
+    PTRY(comm_allgather_host(c, p->link, sums.data(), p->gather_host, bytes));
     for (int i = 0; i < count; ++i) {
       G1 acc = G1::identity();
       for (int r = 0; r < p->world; ++r) {
@@ -169,6 +188,8 @@ static void prover_free(Prover* p) {
                   p->tparts, p->agg, p->wit, p->wit2, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  for (void* b : {(void*)p->fold, (void*)p->Fbuf, (void*)p->send, (void*)p->recv, (void*)p->agg2, (void*)p->scratch2}) if (b) (void)hipFree(b);
+  for (int k = 0; k < 8; ++k) { ntt_coset_free(&p->cs_fwd[k]); ntt_coset_free(&p->cs_inv[k]); }
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
   if (p->ev_pi) (void)hipEventDestroy(p->ev_pi);
@@ -221,24 +242,47 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   }
   p->allgather = d->allgather;
   p->allgather_user = d->allgather_user;
+  p->link.rank = p->rank; p->link.world = p->world; p->link.fn = d->allgather; p->link.user = d->allgather_user;
+  if (p->world > 1 && c->nccl_comm && (c->comm_world != p->world || c->comm_rank != p->rank))
+    return (plonk::set_last_error("invalid argument", "shard_rank / shard_world disagree with the context's communicator", __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (p->world > 1 && !c->nccl_comm && !d->allgather)
+    return (plonk::set_last_error("invalid argument", "sharded prover needs plonk_comm_init on the context or an all-gather callback", __FILE__, __LINE__), PLONK_ERR_ARG);
+  {
+    const char* sq = getenv("PLONK_SHARD_QUOTIENT");   // "0": shard only the MSMs (every rank runs the whole quotient)
+    p->sharded = (p->world == 2 || p->world == 4 || p->world == 8) && n >= 64 && !(sq && sq[0] == '0');
+    if (p->sharded) {
+      p->Q = p->world == 8 ? 8 : 4;
+      p->cpr = p->Q / (uint32_t)p->world;
+      for (uint32_t k = 0; k < p->cpr; ++k) p->cls[k] = (uint32_t)p->rank + (uint32_t)p->world * k;
+      p->qf = p->Q; p->lq = p->Q == 8 ? 3 : 2;
+      p->n8 = p->qf * n;
+      p->per = (p->srs_total + p->world - 1) / p->world;
+      p->stride = p->per + 8;
+      p->lo = p->shard_lo < n + 7 ? p->shard_lo : n + 7;
+      p->hi = p->shard_lo + p->per < n + 7 ? p->shard_lo + p->per : n + 7;
+      if (p->srs_total < n + 7) return (plonk::set_last_error("invalid argument", "sharded prover: srs_total < size + 7", __FILE__, __LINE__), PLONK_ERR_DEGREE);
+    }
+    p->qn = p->sharded ? (uint64_t)p->cpr * n : p->n8;
+  }
   if (p->world > 1) {
     p->gather_host = (uint8_t*)malloc((size_t)p->world * 16 * sizeof(G1));
     if (!p->gather_host) return (plonk::set_last_error("malloc", "gather_host", __FILE__, __LINE__), PLONK_ERR_HIP);
   }
-  const uint64_t np = p->np, n8 = p->n8;
+  const uint64_t np = p->np, n8 = p->n8, qn = p->qn;
+  const uint64_t wn = p->sharded ? n : n8;   // largest transform run inside prove(): scratch size
 #define ALLOC(ptr, count) do { hipError_t _e = hipMalloc((void**)&(ptr), sizeof(*(ptr)) * (size_t)(count)); \
     if (_e != hipSuccess) { set_last_error("hipMalloc " #ptr, hipGetErrorString(_e), __FILE__, __LINE__); return PLONK_ERR_HIP; } } while (0)
   ALLOC(p->polys, P_COUNT * np);
-  ALLOC(p->evals8, (P_COUNT + 2) * n8);
+  ALLOC(p->evals8, (P_COUNT + 2) * qn);
   ALLOC(p->sigma_n, 4 * n);
   ALLOC(p->wires, 4 * n);
   ALLOC(p->wpoly, 4 * np);
   ALLOC(p->zpoly, np);
   ALLOC(p->pipoly, np);
-  ALLOC(p->cos, 6 * n8);
-  ALLOC(p->tbuf, n8 + 16);
-  ALLOC(p->tmp8, n8);
-  ALLOC(p->tmp8b, n8);
+  ALLOC(p->cos, 6 * qn);
+  ALLOC(p->tbuf, (p->sharded ? np : n8) + 16);   // sharded: t_fourth only, indexed by coefficient
+  ALLOC(p->tmp8, wn);
+  ALLOC(p->tmp8b, wn);
   ALLOC(p->tparts, 3 * np);
   ALLOC(p->agg, np);
   ALLOC(p->wit, np);
@@ -251,6 +295,14 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   ALLOC(p->res, 16 * RES_STRIDE);
   ALLOC(p->len_dev, 1);
   ALLOC(p->flag_dev, 1);
+  if (p->sharded) {
+    ALLOC(p->fold, 2 * n);
+    ALLOC(p->Fbuf, (uint64_t)p->cpr * n);
+    ALLOC(p->send, (uint64_t)p->world * p->cpr * p->stride);
+    ALLOC(p->recv, (uint64_t)p->world * p->cpr * p->stride);
+    ALLOC(p->agg2, np);
+    ALLOC(p->scratch2, np + 1);
+  }
 #undef ALLOC
   HIP_TRY(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming));
@@ -278,26 +330,16 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
       p->key_low[k][i] = (uint64_t)i < p->poly_len[k] ? ((const Fr*)d->polys[k])[i] : Fr::zero();
 
   // ---- cached evaluations: 16 coset FFTs on the quotient domain (8n in compiler.rs:312-377) ...
-  for (int k = 0; k < P_COUNT; ++k)
-    PTRY(ntt_device(c, p->polys + k * np, p->evals8 + k * n8, p->tmp8, L + p->lq, false, true, p->poly_len[k]));
-  {
-    const Fr lin[2] = {Fr::zero(), Fr::one()};
-    HIP_TRY(hipMemcpyAsync(p->scratch, lin, sizeof lin, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    PTRY(ntt_device(c, p->scratch, p->evals8 + P_COUNT * n8, p->tmp8, L + p->lq, false, true, 2));
-  }
-  // ... 4 sigma FFTs on n (prover.rs:95-100)
-  for (int k = 0; k < 4; ++k)
-    PTRY(ntt_device(c, p->polys + (P_S1 + k) * np, p->sigma_n + k * n, p->tmp8, L, false, false, p->poly_len[P_S1 + k]));
-  // ... vanishing polynomial over the coset: 8 distinct values g^n * w8^i - 1 (domain.rs:338-351) and
-  // their inverses (prover.rs:78-91); L1 over the coset (quotient_poly.rs:266-284)
   L1Args l1a;
   {
+    // vanishing polynomial over the coset: qf distinct values g^n * w_qf^i - 1 (domain.rs:338-351) and
+    // their inverses (prover.rs:78-91); the 8 slots repeat with period qf
     Fr point = fr_generator().pow_u64(n);
-    const Fr step = omega_of(L + p->lq).pow_u64(n);   // order qf: the 8 slots repeat with period qf
+    const Fr step = omega_of(L + p->lq).pow_u64(n);   // primitive qf-th root of unity
     for (int i = 0; i < 8; ++i) {
       l1a.vh[i] = point - Fr::one();
       p->vinv[i] = l1a.vh[i].inv();
+      p->sigma_j[i] = point;
       point = point * step;
     }
     l1a.n_inv = Fr::from_u64(n).inv();
@@ -307,14 +349,52 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
     p->gq_inv = fr_generator().pow_u64(p->n8).inv();                    // g^-(quotient domain size), de-aliasing
     p->omega = omega_of(L);
     p->omega_inv = p->omega.inv();
+    if (p->sharded) {   // coef[i1][j] = g^(-n i1) w_Q^(-j i1) / Q
+      const Fr gn_inv = fr_generator().pow_u64(n).inv(), w_inv = step.inv(), q_inv = Fr::from_u64(p->Q).inv();
+      Fr gi = q_inv;
+      for (uint32_t i1 = 0; i1 < 5; ++i1) {
+        const Fr wi = w_inv.pow_u64(i1);
+        Fr t = gi;
+        for (uint32_t j = 0; j < 8; ++j) { p->coef[i1][j] = t; t = t * wi; }
+        gi = gi * gn_inv;
+      }
+    }
   }
-  PTRY(poly_l1(c, p->evals8 + P_COUNT * n8, p->evals8 + (P_COUNT + 1) * n8, n8, l1a));
+  const Fr lin[2] = {Fr::zero(), Fr::one()};
+  HIP_TRY(hipMemcpyAsync(p->scratch, lin, sizeof lin, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!p->sharded) {
+    for (int k = 0; k < P_COUNT; ++k)
+      PTRY(ntt_device(c, p->polys + k * np, p->evals8 + k * n8, p->tmp8, L + p->lq, false, true, p->poly_len[k]));
+    PTRY(ntt_device(c, p->scratch, p->evals8 + P_COUNT * n8, p->tmp8, L + p->lq, false, true, 2));
+    // L1 over the coset (quotient_poly.rs:266-284)
+    PTRY(poly_l1(c, p->evals8 + P_COUNT * n8, p->evals8 + (P_COUNT + 1) * n8, n8, l1a));
+  } else {
+    // the same evaluations restricted to the classes this rank owns: size-n coset transforms with
+    // shift g w_N^j, arrays laid out [polynomial][owned class][n]
+    const Fr wN = omega_of(L + p->lq);
+    for (uint32_t k = 0; k < p->cpr; ++k) {
+      const uint32_t j = p->cls[k];
+      const Fr shift = fr_generator() * wN.pow_u64(j);
+      PTRY(ntt_coset_tables(c, L, shift, false, &p->cs_fwd[k]));
+      PTRY(ntt_coset_tables(c, L, shift, true, &p->cs_inv[k]));
+      for (int id = 0; id < P_COUNT; ++id)
+        PTRY(ntt_device(c, p->polys + id * np, p->evals8 + id * qn + k * n, p->tmp8, L, false, true, p->poly_len[id], &p->cs_fwd[k]));
+      PTRY(ntt_device(c, p->scratch, p->evals8 + P_COUNT * qn + k * n, p->tmp8, L, false, true, 2, &p->cs_fwd[k]));
+      L1Args lj = l1a;
+      for (int i = 0; i < 8; ++i) lj.vh[i] = l1a.vh[j];   // X^n - 1 is constant on a class
+      PTRY(poly_l1(c, p->evals8 + P_COUNT * qn + k * n, p->evals8 + (P_COUNT + 1) * qn + k * n, n, lj));
+    }
+  }
+  // ... 4 sigma FFTs on n (prover.rs:95-100)
+  for (int k = 0; k < 4; ++k)
+    PTRY(ntt_device(c, p->polys + (P_S1 + k) * np, p->sigma_n + k * n, p->tmp8, L, false, false, p->poly_len[P_S1 + k]));
   // pre-scaling for the reduced-radix quotient kernel (poly.hip): q_m * 2^10; q_l q_r q_o q_f q_arith, L1 * 2^5
   {
     const Fr s5 = Fr::from_u64(32), s10 = Fr::from_u64(1024);
-    PTRY(poly_scale_array(c, p->evals8 + P_QM * n8, n8, s10));
+    PTRY(poly_scale_array(c, p->evals8 + P_QM * qn, qn, s10));
     const int five[] = {P_QL, P_QR, P_QO, P_QF, P_QARITH, P_COUNT + 1};
-    for (int id : five) PTRY(poly_scale_array(c, p->evals8 + (uint64_t)id * n8, n8, s5));
+    for (int id : five) PTRY(poly_scale_array(c, p->evals8 + (uint64_t)id * qn, qn, s5));
   }
 
   // ---- verifier-key commitments for transcript seeding
@@ -336,8 +416,12 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   return PLONK_OK;
 }
 
+static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
+                                const Fr* bl, uint8_t proof[1008]);
+
 static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
                         const Fr* bl, uint8_t proof[1008]) {
+  if (p->sharded) return prover_prove_sharded(p, wires_dev, pi_idx, pi_val, pi_count, bl, proof);
   Ctx* c = p->c;
   // the commit key of the context was replaced after this prover was built (plonk_srs_load /
   // plonk_prover_from_bytes): its degree bounds and shard ranges no longer describe the tables
@@ -712,6 +796,390 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   return PLONK_OK;
 }
 
+// ---- multi-GPU prove(): the same transcript on every rank, the work split as described at
+// Prover::sharded.  Replicated: the wire / permutation polynomials (rounds 1-2: 5 size-n inverse
+// transforms and the grand product).  Sharded: every MSM (SRS point range), the quotient (residue
+// classes of the coset), evaluations, linearisation and opening quotients (coefficient range).
+// Exchanges per proof: 4 all-gathers of MSM partial sums, 1 all-to-all of the class remainders,
+// 1 all-gather of 15 partial evaluations, 1 all-gather of two suffix-sum carries.
+static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
+                                const Fr* bl, uint8_t proof[1008]) {
+  Ctx* c = p->c;
+  if (p->srs_gen != c->srs_gen) return (set_last_error("prover is bound to an SRS that was replaced on its context", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
+  const uint64_t n = p->n, np = p->np, qn = p->qn;
+  const uint32_t L = p->logn, W = (uint32_t)p->world, cpr = p->cpr, Q = p->Q;
+  const uint64_t lo = p->lo, hi = p->hi;                       // owned coefficient indices, hi <= n + 7
+  NttTables* tbn;
+  PTRY(ntt_tables(c, L, false, &tbn));
+  const Fr omega = p->omega, one = Fr::one();
+  auto own_len = [&](uint64_t len) -> uint64_t {               // coefficients of a length-`len` polynomial inside [lo, hi)
+    const uint64_t e = len < hi ? len : hi;
+    return e > lo ? e - lo : 0;
+  };
+
+  Transcript tr((const uint8_t*)p->label.data(), p->label.size());
+  tr.circuit_domain_sep(p->constraints);
+  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[VK_ORDER[k]]);
+  tr.circuit_domain_sep(p->constraints);
+  for (uint64_t i = 0; i < pi_count; ++i) tr.append_scalar("pi", pi_val[i]);
+
+  uint8_t comm[11][48];
+  // ---- round 1 (replicated polynomials, sharded commitments)
+  for (int k = 0; k < 4; ++k) {
+    Fr* wp = p->wpoly + k * np;
+    PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
+    BlindArgs ba;
+    ba.count = 2;
+    ba.b[0] = bl[2 * k];
+    ba.b[1] = bl[2 * k + 1];
+    PTRY(poly_fill_zero(c, wp + n, np - n));
+    PTRY(poly_blind(c, wp, n, ba));
+  }
+  SideJoin side_join{c};
+  uint64_t pi_len = 0;
+  for (int k = 0; k < 4; ++k)
+    HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+  Fr* fold_side = p->fold + n;
+  {
+    // class evaluations of a, b, c, d, PI on the side stream: fold mod (X^n - x^n|class), size-n coset transform
+    SideScope side(c, p->ev_ready);
+    for (uint32_t k = 0; k < cpr; ++k)
+      for (int w = 0; w < 4; ++w) {
+        PTRY(poly_fold(c, p->wpoly + w * np, fold_side, n, 2, p->sigma_j[p->cls[k]]));
+        PTRY(ntt_device(c, fold_side, p->cos + (1 + w) * qn + k * n, p->tmp8b, L, false, true, n, &p->cs_fwd[k]));
+      }
+    PTRY(poly_fill_zero(c, p->pipoly, np));
+    if (pi_count) {
+      if (pi_count > p->pi_cap) {
+        if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); }
+        HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
+        HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
+        p->pi_cap = pi_count;
+      }
+      for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+      HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
+      PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
+      PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8b, L, true, false, n));
+      pi_len = n;
+    }
+    HIP_TRY(hipMemcpyAsync(p->low_host + 35, p->pipoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(p->ev_pi, c->stream));
+    if (pi_len)
+      for (uint32_t k = 0; k < cpr; ++k)
+        PTRY(ntt_device(c, p->pipoly, p->cos + 5 * qn + k * n, p->tmp8b, L, false, true, n, &p->cs_fwd[k]));
+  }
+  {
+    const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
+    const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
+    PTRY(msm_group(p, sc, ms, 4, 0));
+  }
+  PTRY(fetch_commitments(p, 0, 4, comm));
+  tr.append_commitment("a_comm", comm[0]);
+  tr.append_commitment("b_comm", comm[1]);
+  tr.append_commitment("c_comm", comm[2]);
+  tr.append_commitment("d_comm", comm[3]);
+
+  // ---- round 2 (replicated grand product)
+  const Fr beta = tr.challenge_scalar("beta");
+  tr.append_scalar("beta", beta);
+  const Fr gamma = tr.challenge_scalar("gamma");
+  {
+    PermArgs pa;
+    pa.n = n;
+    for (int k = 0; k < 4; ++k) { pa.wires[k] = wires_dev + k * n; pa.sigma[k] = p->sigma_n + k * n; }
+    pa.beta = beta; pa.gamma = gamma;
+    pa.ks[0] = Fr::one(); pa.ks[1] = fr_small(7); pa.ks[2] = fr_small(13); pa.ks[3] = fr_small(17);
+    pa.tw_lo29 = tbn->tw_lo29; pa.tw_hi29 = tbn->tw_hi29; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
+    pa.num = p->scratch; pa.den = p->scratch + np;
+    HIP_TRY(hipMemsetAsync(p->flag_dev, 0, sizeof(int), c->stream));
+    PTRY(poly_perm_terms(c, pa));
+    PTRY(poly_batch_inverse(c, pa.den, n, true));
+    PTRY(poly_mul_arrays(c, pa.num, pa.den, n, p->flag_dev));
+    PTRY(scan_prefix_product(c, pa.num, n, p->totals));
+    PTRY(ntt_device(c, pa.num, p->zpoly, p->tmp8, L, true, false, n));
+    BlindArgs ba;
+    ba.count = 3;
+    ba.b[0] = bl[8]; ba.b[1] = bl[9]; ba.b[2] = bl[10];
+    PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
+    PTRY(poly_blind(c, p->zpoly, n, ba));
+  }
+  HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+  {
+    SideScope side(c, p->ev_ready);
+    for (uint32_t k = 0; k < cpr; ++k) {
+      PTRY(poly_fold(c, p->zpoly, fold_side, n, 3, p->sigma_j[p->cls[k]]));
+      PTRY(ntt_device(c, fold_side, p->cos + k * n, p->tmp8b, L, false, true, n, &p->cs_fwd[k]));
+    }
+    HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+  }
+  PTRY(msm_to(p, p->zpoly, n + 3, 4));
+  PTRY(fetch_commitments(p, 4, 1, comm + 4));
+  tr.append_commitment("z_comm", comm[4]);
+
+  // ---- round 3: quotient on the owned classes
+  const Fr alpha = tr.challenge_scalar("alpha");
+  const Fr range_ch = tr.challenge_scalar("range separation challenge");
+  const Fr logic_ch = tr.challenge_scalar("logic separation challenge");
+  const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
+  const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
+  const Fr edwards_d = p->edwards_d;
+  HIP_TRY(hipStreamWaitEvent(c->main_stream, p->ev_side, 0));
+  for (uint32_t k = 0; k < cpr; ++k) {
+    QuotientArgs q;
+    q.n8 = n;
+    q.rot = 1;                                                 // X -> omega X is the next point of the class
+    const Fr* co = p->cos + k * n;
+    q.z = co; q.a = co + qn; q.b = co + 2 * qn; q.c = co + 3 * qn; q.d = co + 4 * qn; q.pi = pi_len ? co + 5 * qn : nullptr;
+    const Fr* e = p->evals8 + k * n;
+    q.q_m = e + P_QM * qn; q.q_l = e + P_QL * qn; q.q_r = e + P_QR * qn; q.q_o = e + P_QO * qn; q.q_f = e + P_QF * qn;
+    q.q_c = e + P_QC * qn; q.q_arith = e + P_QARITH * qn; q.q_range = e + P_QRANGE * qn; q.q_logic = e + P_QLOGIC * qn;
+    q.q_fixed = e + P_QFIXED * qn; q.q_var = e + P_QVAR * qn;
+    q.s1 = e + P_S1 * qn; q.s2 = e + P_S2 * qn; q.s3 = e + P_S3 * qn; q.s4 = e + P_S4 * qn;
+    q.linear = e + P_COUNT * qn; q.l1 = e + (P_COUNT + 1) * qn;
+    for (int s = 0; s < QS_COUNT; ++s) q.has[s] = p->has[s];
+    q.range_ch = range_ch; q.logic_ch = logic_ch; q.fixed_ch = fixed_ch; q.var_ch = var_ch;
+    q.edwards_d = edwards_d;
+    q.inv32 = p->inv32;
+    quotient_data(gamma, q.k.gamma);
+    quotient_data(Fr::one(), q.k.one);
+    const Fr ks[4] = {Fr::one(), fr_small(7), fr_small(13), fr_small(17)};
+    for (int i = 0; i < 4; ++i) quotient_const(beta * ks[i], 0, q.k.beta_k[i]);
+    quotient_const(alpha, 20, q.k.alpha_pos);
+    quotient_const(alpha.neg(), 20, q.k.alpha_neg);
+    quotient_const(alpha.sqr(), 0, q.k.alpha_sq);
+    for (int i = 0; i < 8; ++i) quotient_const(p->vinv[p->cls[k]], 0, q.k.vinv[i]);   // 1 / (x^n - 1): constant on a class
+    q.out = p->Fbuf + (uint64_t)k * n;
+    PTRY(poly_quotient(c, q));
+    // t mod (X^n - x^n|class): size-n inverse coset transform with the class shift
+    PTRY(ntt_device(c, q.out, q.out, p->tmp8, L, true, true, n, &p->cs_inv[k]));
+  }
+  Fr* t4 = p->tbuf;                                            // t_fourth, indexed by coefficient
+  {
+    ShardPackArgs pk{};
+    for (uint32_t k = 0; k < cpr; ++k) pk.F[k] = p->Fbuf + (uint64_t)k * n;
+    pk.send = p->send; pk.n = n; pk.per = p->per; pk.stride = p->stride; pk.cpr = cpr;
+    PTRY(poly_shard_pack(c, pk, W));
+    PTRY(comm_alltoall_dev(c, p->link, p->send, p->recv, sizeof(Fr) * (size_t)cpr * p->stride));
+    ShardCombineArgs cb{};
+    cb.recv = p->recv; cb.stride = p->stride; cb.per = p->per; cb.lo = lo; cb.hi = hi; cb.n = n;
+    cb.cnt = (hi < n ? hi : n) > lo ? (hi < n ? hi : n) - lo : 0;
+    cb.W = W; cb.cpr = cpr; cb.Q = Q;
+    for (int i1 = 0; i1 < 5; ++i1) for (int j = 0; j < 8; ++j) cb.coef[i1][j] = p->coef[i1][j];
+    if (Q == 4) {   // de-alias with the host-computed low coefficients, as on one GPU (quotient_low)
+      HIP_TRY(hipEventSynchronize(p->ev_pi));
+      QuotientLowIn qi;
+      qi.low = p->low_host;
+      qi.alpha = alpha; qi.beta = beta; qi.gamma = gamma;
+      qi.range_ch = range_ch; qi.logic_ch = logic_ch; qi.fixed_ch = fixed_ch; qi.var_ch = var_ch;
+      qi.edwards_d = edwards_d; qi.omega = omega; qi.n_inv = p->n_inv;
+      quotient_low(p->key_low, p->has, qi, cb.low);
+    }
+    cb.g4n_inv = p->gq_inv;
+    cb.parts[0] = p->tparts; cb.parts[1] = p->tparts + np; cb.parts[2] = p->tparts + 2 * np; cb.parts[3] = t4;
+    PTRY(poly_shard_combine(c, cb));
+    ShardSplitFix sf{};
+    for (int i = 0; i < 4; ++i) sf.parts[i] = cb.parts[i];
+    sf.lo = lo; sf.hi = hi; sf.n = n;
+    sf.b[0] = bl[11]; sf.b[1] = bl[12]; sf.b[2] = bl[13];
+    PTRY(poly_shard_split_fix(c, sf));
+  }
+  HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  const uint64_t t4_len = n + 7;   // t has 4n + 7 coefficients by construction (prover.hip, 4n path); explicit zeros do not change a commitment
+  {
+    const Fr* sc[4] = {p->tparts, p->tparts + np, p->tparts + 2 * np, t4};
+    const uint64_t ms[4] = {n + 1, n + 1, n + 1, t4_len};
+    PTRY(msm_group(p, sc, ms, 4, 5));
+  }
+  PTRY(fetch_commitments(p, 5, 4, comm + 5));
+  if (*p->flag_host) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  tr.append_commitment("t_low_comm", comm[5]);
+  tr.append_commitment("t_mid_comm", comm[6]);
+  tr.append_commitment("t_high_comm", comm[7]);
+  tr.append_commitment("t_fourth_comm", comm[8]);
+
+  // ---- round 4: every rank evaluates its coefficient range, partial sums are all-gathered
+  const Fr z_ch = tr.challenge_scalar("z_challenge");
+  const Fr zw = z_ch * omega;
+  Evals ev;
+  {
+    EvalArgs ea;
+    ea.partial = p->evpart;
+    ea.max_blocks = p->ev_max_blocks;
+    const Fr* P = p->polys;
+    const Fr* pol[15] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np,
+                         p->wpoly, p->wpoly + np, p->wpoly + 3 * np,
+                         P + P_QARITH * np, P + P_QC * np, P + P_QL * np, P + P_QR * np,
+                         P + P_S1 * np, P + P_S2 * np, P + P_S3 * np, p->zpoly};
+    const uint64_t len[15] = {n + 2, n + 2, n + 2, n + 2, n + 2, n + 2, n + 2,
+                              p->poly_len[P_QARITH], p->poly_len[P_QC], p->poly_len[P_QL], p->poly_len[P_QR],
+                              p->poly_len[P_S1], p->poly_len[P_S2], p->poly_len[P_S3], n + 3};
+    uint64_t max_len = 1;
+    for (int k = 0; k < 15; ++k) {
+      ea.items[k].poly = pol[k] + lo;
+      ea.items[k].len = own_len(len[k]);
+      ea.items[k].x = (k >= 4 && k <= 6) || k == 14 ? zw : z_ch;
+      if (ea.items[k].len > max_len) max_len = ea.items[k].len;
+    }
+    PTRY(poly_eval(c, ea, 15, max_len, p->evout));
+    HIP_TRY(hipMemcpyAsync(p->ev_host, p->evout, 15 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<Fr> all(15 * (size_t)W);
+    PTRY(comm_allgather_host(c, p->link, p->ev_host, all.data(), 15 * sizeof(Fr)));
+    Fr h[15];
+    for (int k = 0; k < 15; ++k) h[k] = Fr::zero();
+    for (uint32_t r = 0; r < W; ++r) {                         // sum_r x^(lo_r) * partial_r
+      uint64_t lo_r = p->per * r;
+      if (lo_r > n + 7) lo_r = n + 7;
+      const Fr pz = z_ch.pow_u64(lo_r), pzw = zw.pow_u64(lo_r);
+      for (int k = 0; k < 15; ++k) h[k] = h[k] + all[15 * r + k] * (((k >= 4 && k <= 6) || k == 14) ? pzw : pz);
+    }
+    ev.a = h[0]; ev.b = h[1]; ev.c = h[2]; ev.d = h[3]; ev.a_w = h[4]; ev.b_w = h[5]; ev.d_w = h[6];
+    ev.q_arith = h[7]; ev.q_c = h[8]; ev.q_l = h[9]; ev.q_r = h[10]; ev.s1 = h[11]; ev.s2 = h[12]; ev.s3 = h[13]; ev.z = h[14];
+  }
+  tr.append_scalar("a_eval", ev.a);
+  tr.append_scalar("b_eval", ev.b);
+  tr.append_scalar("c_eval", ev.c);
+  tr.append_scalar("d_eval", ev.d);
+  tr.append_scalar("s_sigma_1_eval", ev.s1);
+  tr.append_scalar("s_sigma_2_eval", ev.s2);
+  tr.append_scalar("s_sigma_3_eval", ev.s3);
+  tr.append_scalar("z_eval", ev.z);
+  tr.append_scalar("a_w_eval", ev.a_w);
+  tr.append_scalar("b_w_eval", ev.b_w);
+  tr.append_scalar("d_w_eval", ev.d_w);
+  tr.append_scalar("q_arith_eval", ev.q_arith);
+  tr.append_scalar("q_c_eval", ev.q_c);
+  tr.append_scalar("q_l_eval", ev.q_l);
+  tr.append_scalar("q_r_eval", ev.q_r);
+
+  // ---- round 5: linearisation + both opening quotients on the owned coefficient range
+  const Fr v = tr.challenge_scalar("v_challenge");
+  const Fr v_w = tr.challenge_scalar("v_w_challenge");        // W_z's commitment is not absorbed before it (prover.rs:727-730)
+  const Fr z_n = z_ch.pow_u64(n);
+  const Fr zh = z_n - one;
+  const Fr n_inv = p->n_inv;
+  if (z_ch.is_zero() || zw.is_zero()) return PLONK_ERR_STATE;   // probability 2^-255
+  const Fr zm1 = z_ch - one;
+  const Fr iab = (z_ch * (zm1.is_zero() ? one : zm1)).inv();
+  const Fr inv_z = iab * (zm1.is_zero() ? one : zm1), inv_zm1 = iab * z_ch;
+  Fr pi_eval = Fr::zero();
+  if (pi_count) {
+    std::vector<Fr> den(pi_count), pre(pi_count);
+    Fr run = one;
+    for (uint64_t i = 0; i < pi_count; ++i) {
+      den[i] = p->omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
+      pre[i] = run;
+      if (!pi_val[i].is_zero() && !den[i].is_zero()) run = run * den[i];
+    }
+    Fr inv = run.inv(), acc = Fr::zero();
+    for (uint64_t i = pi_count; i-- > 0;) {
+      if (pi_val[i].is_zero() || den[i].is_zero()) continue;
+      acc = acc + inv * pre[i] * pi_val[i];
+      inv = inv * den[i];
+    }
+    pi_eval = acc * (zh * n_inv);
+  }
+  const Fr bz = beta * z_ch;
+  const Fr lin_a = (ev.a + bz + gamma) * (ev.b + fr_small(7) * bz + gamma) * (ev.c + fr_small(13) * bz + gamma) *
+                   (ev.d + fr_small(17) * bz + gamma) * alpha;
+  const Fr lin_b = (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) * (ev.c + beta * ev.s3 + gamma) *
+                   (beta * ev.z) * alpha;
+  Fr l1_z;
+  if (z_n == one) l1_z = (z_ch == one) ? one : Fr::zero();
+  else l1_z = zh * n_inv * inv_zm1;
+  const Fr c_range = range_identity(range_ch, ev) * range_ch;
+  const Fr c_logic = logic_identity(logic_ch, ev) * logic_ch;
+  const Fr c_fixed = fixed_identity(fixed_ch, ev, edwards_d) * fixed_ch;
+  const Fr c_var = var_identity(var_ch, ev, edwards_d) * var_ch;
+  const Fr nzh = zh.neg();
+  Fr vp[12];
+  vp[0] = one;
+  for (int k = 1; k < 12; ++k) vp[k] = vp[k - 1] * v;
+  const uint64_t rlen = hi - lo;                               // owned part of the n + 7 numerator coefficients
+  {
+    LinCombArgs la;
+    int k = 0;
+    const Fr* P = p->polys;
+    auto term = [&](const Fr* ptr, uint64_t len, const Fr& s) { la.t[k].p = ptr + lo; la.t[k].len = own_len(len); la.t[k].s = s; ++k; };
+    term(P + P_QM * np, p->poly_len[P_QM], ev.q_arith * ev.a * ev.b);
+    term(P + P_QL * np, p->poly_len[P_QL], ev.q_arith * ev.a + vp[10]);
+    term(P + P_QR * np, p->poly_len[P_QR], ev.q_arith * ev.b + vp[11]);
+    term(P + P_QO * np, p->poly_len[P_QO], ev.q_arith * ev.c);
+    term(P + P_QF * np, p->poly_len[P_QF], ev.q_arith * ev.d);
+    term(P + P_QC * np, p->poly_len[P_QC], ev.q_arith + vp[9]);
+    term(P + P_QARITH * np, p->poly_len[P_QARITH], vp[8]);
+    term(P + P_QRANGE * np, p->poly_len[P_QRANGE], c_range);
+    term(P + P_QLOGIC * np, p->poly_len[P_QLOGIC], c_logic);
+    term(P + P_QFIXED * np, p->poly_len[P_QFIXED], c_fixed);
+    term(P + P_QVAR * np, p->poly_len[P_QVAR], c_var);
+    term(P + P_S1 * np, p->poly_len[P_S1], vp[5]);
+    term(P + P_S2 * np, p->poly_len[P_S2], vp[6]);
+    term(P + P_S3 * np, p->poly_len[P_S3], vp[7]);
+    term(P + P_S4 * np, p->poly_len[P_S4], lin_b.neg());
+    term(p->zpoly, n + 3, lin_a + l1_z * alpha.sqr());
+    term(p->wpoly, n + 2, vp[1]);
+    term(p->wpoly + np, n + 2, vp[2]);
+    term(p->wpoly + 2 * np, n + 2, vp[3]);
+    term(p->wpoly + 3 * np, n + 2, vp[4]);
+    term(p->tparts, n + 1, nzh);
+    term(p->tparts + np, n + 1, nzh * z_n);
+    term(p->tparts + 2 * np, n + 1, nzh * z_n.sqr());
+    term(t4, t4_len, nzh * z_n.sqr() * z_n);
+    la.count = k;
+    la.len = rlen;
+    la.constant = lo == 0 ? pi_eval : Fr::zero();
+    la.out = p->agg + lo;
+    if (rlen) PTRY(poly_lincomb(c, la));
+  }
+  PTRY(poly_ruffini_local(c, p->agg + lo, lo, rlen, z_ch, p->scratch, p->totals));
+  {
+    LinCombArgs la;
+    la.t[0].p = p->zpoly + lo; la.t[0].len = own_len(n + 3); la.t[0].s = one;
+    la.t[1].p = p->wpoly + lo; la.t[1].len = own_len(n + 2); la.t[1].s = v_w;
+    la.t[2].p = p->wpoly + np + lo; la.t[2].len = own_len(n + 2); la.t[2].s = v_w.sqr();
+    la.t[3].p = p->wpoly + 3 * np + lo; la.t[3].len = own_len(n + 2); la.t[3].s = v_w.sqr() * v_w;
+    la.count = 4;
+    la.len = rlen;
+    la.constant = Fr::zero();
+    la.out = p->agg2 + lo;
+    if (rlen) PTRY(poly_lincomb(c, la));
+  }
+  PTRY(poly_ruffini_local(c, p->agg2 + lo, lo, rlen, zw, p->scratch2, p->totals));
+  // the suffix sums of the ranges above this one: all-gather of (total_z, total_zw) per rank
+  HIP_TRY(hipMemcpyAsync(p->ev_host, p->scratch, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(p->ev_host + 1, p->scratch2, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::vector<Fr> tot(2 * (size_t)W);
+  PTRY(comm_allgather_host(c, p->link, p->ev_host, tot.data(), 2 * sizeof(Fr)));
+  Fr carry_z = Fr::zero(), carry_zw = Fr::zero(), num_at_z = Fr::zero();
+  for (uint32_t r = 0; r < W; ++r) {
+    num_at_z = num_at_z + tot[2 * r];
+    if (r > (uint32_t)p->rank) { carry_z = carry_z + tot[2 * r]; carry_zw = carry_zw + tot[2 * r + 1]; }
+  }
+  PTRY(poly_ruffini_finish(c, p->scratch, p->wit, lo, rlen, inv_z, carry_z, n + 6));
+  PTRY(poly_ruffini_finish(c, p->scratch2, p->wit2, lo, rlen, inv_z * p->omega_inv, carry_zw, n + 6));
+  {
+    const Fr* sc[2] = {p->wit, p->wit2};
+    const uint64_t ms[2] = {np - 2, np - 2};
+    PTRY(msm_group(p, sc, ms, 2, 9));
+  }
+  PTRY(fetch_commitments(p, 9, 2, comm + 9));
+  {
+    // quotient identity at z (see prover_prove): a mismatch means the witness does not satisfy the circuit
+    Fr expect = alpha.sqr() * l1_z + (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) *
+                                         (ev.c + beta * ev.s3 + gamma) * (ev.d + gamma) * ev.z * alpha;
+    const Fr* evs[11] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.s1, &ev.s2, &ev.s3, &ev.q_arith, &ev.q_c, &ev.q_l, &ev.q_r};
+    for (int k = 0; k < 11; ++k) expect = expect + vp[k + 1] * *evs[k];
+    if (num_at_z != expect) return PLONK_ERR_UNSAT;
+  }
+  memcpy(proof, comm, 11 * 48);
+  const Fr* order[15] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.a_w, &ev.b_w, &ev.d_w, &ev.q_arith, &ev.q_c, &ev.q_l,
+                         &ev.q_r, &ev.s1, &ev.s2, &ev.s3, &ev.z};
+  for (int k = 0; k < 15; ++k) fr_to_bytes(*order[k], proof + 11 * 48 + 32 * k);
+  return PLONK_OK;
+}
+
 }  // namespace plonk
 
 using namespace plonk;
@@ -761,8 +1229,8 @@ int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t cou
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   const Fr* base[] = {p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tparts, p->agg, p->wit,
                       p->evals8, p->sigma_n, p->scratch, p->evout, p->polys};
-  const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->n8, p->n8, 3 * p->np, p->np, p->np,
-                          (uint64_t)(P_COUNT + 2) * p->n8, 4 * p->n, 2 * p->np, 16, (uint64_t)P_COUNT * p->np};
+  const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->qn, p->sharded ? p->np : p->n8, 3 * p->np, p->np, p->np,
+                          (uint64_t)(P_COUNT + 2) * p->qn, 4 * p->n, 2 * p->np, 16, (uint64_t)P_COUNT * p->np};
   if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   HIP_TRY(hipMemcpyAsync(out, base[which] + offset, sizeof(Fr) * count, hipMemcpyDeviceToHost, p->c->stream));

@@ -1,7 +1,10 @@
-"""GPU, 2 ranks on ONE device (gloo exchange): the point-range-sharded prove() of bench.py
-must output the same Proof bytes as the single-GPU run.  Exercises prover.hip's msm_group /
-fetch_commitments all-gather path and the ctypes exchange callback on real hardware (RCCL
-itself cannot run two ranks on one device; the driver's 2/4/8-GPU runs use backend nccl)."""
+"""GPU, several ranks on ONE device: the multi-GPU prove() of prover.hip (prover_prove_sharded) must output
+the same Proof bytes as the single-GPU run — MSMs sharded by SRS point range, the quotient by residue
+class of the coset, rounds 4-5 by coefficient range.  The exchanges go through the library's host-callback
+transport over gloo here (RCCL refuses two ranks on one device); the driver's 2/4/8-GPU runs use the
+RCCL transport inside the library, which differs only in how the same buffers travel.  The RCCL code
+path itself (dlopen, communicator, both collectives on the library's stream) is exercised with a
+one-rank communicator."""
 import json
 import os
 import subprocess
@@ -22,27 +25,69 @@ def _run(cmd, env=None):
     return json.loads(line)
 
 
-@pytest.mark.parametrize("ranks,log_gates", [(2, 12), (3, 13)])
-def test_sharded_prove_matches_single_gpu(ranks, log_gates):
-    single = _run([sys.executable, "bench.py", "--log-gates", str(log_gates), "--steps", "1", "--warmup", "0",
-                   "--no-cpu-baseline"])
-    multi = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
-                  "--master-addr", "127.0.0.1", "--master-port", str(29600 + ranks), "bench.py", "--gpus", str(ranks),
-                  "--log-gates", str(log_gates), "--steps", "1", "--warmup", "0"],
-                 {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
-    assert multi["n_gpus"] == ranks and single["n_gpus"] == 1
-    assert multi["proof_blake2b"] == single["proof_blake2b"]
+_single = {}
+
+
+def single(log_gates, profile):
+    key = (log_gates, profile)
+    if key not in _single:
+        _single[key] = _run([sys.executable, "bench.py", "--log-gates", str(log_gates), "--steps", "1", "--warmup", "0",
+                             "--profile", profile, "--no-cpu-baseline", "--no-extras"])
+    return _single[key]
+
+
+def multi(ranks, log_gates, profile, env):
+    return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
+                 "--master-addr", "127.0.0.1", "--master-port", str(29600 + ranks), "bench.py", "--gpus", str(ranks),
+                 "--log-gates", str(log_gates), "--steps", "1", "--warmup", "1", "--profile", profile, "--no-extras"], env)
+
+
+@pytest.mark.parametrize("ranks,log_gates,profile", [(2, 13, "widgets"), (4, 13, "widgets"), (8, 13, "widgets"),
+                                                      (4, 16, "dense"), (2, 12, "bench-like")])
+def test_sharded_quotient_prove_matches_single_gpu(ranks, log_gates, profile):
+    """world in {2, 4, 8}: class-sharded quotient (Q = 4 classes, 8 for world 8), every widget + public inputs."""
+    s = single(log_gates, profile)
+    m = multi(ranks, log_gates, profile, {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
+    assert m["n_gpus"] == ranks and s["n_gpus"] == 1 and m["config"]["collective"] == "gloo"
+    assert "residue class" in m["config"]["parallelism"]
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
+@pytest.mark.parametrize("ranks,log_gates,env", [(3, 13, {}), (2, 12, {"PLONK_SHARD_QUOTIENT": "0"})])
+def test_msm_only_sharding_matches_single_gpu(ranks, log_gates, env):
+    """other world sizes / PLONK_SHARD_QUOTIENT=0: only the MSMs are sharded (round-1 path)."""
+    s = single(log_gates, "dense")
+    e = {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"}
+    e.update(env)
+    m = multi(ranks, log_gates, "dense", e)
+    assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
 def test_default_backend_self_test_and_fallback():
-    """`bench.py --gpus 2` as the driver launches it (backend nccl = RCCL).  On this 1-GPU box both
-    ranks share the device, which RCCL refuses: the self-test must notice, every rank must agree
-    on the gloo fallback, and the proof must still equal the single-GPU one.  (On a real multi-GPU
-    node the same code path reports "collective": "rccl".)"""
-    single = _run([sys.executable, "bench.py", "--log-gates", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
-    multi = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                  "--master-addr", "127.0.0.1", "--master-port", "29611", "bench.py", "--gpus", "2",
-                  "--log-gates", "12", "--steps", "1", "--warmup", "0"],
-                 {"PLONK_BENCH_SHARE_GPU": "1"})
-    assert multi["config"]["collective"] in ("rccl", "gloo")
-    assert multi["proof_blake2b"] == single["proof_blake2b"]
+    """`bench.py --gpus 2` as the driver launches it (RCCL inside the library).  On this 1-GPU box both ranks
+    share the device, which RCCL refuses: the bring-up must notice, every rank must agree on the gloo
+    transport, and the proof must still equal the single-GPU one.  (On a real multi-GPU node the same
+    code path reports "collective": "rccl".)"""
+    s = single(12, "dense")
+    m = multi(2, 12, "dense", {"PLONK_BENCH_SHARE_GPU": "1"})
+    assert m["config"]["collective"] in ("rccl", "gloo")
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
+def test_rccl_transport_single_rank_communicator():
+    """plonk_comm_unique_id / plonk_comm_init / plonk_comm_selftest with world = 1: RCCL is found and loaded,
+    the communicator comes up on the context's device and ncclAllGather / ncclAllToAll run on the library's
+    stream; a second init on the same context is refused; after destroy the context is reusable."""
+    import plonk_amd
+    ctx = plonk_amd.Context(0)
+    uid = plonk_amd.Context.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    ctx.comm_init(uid, 0, 1)
+    ctx.comm_selftest()
+    with pytest.raises(plonk_amd.PlonkError):
+        ctx.comm_init(uid, 0, 1)
+    ctx.comm_destroy()
+    with pytest.raises(plonk_amd.PlonkError):
+        ctx.comm_selftest()
+    assert ctx.ntt([1, 2, 3, 4], 2) is not None
+    ctx.close()
