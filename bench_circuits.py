@@ -45,59 +45,92 @@ def _omega_table(log_n):
     return T
 
 
-def arithmetic_circuit(log_n: int, profile: str = "dense"):
-    """Chain of n arithmetic gates: the output of gate i is wired to input a of gate i + 1 (sigma_1, sigma_3
-    non-trivial), q_O = -1, q_arith = 1.  `dense`: random selectors, the output follows.  `bench-like`: the
-    wire values are drawn first (half of them < 4), q_C is solved for so that each gate holds.
-    Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, trivial polys {name: [ints]})."""
-    n = 1 << log_n
+def _arith_chunk(args):
+    """rows [0, cnt) of an independent gate chain (own RNG stream); returns the nine columns as lists"""
+    profile, seed, cnt = args
+    rnd = random.Random(seed)
+    rb = rnd.getrandbits
     if profile == "dense":
-        rnd = random.Random(0x5EED0001)
-        rb = rnd.getrandbits
-        a = [0] * n
-        b = [rb(254) % Q for _ in range(n)]
-        d = [rb(254) % Q for _ in range(n)]
-        qm = [rb(254) % Q for _ in range(n)]
-        ql = [rb(254) % Q for _ in range(n)]
-        qr = [rb(254) % Q for _ in range(n)]
-        qf = [rb(254) % Q for _ in range(n)]
-        qc = [rb(254) % Q for _ in range(n)]
-        c = [0] * n
+        a = [0] * cnt
+        b = [rb(254) % Q for _ in range(cnt)]
+        d = [rb(254) % Q for _ in range(cnt)]
+        qm = [rb(254) % Q for _ in range(cnt)]
+        ql = [rb(254) % Q for _ in range(cnt)]
+        qr = [rb(254) % Q for _ in range(cnt)]
+        qf = [rb(254) % Q for _ in range(cnt)]
+        qc = [rb(254) % Q for _ in range(cnt)]
+        c = [0] * cnt
         cur = rb(254) % Q
-        for i in range(n):
+        for i in range(cnt):
             a[i] = cur
             bi = b[i]
             # all values are Montgomery forms: c~ = (qm~ a~ b~ R^-2 + ql~ a~ R^-1 + qr~ b~ R^-1 + qf~ d~ R^-1 + qc~)
             cur = ((qm[i] * cur % Q * bi % Q * RINV + ql[i] * cur + qr[i] * bi + qf[i] * d[i]) % Q * RINV + qc[i]) % Q
             c[i] = cur
     elif profile == "bench-like":
-        rnd = random.Random(0x5EED0002)
-        rb = rnd.getrandbits
-
         def val():      # half small (< 4), half uniform — Montgomery form of the value
             return (rb(2) * R) % Q if rb(1) else rb(254) % Q
-        b = [val() for _ in range(n)]
-        d = [val() for _ in range(n)]
-        c = [val() for _ in range(n)]
+        b = [val() for _ in range(cnt)]
+        d = [val() for _ in range(cnt)]
+        c = [val() for _ in range(cnt)]
         a = [val()] + c[:-1]
-        qm = [rb(254) % Q for _ in range(n)]
-        ql = [rb(254) % Q for _ in range(n)]
-        qr = [rb(254) % Q for _ in range(n)]
-        qf = [rb(254) % Q for _ in range(n)]
-        qc = [0] * n
-        for i in range(n):
+        qm = [rb(254) % Q for _ in range(cnt)]
+        ql = [rb(254) % Q for _ in range(cnt)]
+        qr = [rb(254) % Q for _ in range(cnt)]
+        qf = [rb(254) % Q for _ in range(cnt)]
+        qc = [0] * cnt
+        for i in range(cnt):
             lhs = (qm[i] * a[i] % Q * b[i] % Q * RINV + ql[i] * a[i] + qr[i] * b[i] + qf[i] * d[i]) % Q * RINV % Q
             qc[i] = (c[i] - lhs) % Q
     else:
         raise ValueError(profile)
-    wires = [_bytes(col) for col in (a, b, c, d)]
+    return [_bytes(col) for col in (a, b, c, d, qm, ql, qr, qf, qc)]
+
+
+def arithmetic_circuit(log_n: int, profile: str = "dense", workers: int = 0):
+    """Chains of arithmetic gates: the output of gate i is wired to input a of gate i + 1 (sigma_1, sigma_3
+    non-trivial), q_O = -1, q_arith = 1.  `dense`: random selectors, the output follows.  `bench-like`: the
+    wire values are drawn first (half of them < 4), q_C is solved for so that each gate holds.
+    Up to 2^20 gates it is ONE chain from one RNG stream (the headline workload, stable proof digest); above,
+    the rows are 2^20-gate chains with their own streams, generated in `workers` processes when asked.
+    Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, trivial polys {name: [ints]})."""
+    n = 1 << log_n
+    seed0 = {"dense": 0x5EED0001, "bench-like": 0x5EED0002}[profile]
+    seg = min(n, 1 << 20)
+    jobs = [(profile, seed0 + 0x10000 * k, seg) for k in range(n // seg)]
+    if workers > 1 and len(jobs) > 1:
+        # plain subprocesses of this file (no multiprocessing: nothing depends on the caller's __main__, no fork of a
+        # process that holds a GPU context); each writes its nine columns to a file
+        import os
+        import subprocess
+        import sys
+        import tempfile
+        parts = [None] * len(jobs)
+        with tempfile.TemporaryDirectory() as tmp:
+            pending = list(enumerate(jobs))
+            running = []
+            while pending or running:
+                while pending and len(running) < workers:
+                    k, (prof, seed, cnt) = pending.pop(0)
+                    path = os.path.join(tmp, f"chunk{k}.bin")
+                    running.append((k, path, subprocess.Popen([sys.executable, os.path.abspath(__file__), prof, str(seed), str(cnt), path])))
+                k, path, proc = running.pop(0)
+                if proc.wait(timeout=900) != 0:
+                    raise RuntimeError("circuit chunk generator failed")
+                raw = open(path, "rb").read()
+                step = len(raw) // 9
+                parts[k] = [raw[i * step:(i + 1) * step] for i in range(9)]
+    else:
+        parts = [_arith_chunk(j) for j in jobs]
+    col = [b"".join(p[k] for p in parts) for k in range(9)]
+    wires = col[:4]
     T = _omega_table(log_n)
-    # sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_1[0] = w^0 ; sigma_3[i] = w^(i+1) (Left(i+1)), last = itself
-    s1 = [T[0]] + [K2 * T[i - 1] % Q for i in range(1, n)]
-    s3 = [T[i + 1] for i in range(n - 1)] + [K2 * T[n - 1] % Q]
+    # inside a chain: sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_3[i] = w^(i+1) (Left(i+1)); chain ends map to themselves
+    s1 = [T[i] if i % seg == 0 else K2 * T[i - 1] % Q for i in range(n)]
+    s3 = [K2 * T[i] % Q if i % seg == seg - 1 else T[i + 1] for i in range(n)]
     cols = {"s_sigma_1": _bytes(s1), "s_sigma_3": _bytes(s3)}
-    for name, col in (("q_m", qm), ("q_l", ql), ("q_r", qr), ("q_f", qf), ("q_c", qc)):
-        cols[name] = _bytes(col)
+    for name, k in (("q_m", 4), ("q_l", 5), ("q_r", 6), ("q_f", 7), ("q_c", 8)):
+        cols[name] = col[k]
     trivial = {"q_o": [Q - 1], "q_arith": [1], "s_sigma_2": [0, K1], "s_sigma_4": [0, K3]}
     return wires, cols, trivial
 
@@ -231,37 +264,64 @@ def widget_block(blk: int, seed: int = 0x5EED0003) -> _Rows:
     return rows
 
 
-def widget_circuit(log_n: int, blk_log: int = 8):
-    """n = 2^log_n rows: a block of 2^blk_log rows tiled over the domain.  Position (column, row) of tile t is
-    copy-constrained to the same position of tile t + 1 (equal values by construction), so the permutation
-    is a product of n / blk-cycles; two public inputs sit on the last two rows of tile 0.
+def widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
+    """n = 2^log_n rows: tiles of 2^blk_log rows drawn at random from a pool of `pool` different blocks (different
+    witnesses), so no column is periodic and every polynomial is dense.  Position (column, row) of a tile is
+    copy-constrained to the same position of the next tile built from the same block (equal values by
+    construction): the permutation is a product of long cycles; two public inputs sit on the last two rows
+    of tile 0.
     Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, public inputs {row: value})."""
     n = 1 << log_n
     blk = 1 << min(blk_log, log_n)
     tiles = n // blk
-    rows = widget_block(blk).rows
+    pool = max(1, min(pool, tiles))
+    rnd = random.Random(0x5EED0003)
+    blocks = [widget_block(blk, 0x5EED0003 + 7919 * b).rows for b in range(pool)]
+    ids = [t % pool for t in range(tiles)]
+    rnd.shuffle(ids)
     mont = lambda v: v % Q * R % Q   # noqa: E731
-    wires = []
-    for col in range(4):
-        wires.append(_bytes([mont(rw[0][col]) for rw in rows]) * tiles)
+    wcols = [[_bytes([mont(rw[0][col]) for rw in rows]) for rows in blocks] for col in range(4)]
+    wires = [b"".join(wcols[col][b] for b in ids) for col in range(4)]
     cols = {}
     for name in SELECTORS:
-        vals = [mont(rw[1].get(name, 0)) for rw in rows]
-        if any(vals):
-            cols[name] = bytearray(_bytes(vals) * tiles)
-    # public inputs: rows blk-2, blk-1 of tile 0 are `-a + PI = 0` (q_l = -1, q_arith = 1, PI = a); the same
-    # rows of the other tiles keep their multiplication gate — the wire values are identical either way
+        per_block = [[mont(rw[1].get(name, 0)) for rw in rows] for rows in blocks]
+        if any(any(v) for v in per_block):
+            raw = [_bytes(v) for v in per_block]
+            cols[name] = bytearray(b"".join(raw[b] for b in ids))
+    # public inputs: rows blk-2, blk-1 of tile 0 are `-a + PI = 0` (q_l = -1, q_arith = 1, PI = a); the tiles that
+    # repeat this block keep their multiplication gate on those rows — the wire values are identical either way
     pi = {}
     for row in (blk - 2, blk - 1):
-        a_val = rows[row][0][0]
-        for name in SELECTORS:
-            if name in cols:
-                v = {"q_l": Q - 1, "q_arith": 1}.get(name, 0)
-                cols[name][32 * row:32 * row + 32] = int.to_bytes(mont(v), 32, "little")
+        a_val = blocks[ids[0]][row][0][0]
+        for name in cols:
+            v = {"q_l": Q - 1, "q_arith": 1}.get(name, 0)
+            cols[name][32 * row:32 * row + 32] = int.to_bytes(mont(v), 32, "little")
         pi[row] = a_val
+    # sigma: tile t -> the next tile with the same block id (cyclically)
+    nxt = [0] * tiles
+    last, first = {}, {}
+    for t, b in enumerate(ids):
+        if b in last:
+            nxt[last[b]] = t
+        else:
+            first[b] = t
+        last[b] = t
+    for b, t in last.items():
+        nxt[t] = first[b]
     T = _omega_table(log_n)
     ks = (1, K1, K2, K3)
-    for k in range(4):   # sigma_k[i] = K_k * w^((i + blk) mod n)
-        rot = T[blk:] + T[:blk]
-        cols[f"s_sigma_{k + 1}"] = _bytes([ks[k] * t % Q for t in rot]) if tiles > 1 else _bytes([ks[k] * t % Q for t in T])
+    for k in range(4):   # sigma_k[t * blk + r] = K_k * w^(nxt[t] * blk + r)
+        out = []
+        for t in range(tiles):
+            seg = T[nxt[t] * blk:(nxt[t] + 1) * blk]
+            out.append(_bytes(seg if k == 0 else [ks[k] * v % Q for v in seg]))
+        cols[f"s_sigma_{k + 1}"] = b"".join(out)
     return wires, {k: bytes(v) for k, v in cols.items()}, pi
+
+
+if __name__ == "__main__":   # chunk worker of arithmetic_circuit: <profile> <seed> <count> <output file>
+    import sys
+    _prof, _seed, _cnt, _out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    with open(_out, "wb") as _f:
+        for _col in _arith_chunk((_prof, _seed, _cnt)):
+            _f.write(_col)

@@ -72,9 +72,13 @@ int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int cose
 int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_n, int inverse,
                     int coset, const uint64_t* in_len);
 
-/* Upload the commit key (npoints x 96 B).  Builds the per-window tables
- * 2^(16 w) * P_i in HBM (16 x 96 B per point). */
+/* Load the commit key (npoints x 96 B, npoints <= 2^23) and build the per-window tables 2^(16 w) * P_i in HBM
+ * (16 x 128 B per point).  The key is STREAMED from host memory in 2^18-point chunks through two device
+ * staging buffers, the upload of chunk k + 1 overlapping the table build of chunk k; pass memory from
+ * plonk_host_alloc (pinned) for asynchronous uploads.  A multi-GPU rank passes only its point range. */
 int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
+int plonk_host_alloc(uint64_t bytes, void** out);   /* pinned host memory (hipHostMalloc) */
+int plonk_host_free(void* p);
 
 /* sum_i scalars[i] * P_i for i < m.  m == 0 -> identity. */
 int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_xy_inf[97]);

@@ -47,6 +47,7 @@ EXPORTS = [
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
+    "plonk_host_alloc", "plonk_host_free",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -153,6 +154,8 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_prover_blob_check.argtypes = [vp, u64, ctypes.POINTER(_BlobInfo)]
     lib.plonk_prover_from_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
     lib.plonk_srs_validate.argtypes = [vp, vp, u64]
+    lib.plonk_host_alloc.argtypes = [u64, ctypes.POINTER(vp)]
+    lib.plonk_host_free.argtypes = [vp]
     lib.plonk_comm_unique_id.argtypes = [vp]
     lib.plonk_comm_init.argtypes = [vp, vp, ci, ci]
     lib.plonk_comm_selftest.argtypes = [vp]
@@ -230,6 +233,28 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             self.ctx.lib.plonk_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class PinnedBuffer:
+    """Pinned host memory (plonk_host_alloc): uploads from it are asynchronous, which is what lets
+    plonk_srs_load overlap the streamed key with the table build."""
+
+    def __init__(self, nbytes: int):
+        self.lib = load_library()
+        p = ctypes.c_void_p()
+        rc = self.lib.plonk_host_alloc(nbytes, ctypes.byref(p))
+        if rc != PLONK_OK:
+            raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def write(self, data: bytes, offset: int = 0):
+        assert offset + len(data) <= self.nbytes
+        ctypes.memmove(self.ptr + offset, data, len(data))
+
+    def free(self):
+        if self.ptr:
+            self.lib.plonk_host_free(self.ptr)
             self.ptr = None
 
 
@@ -316,6 +341,14 @@ class Context:
     def srs_load_bytes(self, raw: bytes, npoints: int) -> None:
         self._check(self.lib.plonk_srs_load(self.handle, raw, npoints))
         self.srs_points = npoints
+
+    def srs_load_host_ptr(self, ptr: int, npoints: int) -> None:
+        """plonk_srs_load from a raw host address (e.g. inside a PinnedBuffer): streamed in chunks."""
+        self._check(self.lib.plonk_srs_load(self.handle, ctypes.c_void_p(ptr), npoints))
+        self.srs_points = npoints
+
+    def d2h_into(self, host_ptr: int, dev_ptr: int, nbytes: int) -> None:
+        self._check(self.lib.plonk_dev_d2h(self.handle, ctypes.c_void_p(host_ptr), dev_ptr, nbytes))
 
     def msm_bytes(self, scalars_mont: bytes, m: int) -> bytes:
         out = ctypes.create_string_buffer(97)

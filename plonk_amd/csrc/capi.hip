@@ -313,18 +313,66 @@ int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints) {
   return srs_load_device(&ctx->c, (const G1Affine*)xy96_dev, npoints);
 }
 
+// The commit key is STREAMED from host memory: chunks of 2^18 points (24 MiB) alternate between two device
+// staging buffers — the copy stream uploads chunk k + 1 while the main stream builds the window-table rows
+// of chunk k — so no device copy of the raw key ever exists and the upload hides behind the table build
+// (BASELINE config 5: "streamed SRS from host pinned memory"; with pinned memory, plonk_host_alloc, the
+// uploads are truly asynchronous; pageable memory works, the runtime then stages each chunk itself).
+// In a multi-GPU run every rank streams only its own point range of the host copy.
 int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
   if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
   HIP_TRY(hipSetDevice(c.device));
-  G1Affine* tmp = nullptr;
-  HIP_TRY(hipMalloc((void**)&tmp, sizeof(G1Affine) * (npoints ? npoints : 1)));
-  hipError_t e = hipMemcpyAsync(tmp, xy96, sizeof(G1Affine) * npoints, hipMemcpyHostToDevice, c.stream);
-  int rc = (e == hipSuccess) ? srs_load_device(&c, tmp, npoints) : PLONK_ERR_HIP;
-  (void)hipStreamSynchronize(c.stream);
-  (void)hipFree(tmp);
+  int rc = srs_table_begin(&c, npoints);
+  if (rc || npoints == 0) return rc;
+  constexpr uint64_t CHUNK = 1ull << 18;
+  const uint64_t cap = npoints < CHUNK ? npoints : CHUNK;
+  if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
+  G1Affine* stage[2] = {nullptr, nullptr};
+  hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+  auto cleanup = [&] {
+    (void)hipStreamSynchronize(c.copy_stream);
+    (void)hipStreamSynchronize(c.stream);
+    for (int k = 0; k < 2; ++k) {
+      if (stage[k]) (void)hipFree(stage[k]);
+      if (up[k]) (void)hipEventDestroy(up[k]);
+      if (done[k]) (void)hipEventDestroy(done[k]);
+    }
+  };
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipMalloc((void**)&stage[k], sizeof(G1Affine) * cap);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&up[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+  }
+  uint64_t k = 0;
+  for (uint64_t first = 0; first < npoints && e == hipSuccess && rc == PLONK_OK; first += CHUNK, ++k) {
+    const uint64_t cnt = npoints - first < CHUNK ? npoints - first : CHUNK;
+    const int b = (int)(k & 1);
+    if (k >= 2) e = hipStreamWaitEvent(c.copy_stream, done[b], 0);             // the staging buffer is free again
+    if (e == hipSuccess) e = hipMemcpyAsync(stage[b], xy96 + 96 * first, sizeof(G1Affine) * cnt, hipMemcpyHostToDevice, c.copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(up[b], c.copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c.stream, up[b], 0);
+    if (e == hipSuccess) rc = srs_table_chunk(&c, stage[b], npoints, first, cnt, c.stream);
+    if (e == hipSuccess && rc == PLONK_OK) e = hipEventRecord(done[b], c.stream);
+  }
+  if (e == hipSuccess && rc == PLONK_OK) e = hipStreamSynchronize(c.stream);
+  cleanup();
+  if (e != hipSuccess) { set_last_error("plonk_srs_load", hipGetErrorString(e), __FILE__, __LINE__); rc = PLONK_ERR_HIP; }
+  if (rc == PLONK_OK) c.srs_n = npoints;
   return rc;
+}
+
+// pinned host memory for callers without HIP bindings (commit keys to stream, batch transform buffers)
+int plonk_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return PLONK_ERR_ARG;
+  HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return PLONK_OK;
+}
+int plonk_host_free(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return PLONK_OK;
 }
 
 int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {

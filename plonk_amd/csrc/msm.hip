@@ -110,10 +110,14 @@ __device__ __forceinline__ void st_g1r(G1RSlot* p, const G1R& v) {
 // T[w * n + i] = 2^(16 w) * P_i, affine, in the reduced-radix form (x, y < 2p).  One lane per
 // point; 16 doublings and one Fp inversion per window (one-off per Prover, outside every
 // timed region).
-__global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __restrict__ table, uint64_t n) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const G1Affine a = ld_aff(pts + i);
+// `pts` holds points [first, first + count) of the key (a chunk of the stream in plonk_srs_load); the table
+// row of window w starts at w * n.
+__global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __restrict__ table, uint64_t n,
+                                 uint64_t first, uint64_t count) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const uint64_t i = first + j;
+  const G1Affine a = ld_aff(pts + j);
   Fp28 x = Fp28::from_fp(a.x), y = Fp28::from_fp(a.y);
   st_f28(&table[i].x, x);
   st_f28(&table[i].y, y);
@@ -431,14 +435,27 @@ __global__ void msm_identity_kernel(G1* out) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
+// allocate the window tables of an n-point key (replacing the old key); the rows are filled by srs_table_chunk
+int srs_table_begin(Ctx* c, uint64_t n) {
   ++c->srs_gen;   // provers built on the previous key refuse to prove (prover.hip)
-  if (c->srs_table) { HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
+  if (c->srs_table) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
   if (n == 0) return PLONK_OK;
-  if ((uint64_t)MSM_W * n >= (1ull << 31)) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // entry word: 31-bit table index
+  if ((uint64_t)MSM_W * n > (1ull << 27)) return (plonk::set_last_error("invalid argument", "commit key: MSM_W * points must be <= 2^27 (27-bit table index of the bucket sort)", __FILE__, __LINE__), PLONK_ERR_ARG);
   HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)MSM_W * n));
-  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, (G1AffineR*)c->srs_table, n);
+  return PLONK_OK;
+}
+// table entries of points [first, first + count), read from pts_dev[0 .. count), on `st`
+int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
+  if (!count) return PLONK_OK;
+  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, pts_dev, (G1AffineR*)c->srs_table, n, first, count);
   HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
+  int rc = srs_table_begin(c, n);
+  if (rc || n == 0) return rc;
+  rc = srs_table_chunk(c, pts_dev, n, 0, n, c->stream);
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->srs_n = n;
   return PLONK_OK;

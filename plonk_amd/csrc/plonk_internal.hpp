@@ -137,6 +137,8 @@ int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* rec
 
 // msm.hip
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
+int srs_table_begin(Ctx* c, uint64_t n);
+int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first, uint64_t count, hipStream_t st);
 int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev);
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 // bit_sums = false: out[k] = the commitment (one XYZZ point).  true: out[k][0..16) = partial sums the
