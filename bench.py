@@ -260,6 +260,7 @@ def main():
     acc_ms, acc_n = ctx.profile_read(1)     # msm_accumulate launches inside the timed region
     oth_ms, oth_n = ctx.profile_read(2)
     q_ms, q_n = ctx.profile_read(3)
+    rep_ms, rep_n = ctx.profile_read(4)
     ctx.profile(False)
     if dist is not None:
         import torch
@@ -332,7 +333,9 @@ def main():
                          "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; see DESIGN.md"},
             "kernel_ms_per_prove": {"msm_accumulate": round(acc_ms / args.steps, 3),
                                     "msm_other": round(oth_ms / args.steps, 3),
-                                    "quotient_pointwise": round(q_ms / args.steps, 3)},
+                                    "quotient_pointwise": round(q_ms / args.steps, 3),
+                                    # wire / permutation polynomials of rounds 1-2: the part every rank of a multi-GPU run repeats
+                                    "rounds_1_2_polynomials_replicated": round(rep_ms / args.steps, 3)},
         }
         vk48 = prover.vk_commitments()
         prover.close()

@@ -218,7 +218,8 @@ int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
  * When enabled, every launch of the dominant kernels is bracketed by a hipEvent
  * pair ON THE LIBRARY'S STREAM and accumulated per slot.  Slots:
  *   0 ntt pass kernels, 1 msm bucket accumulation, 2 msm (all other kernels),
- *   3 quotient/pointwise kernels. */
+ *   3 quotient/pointwise kernels, 4 the polynomial work of prove() rounds 1-2 (wire / permutation
+ *   polynomials: what stays replicated on every rank of a multi-GPU run). */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches);
 int plonk_profile_reset(plonk_ctx* ctx);

@@ -441,6 +441,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
 
   uint8_t comm[11][48];
   // ---- round 1 (prover.rs:444-479)
+  prof_begin(c, 4);   // slot 4: the polynomial work of rounds 1-2 (replicated on every rank of a multi-GPU run)
   for (int k = 0; k < 4; ++k) {
     Fr* wp = p->wpoly + k * np;
     PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
@@ -451,6 +452,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_fill_zero(c, wp + n, np - n));
     PTRY(poly_blind(c, wp, n, ba));
   }
+  prof_end(c, 4);
   SideJoin side_join{c};
   uint64_t pi_len = 0;
   for (int k = 0; k < 4; ++k)   // lowest coefficients of the blinded wire polynomials (quotient_low)
@@ -496,6 +498,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   tr.append_scalar("beta", beta);
   const Fr gamma = tr.challenge_scalar("gamma");
   {
+    prof_begin(c, 4);
     PermArgs pa;
     pa.n = n;
     for (int k = 0; k < 4; ++k) { pa.wires[k] = wires_dev + k * n; pa.sigma[k] = p->sigma_n + k * n; }
@@ -515,6 +518,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     ba.b[0] = bl[8]; ba.b[1] = bl[9]; ba.b[2] = bl[10];
     PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
     PTRY(poly_blind(c, p->zpoly, n, ba));
+    prof_end(c, 4);
   }
   HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   {
@@ -825,6 +829,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
 
   uint8_t comm[11][48];
   // ---- round 1 (replicated polynomials, sharded commitments)
+  prof_begin(c, 4);   // slot 4: replicated polynomial work (rounds 1-2)
   for (int k = 0; k < 4; ++k) {
     Fr* wp = p->wpoly + k * np;
     PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
@@ -835,6 +840,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     PTRY(poly_fill_zero(c, wp + n, np - n));
     PTRY(poly_blind(c, wp, n, ba));
   }
+  prof_end(c, 4);
   SideJoin side_join{c};
   uint64_t pi_len = 0;
   for (int k = 0; k < 4; ++k)
@@ -885,6 +891,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   tr.append_scalar("beta", beta);
   const Fr gamma = tr.challenge_scalar("gamma");
   {
+    prof_begin(c, 4);
     PermArgs pa;
     pa.n = n;
     for (int k = 0; k < 4; ++k) { pa.wires[k] = wires_dev + k * n; pa.sigma[k] = p->sigma_n + k * n; }
@@ -903,6 +910,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     ba.b[0] = bl[8]; ba.b[1] = bl[9]; ba.b[2] = bl[10];
     PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
     PTRY(poly_blind(c, p->zpoly, n, ba));
+    prof_end(c, 4);
   }
   HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   {

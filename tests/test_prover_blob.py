@@ -6,6 +6,7 @@ no GPU needed for the structural part) must locate every piece and reject what
 Prover::try_from_bytes / ProverKey::from_slice / Evaluations::from_slice /
 CommitKey::from_raw_var_bytes reject, with the same error kinds."""
 import hashlib
+import os
 
 import pytest
 
@@ -20,6 +21,20 @@ from oracle.serialize import DOMAIN_SIZE, VERIFIER_KEY_SIZE, prover_to_bytes
 def blob(kat_setup):
     _, oprover, _ = kat_setup
     return prover_to_bytes(oprover)
+
+
+def test_kat_blob_digest_prediction(blob):
+    """The digest tools/dump_kat_blob.rs prints when run inside the reference tree (cargo is not available
+    here): the serialised KAT prover this repository predicts.  One external run of that file against this
+    literal pins the format to the reference's real bytes; until then the format is pinned only to the
+    layout restated from prover.rs:238-263 / widget.rs:347-447 / key.rs:215-229."""
+    assert len(blob) == 43966
+    assert hashlib.blake2b(blob).hexdigest() == (
+        "959ac0e3ee3d8f14695fccf849c92c9e2292e979b6de720d9a6d15e279b88e98"
+        "da02c27c8e99f76ec8453c0b7813f7d11e68baf5cf67795ec985771bcca3ed23")
+    real = os.path.join(os.path.dirname(__file__), "golden", "kat_prover.blob")   # dropped here by whoever ran the Rust tool
+    if os.path.exists(real):
+        assert open(real, "rb").read() == blob
 
 
 def test_blob_layout_matches_reference_sizes(blob, kat_setup):
