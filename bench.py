@@ -103,12 +103,16 @@ def time_profile(ctx, log_n, profile, steps, blinders):
 
 
 def leaf_costs(ctx, log_n):
-    """Seam-level drop-in cost, PCIe included (host buffers in, host buffers out): one plonk_ntt of the
-    8n quotient-domain size and one plonk_msm_batch of 4 scalar sets — what a Rust shim at the two
-    crate-private seams (domain.rs:173-232, key.rs:384) would pay per call."""
+    """Seam-level drop-in cost, PCIe included (host buffers in, host buffers out): plonk_ntt / plonk_ntt_batch at the
+    8n quotient-domain size and plonk_msm_batch of 4 scalar sets — what a Rust shim at the two crate-private
+    seams (domain.rs:173-232, key.rs:384) pays per call when its vectors live in pinned memory
+    (plonk_host_alloc / hipHostRegister).  The C entry points are called directly on the pinned addresses."""
+    import ctypes
+
     import numpy as np
     rng = np.random.default_rng(3)
     n = 1 << log_n
+    lib, h = ctx.lib, ctx.handle
 
     def rand_fr(cnt):
         a = rng.integers(0, 256, size=(cnt, 32), dtype=np.uint8)
@@ -116,21 +120,36 @@ def leaf_costs(ctx, log_n):
         return a.tobytes()
     out = {}
     L8 = min(log_n + 3, 23)
-    d = rand_fr(1 << L8)
-    ctx.ntt_bytes(d, L8, False, True, 1 << L8)
+    n8 = 1 << L8
+    bufs = [plonk_amd.PinnedBuffer(32 * n8) for _ in range(5)]
+    d = rand_fr(n8)
+    for b in bufs:
+        b.write(d)
+    vp = ctypes.c_void_p
+    ctx._check(lib.plonk_ntt(h, vp(bufs[0].ptr), L8, 0, 1, n8))           # warm-up (tables, staging)
     t0 = time.perf_counter()
-    ctx.ntt_bytes(d, L8, False, True, 1 << L8)
+    ctx._check(lib.plonk_ntt(h, vp(bufs[0].ptr), L8, 0, 1, n8))
     out["plonk_ntt_2p%d_ms" % L8] = round((time.perf_counter() - t0) * 1e3, 2)
-    five = [d] * 5
+    arr = (vp * 5)(*[vp(b.ptr) for b in bufs])
+    ctx._check(lib.plonk_ntt_batch(h, arr, 5, L8, 0, 1, None))
     t0 = time.perf_counter()
-    ctx.ntt_batch_bytes(five, L8, False, True)
+    ctx._check(lib.plonk_ntt_batch(h, arr, 5, L8, 0, 1, None))
     out["plonk_ntt_batch5_2p%d_ms" % L8] = round((time.perf_counter() - t0) * 1e3, 2)
-    sets = [rand_fr(n + 2) for _ in range(4)]
-    ctx.msm_batch_bytes(sets)
+    for b in bufs:
+        b.free()
+    sets = [plonk_amd.PinnedBuffer(32 * (n + 2)) for _ in range(4)]
+    for sb in sets:
+        sb.write(rand_fr(n + 2))
+    sarr = (vp * 4)(*[vp(sb.ptr) for sb in sets])
+    ms = (ctypes.c_uint64 * 4)(*[n + 2] * 4)
+    res = ctypes.create_string_buffer(4 * 97)
+    ctx._check(lib.plonk_msm_batch(h, sarr, ms, 4, res))
     t0 = time.perf_counter()
-    ctx.msm_batch_bytes(sets)
+    ctx._check(lib.plonk_msm_batch(h, sarr, ms, 4, res))
     out["plonk_msm_batch4_2p%d_ms" % log_n] = round((time.perf_counter() - t0) * 1e3, 2)
-    out["note"] = "host buffers in and out through ctypes (includes the Python-side buffer copies)"
+    for sb in sets:
+        sb.free()
+    out["note"] = "pinned host buffers in and out, C entry points called directly (PCIe both ways included)"
     return out
 
 

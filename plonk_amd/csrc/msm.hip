@@ -22,6 +22,8 @@
 //                    sum_b b * B_b -> affine.
 //
 // Algorithmic HBM bytes per MSM of m terms: 128 * m (32 B scalar + 96 B base).
+#include <cstdlib>
+
 #include "plonk_internal.hpp"
 #include "curve28.cuh"
 #include "fr29.cuh"
@@ -478,12 +480,15 @@ int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G
 // Slice length: 32 entries from m = 2^20 up; halved with m below that (down to 4) so that a smaller
 // MSM still spreads over ~2^19 lanes instead of leaving most SIMDs idle behind 32 serial additions.
 static uint32_t msm_ksl(uint64_t m) {
+  static const int forced = [] { const char* e = getenv("PLONK_MSM_KSL"); return e ? atoi(e) : 0; }();   // tuning experiments only
+  if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return (uint32_t)forced;
   uint32_t r = 4;
   while (r < MSM_KSL && (uint64_t)r * MSM_NB < m) r *= 2;   // smallest power of two >= m / 2^15, clamped to [4, 32]
   return r;
 }
 // upper bound of the slice count over every m <= cap (MSM_W * m / msm_ksl(m) <= 16 * 2^15 below 2^20)
 static uint64_t msm_slice_cap(uint64_t cap) {
+  if (const char* e = getenv("PLONK_MSM_KSL")) { const int f = atoi(e); if (f >= 4) return (uint64_t)MSM_W * cap / f + MSM_NB + 1; }
   const uint64_t small = (uint64_t)MSM_W * cap / 4 < (uint64_t)MSM_W * MSM_NB ? (uint64_t)MSM_W * cap / 4 : (uint64_t)MSM_W * MSM_NB;
   const uint64_t large = (uint64_t)MSM_W * cap / MSM_KSL;
   return (small > large ? small : large) + MSM_NB + 1;
