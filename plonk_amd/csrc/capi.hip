@@ -469,7 +469,7 @@ int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64
     G1* res[MSM_MAX_BATCH];
     for (int k = 0; k < cnt; ++k) {
       Fr* dst = c.msm.scalars_stage + (uint64_t)k * (mmax ? mmax : 1);
-      HIP_TRY(hipMemcpyAsync(dst, scalars[k0 + k], sizeof(Fr) * m[k0 + k], hipMemcpyHostToDevice, c.stream));
+      if (m[k0 + k]) HIP_TRY(hipMemcpyAsync(dst, scalars[k0 + k], sizeof(Fr) * m[k0 + k], hipMemcpyHostToDevice, c.stream));
       sc[k] = dst;
       ms[k] = m[k0 + k];
       res[k] = (G1*)c.msm.result + (size_t)k * MSM_BIT_SUMS;

@@ -253,9 +253,12 @@ int plonk_prover_from_bytes(plonk_ctx* ctx, const uint8_t* blob, uint64_t len, p
   // commit key: 97-byte raw points -> x || y, subgroup check + window tables on the device
   std::vector<uint8_t> xy((size_t)info.srs_points * 96);
   for (uint64_t i = 0; i < info.srs_points; ++i) memcpy(&xy[96 * i], blob + info.srs_off + RAW_POINT * i, 96);
-  rc = plonk_srs_validate(ctx, xy.data(), info.srs_points);
+  rc = plonk_srs_validate(ctx, xy.data(), info.srs_points);   // every point, as the reference does
   if (rc) return rc;
-  rc = plonk_srs_load(ctx, xy.data(), info.srs_points);
+  // prove() commits to at most size + 7 coefficients: only that prefix of the key gets window tables (a key trimmed
+  // by Compiler::compile has up to 2 * size + 6 points, compiler.rs:121-124 — twice the table memory for nothing)
+  const uint64_t used = info.srs_points < info.size + 8 ? info.srs_points : info.size + 8;
+  rc = plonk_srs_load(ctx, xy.data(), used);
   if (rc) return rc;
   std::vector<uint8_t>().swap(xy);
   // key polynomials: canonical little-endian scalars -> Montgomery limbs
