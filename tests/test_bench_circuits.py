@@ -1,0 +1,66 @@
+"""CPU: the synthetic workloads of bench.py (bench_circuits.py) are honest circuits — the C restatement of the
+reference's prove() (oracle/c/oracle_prove.c) accepts their witnesses (a wrong gadget layout or permutation
+would be Error::CircuitUnsatisfied, quotient_poly.rs:132), every selector family of the `widgets` profile is
+active, its columns are not periodic, and the chunked generator used above 2^20 gates equals the
+single-process one."""
+import hashlib
+
+import pytest
+
+import bench_circuits as BC
+from oracle import cbind
+from tests import circuits as C
+
+
+def prove_with_oracle(log_n, wires, cols, trivial, pi):
+    n = 1 << log_n
+    polys = {k: C.fr_bytes(v) for k, v in trivial.items()}
+    for name, raw in cols.items():
+        polys[name] = cbind.ntt_bytes(raw, log_n, True, False, n)
+    cp = cbind.CProver(n, b"bench", polys, C.synthetic_srs(n + 7))
+    idx = sorted(pi)
+    proof = cp.prove(wires, idx, C.fr_bytes([pi[i] for i in idx]), C.blinders(5))
+    cp.close()
+    return proof, polys
+
+
+@pytest.mark.parametrize("profile", ["dense", "bench-like"])
+def test_arithmetic_profiles_are_satisfied(profile):
+    wires, cols, trivial = BC.arithmetic_circuit(10, profile)
+    proof, _ = prove_with_oracle(10, wires, cols, trivial, {})
+    assert len(proof) == 1008
+    if profile == "bench-like":     # about half of the wire values are < 4
+        vals = C.fr_vals(wires[1]) + C.fr_vals(wires[3])
+        small = sum(v < 4 for v in vals) / len(vals)
+        assert 0.4 < small < 0.6
+
+
+@pytest.mark.parametrize("log_n", [9, 12])
+def test_widget_profile_is_satisfied_dense_and_complete(log_n):
+    wires, cols, pi = BC.widget_circuit(log_n)
+    assert len(pi) == 2
+    proof, polys = prove_with_oracle(log_n, wires, cols, {}, pi)
+    assert len(proof) == 1008
+    for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add", "q_arith", "q_m"):
+        assert any(polys[name]), name
+    if log_n == 12:   # 16 tiles from a pool of different blocks: no periodic column, dense wire polynomials
+        n = 1 << log_n
+        a_poly = C.fr_vals(cbind.ntt_bytes(wires[0], log_n, True, False, n))
+        assert sum(1 for v in a_poly if v) > n - 8
+
+
+def test_chunk_workers_equal_the_in_process_generator():
+    args = ("dense", 0x5EED0001 + 0x10000, 64)
+    direct = BC._arith_chunk(args)
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "c.bin")
+        subprocess.check_call([sys.executable, BC.__file__, args[0], str(args[1]), str(args[2]), path])
+        raw = open(path, "rb").read()
+    assert raw == b"".join(direct)
+    # the headline circuit is one chain from one stream: its digest is part of the bench line's stability
+    w, c, t = BC.arithmetic_circuit(8, "dense")
+    assert hashlib.blake2b(b"".join(w)).hexdigest()[:16] == hashlib.blake2b(b"".join(BC.arithmetic_circuit(8, "dense")[0])).hexdigest()[:16]
