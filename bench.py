@@ -358,6 +358,23 @@ def main():
                                     "rounds_1_2_polynomials_replicated": round(rep_ms / args.steps, 3)},
         }
         vk48 = prover.vk_commitments()
+        if world == 1 and not args.no_extras:
+            try:   # the boundary handing over HOST wire columns (pinned): PCIe-inclusive prove(), never `value`
+                hw = [plonk_amd.PinnedBuffer(32 * n) for _ in range(4)]
+                for k in range(4):
+                    ctx.d2h_into(hw[k].ptr, wbuf.ptr + 32 * n * k, 32 * n)
+                ptrs = [b.ptr for b in hw]
+                assert prover.prove_host_ptrs(ptrs, pi, blinders) == proof
+                ctx.sync()
+                t1 = time.perf_counter()
+                for _ in range(max(2, min(args.steps, 5))):
+                    prover.prove_host_ptrs(ptrs, pi, blinders)
+                ctx.sync()
+                out["prove_ms_host_wires_pinned"] = round((time.perf_counter() - t1) * 1e3 / max(2, min(args.steps, 5)), 3)
+                for b in hw:
+                    b.free()
+            except Exception as e:   # noqa: BLE001
+                out["host_wires_error"] = repr(e)
         prover.close()
         wbuf.free()
         if world == 1 and not args.no_extras and args.profile == "dense":

@@ -509,6 +509,15 @@ class Prover:
                                                         fr_to_bytes_mont(blinders), proof))
         return proof.raw
 
+    def prove_host_ptrs(self, wire_ptrs, public_inputs, blinders_mont: bytes) -> bytes:
+        """plonk_prover_prove on four raw host addresses (e.g. PinnedBuffer.ptr): the columns are uploaded on the copy
+        stream while round 1 already transforms the ones that have arrived."""
+        arr = (ctypes.c_void_p * 4)(*[ctypes.c_void_p(p) for p in wire_ptrs])
+        idx, val, cnt = self._pi(public_inputs)
+        proof = ctypes.create_string_buffer(1008)
+        self.ctx._check(self.ctx.lib.plonk_prover_prove(self.handle, arr, idx, val, cnt, blinders_mont, proof))
+        return proof.raw
+
     def prove_dev(self, wires_ptr: int, public_inputs, blinders_mont: bytes) -> bytes:
         idx, val, cnt = self._pi(public_inputs)
         proof = ctypes.create_string_buffer(1008)

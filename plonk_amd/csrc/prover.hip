@@ -55,6 +55,8 @@ struct Prover {
   Fr* tmp8 = nullptr;              // [n8] NTT scratch (main stream)
   Fr* tmp8b = nullptr;             // [n8] NTT scratch (side stream)
   hipEvent_t ev_ready = nullptr, ev_side = nullptr;
+  hipEvent_t ev_wire[4] = {nullptr, nullptr, nullptr, nullptr};   // host-wire uploads in flight on the copy stream (plonk_prover_prove)
+  bool wires_pending = false;
   Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
   Fr* agg = nullptr;               // [np] linear combination
   Fr* wit = nullptr;               // [np] opening witness polynomial W_z
@@ -193,6 +195,7 @@ static void prover_free(Prover* p) {
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
   if (p->ev_pi) (void)hipEventDestroy(p->ev_pi);
+  for (int k = 0; k < 4; ++k) if (p->ev_wire[k]) (void)hipEventDestroy(p->ev_wire[k]);
   if (p->low_host) (void)hipHostFree(p->low_host);
   if (p->res_host) (void)hipHostFree(p->res_host);
   if (p->gather_host) free(p->gather_host);
@@ -307,6 +310,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   HIP_TRY(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_pi, hipEventDisableTiming));
+  for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&p->ev_wire[k], hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&p->low_host, 42 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * RES_STRIDE, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->ev_host, 16 * sizeof(Fr), hipHostMallocDefault));
@@ -444,6 +448,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   prof_begin(c, 4);   // slot 4: the polynomial work of rounds 1-2 (replicated on every rank of a multi-GPU run)
   for (int k = 0; k < 4; ++k) {
     Fr* wp = p->wpoly + k * np;
+    if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
     PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
     BlindArgs ba;
     ba.count = 2;
@@ -832,6 +837,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   prof_begin(c, 4);   // slot 4: replicated polynomial work (rounds 1-2)
   for (int k = 0; k < 4; ++k) {
     Fr* wp = p->wpoly + k * np;
+    if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
     PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
     BlindArgs ba;
     ba.count = 2;
@@ -1260,11 +1266,20 @@ int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const u
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
+  Ctx* c = p->c;
+  for (int k = 0; k < 4; ++k) if (!wires[k]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  // the four columns travel on the copy stream while round 1 already transforms the ones that have arrived
+  if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamSynchronize(c->stream));   // the previous proof has finished reading p->wires
   for (int k = 0; k < 4; ++k) {
-    if (!wires[k]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-    HIP_TRY(hipMemcpyAsync(p->wires + k * p->n, wires[k], sizeof(Fr) * p->n, hipMemcpyHostToDevice, p->c->stream));
+    HIP_TRY(hipMemcpyAsync(p->wires + k * p->n, wires[k], sizeof(Fr) * p->n, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipEventRecord(p->ev_wire[k], c->copy_stream));
   }
-  return prover_prove(p, p->wires, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+  p->wires_pending = true;
+  const int rc = prover_prove(p, p->wires, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+  p->wires_pending = false;
+  (void)hipStreamSynchronize(c->copy_stream);
+  return rc;
 }
 
 }  // extern "C"
