@@ -13,9 +13,9 @@
 //                         regroups the tile in LDS (128 KiB of the CU's 160 KiB) and writes runs of
 //                         ~16 consecutive 4-byte words.  The word carries what the second level needs:
 //                         fine bucket (4 bits) | sign | table index (27 bits).
-//   msm_fine_kernel       one workgroup per coarse bin (~8192 entries, L2-resident): histogram of the
-//                         16 fine buckets, then scatter into the final entry array; writes the bucket
-//                         offsets on the way, so no pass over 32768 counters is needed for them.
+//   msm_fine_kernel       one workgroup per coarse bin (~8192 entries, held in registers between the two
+//                         steps): histogram of the 16 fine buckets, then scatter into the final entry array;
+//                         writes the bucket offsets on the way, so no pass over 32768 counters is needed.
 //   msm_slices_kernel     bucket offsets -> slice offsets (prefix sum of ceil(count / KSL)).
 //
 // HBM traffic per commitment of m terms: 2 x 32m (scalars, read twice) + 64m written and read back
@@ -31,7 +31,12 @@ static constexpr uint32_t FINE_BITS = 4;
 static constexpr uint32_t COARSE = MSM_NB >> FINE_BITS;          // 2048 coarse bins
 static constexpr uint32_t TILE = 2048;                           // scalars per workgroup (hist / partition)
 static constexpr uint32_t SORT_T = 1024;                         // threads per workgroup
-static constexpr uint32_t PER_T = TILE / SORT_T;                 // scalars per thread
+static constexpr uint32_t PER_T = TILE / SORT_T;                 // scalars per thread (partition)
+#ifndef PLONK_HIST_PER
+#define PLONK_HIST_PER 2
+#endif
+static constexpr uint32_t HIST_PER = PLONK_HIST_PER;             // scalars per thread of the histogram pass
+static constexpr uint32_t HIST_TILE = SORT_T * HIST_PER;
 static constexpr uint32_t IDX_BITS = 27;                         // table index field of the intermediate word
 static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
 static_assert(COARSE == 2 * SORT_T, "scan / reservation loops assume two coarse bins per thread");
@@ -78,18 +83,24 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
   __shared__ uint32_t hist[COARSE];
   const int kb = blockIdx.y;
   const uint64_t m = bt.m[kb];
-  const uint64_t base = (uint64_t)blockIdx.x * TILE;
+  const uint64_t base = (uint64_t)blockIdx.x * HIST_TILE;
   if (base >= m) return;
   const uint32_t t = threadIdx.x;
   hist[t] = 0;
   hist[t + SORT_T] = 0;
   __syncthreads();
   const Fr* __restrict__ scalars = bt.scalars[kb];
+  Fr raw[HIST_PER];   // all loads of the thread in flight before the first conversion
 #pragma unroll
-  for (uint32_t k = 0; k < PER_T; ++k) {
+  for (uint32_t k = 0; k < HIST_PER; ++k) {
+    const uint64_t i = base + t + (uint64_t)k * SORT_T;
+    if (i < m) raw[k] = ld_scalar(scalars + i);
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < HIST_PER; ++k) {
     const uint64_t i = base + t + (uint64_t)k * SORT_T;
     if (i < m) {
-      const Fr s = scalar_canonical(ld_scalar(scalars + i));
+      const Fr s = scalar_canonical(raw[k]);
       for_each_digit(s, [&](int, uint32_t bucket, uint32_t) { atomicAdd(&hist[bucket >> FINE_BITS], 1u); });
     }
   }
@@ -207,7 +218,15 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
 }
 
 // ---- level 2: fine buckets inside a coarse bin ----------------------------------------------------
-static constexpr uint32_t FINE_T = 256;
+#ifndef PLONK_FINE_T
+#define PLONK_FINE_T 512
+#endif
+#ifndef PLONK_FINE_CACHE
+#define PLONK_FINE_CACHE 20
+#endif
+static constexpr uint32_t FINE_T = PLONK_FINE_T;
+static constexpr uint32_t FINE_CACHE = PLONK_FINE_CACHE;   // words per thread kept in registers between the two passes: 512 x 20 covers a bin of
+                                                           // 10240 words (mean 8192 at 2^20 terms), anything beyond is re-read; A/B r02: -0.25 ms per proof
 __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
                                                           const uint32_t* __restrict__ tmp_all,
                                                           uint32_t* __restrict__ entries_all,
@@ -222,7 +241,16 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
   const uint32_t beg = coff[bin], end = coff[bin + 1];
   if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
   __syncthreads();
-  for (uint32_t j = beg + t; j < end; j += FINE_T) atomicAdd(&cnt[tmp[j] >> (IDX_BITS + 1)], 1u);
+  uint32_t cache[FINE_CACHE > 0 ? FINE_CACHE : 1];
+#pragma unroll
+  for (uint32_t r = 0; r < FINE_CACHE; ++r) {
+    const uint32_t j = beg + t + r * FINE_T;
+    cache[r] = j < end ? tmp[j] : 0u;
+  }
+#pragma unroll
+  for (uint32_t r = 0; r < FINE_CACHE; ++r)
+    if (beg + t + r * FINE_T < end) atomicAdd(&cnt[cache[r] >> (IDX_BITS + 1)], 1u);
+  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) atomicAdd(&cnt[tmp[j] >> (IDX_BITS + 1)], 1u);
   __syncthreads();
   if (t == 0) {
     uint32_t run = beg;
@@ -234,12 +262,15 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
     if (bin == COARSE - 1) offsets[MSM_NB] = run;
   }
   __syncthreads();
-  for (uint32_t j = beg + t; j < end; j += FINE_T) {
-    const uint32_t e = tmp[j];
+  auto place = [&](uint32_t e) {
     const uint32_t f = e >> (IDX_BITS + 1);
     const uint32_t pos = start[f] + atomicAdd(&cur[f], 1u);
     entries[pos] = (e & IDX_MASK) | (((e >> IDX_BITS) & 1u) << 31);   // accumulate's format: index | sign << 31
-  }
+  };
+#pragma unroll
+  for (uint32_t r = 0; r < FINE_CACHE; ++r)
+    if (beg + t + r * FINE_T < end) place(cache[r]);
+  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) place(tmp[j]);
 }
 
 // ---- slice offsets: slice_off[b] = sum_{b' < b} ceil(count[b'] / ksl), one workgroup per commitment
@@ -273,8 +304,9 @@ int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   if ((uint64_t)MSM_W * c->srs_n > (uint64_t)IDX_MASK + 1)
     return (set_last_error("commit key too large for the bucket sort", "MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
   const uint32_t tiles = (uint32_t)((mmax + TILE - 1) / TILE);
+  const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
-  hipLaunchKernelGGL(msm_hist_kernel, dim3(tiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
+  hipLaunchKernelGGL(msm_hist_kernel, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur);
   smem_opt_in(c, (const void*)msm_partition_kernel, PARTITION_LDS);
   hipLaunchKernelGGL(msm_partition_kernel, dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, c->srs_n,
