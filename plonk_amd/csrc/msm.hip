@@ -453,6 +453,103 @@ int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first,
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
+int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out) {
+  *table_out = nullptr;
+  if (n == 0) return PLONK_OK;
+  if ((uint64_t)MSM_W * n > (1ull << 27)) return (plonk::set_last_error("invalid argument", "window tables: MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
+  G1AffineR* t = nullptr;
+  HIP_TRY(hipMalloc((void**)&t, sizeof(G1AffineR) * (size_t)MSM_W * n));
+  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, t, n, (uint64_t)0, n);
+  if (hipGetLastError() != hipSuccess) { (void)hipFree(t); return PLONK_ERR_HIP; }
+  *table_out = t;
+  return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Lagrange-basis commit key: [L_i(tau)] G = 1/n * sum_j w^(-ij) [tau^j] G — an inverse FFT over the group.
+// In-place radix-2 decimation-in-frequency stages on XYZZ points (natural order in, bit-reversed out): the
+// butterfly (a, b) -> (a + b, (a - b) * w^-e) costs one 255-bit double-and-add; n/2 * log2 n of them, once per
+// prover.  The last kernel undoes the bit reversal, multiplies by 1/n, normalises to affine and appends the two
+// points the blinding terms of a wire polynomial need: [tau^n] G - G and [tau^(n+1)] G - [tau] G.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ G1R g1r_neg(const G1R& p) {
+  G1R r = p;
+  if (!p.is_identity()) r.Y = Fp28::sub<16>(Fp28::zero(), p.Y).canon();   // 16p - Y  (Y < 8p)  ->  [0, p)
+  return r;
+}
+__device__ __forceinline__ G1R g1r_mul_fr(const G1R& p, const Fr& k_canonical) {   // 255-bit double-and-add
+  G1R acc = G1R::identity();
+  for (int w = 7; w >= 0; --w)
+    for (int b = 31; b >= 0; --b) {
+      acc = acc.dbl();
+      if ((k_canonical.l[w] >> b) & 1) acc = acc.add(p);
+    }
+  return acc;
+}
+__global__ void ecfft_load_kernel(const G1AffineR* __restrict__ row0, G1RSlot* __restrict__ v, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st_g1r(v + i, G1R::from_affine(ld_f28(&row0[i].x), ld_f28(&row0[i].y)));
+}
+// stage with butterfly span `half`: pairs (blk * 2 half + j, + half), twiddle w_inv^(j * n / (2 half))
+__global__ void __launch_bounds__(64) ecfft_stage_kernel(G1RSlot* __restrict__ v, uint64_t n, uint64_t half, Fr w_inv) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n / 2) return;
+  const uint64_t j = t % half, lo = (t / half) * 2 * half + j, hi = lo + half;
+  const G1R a = ld_g1r(v + lo), b = ld_g1r(v + hi);
+  st_g1r(v + lo, a.add(b));
+  G1R d = a.add(g1r_neg(b));
+  if (j) d = g1r_mul_fr(d, w_inv.pow_u64(j * (n / (2 * half))).from_mont());
+  st_g1r(v + hi, d);
+}
+__global__ void __launch_bounds__(64) ecfft_finish_kernel(const G1RSlot* __restrict__ v, const G1AffineR* __restrict__ row0, uint64_t n,
+                                                          uint32_t L, Fr n_inv_canonical, G1Affine* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n + 2) return;
+  G1R p;
+  if (i < n) {
+    uint64_t r = 0;
+    for (uint32_t b = 0; b < L; ++b) r |= ((i >> b) & 1) << (L - 1 - b);
+    p = g1r_mul_fr(ld_g1r(v + r), n_inv_canonical);
+  } else {   // [tau^(n + k)] G - [tau^k] G, k = i - n
+    const uint64_t k = i - n;
+    p = G1R::from_affine(ld_f28(&row0[n + k].x), ld_f28(&row0[n + k].y))
+            .add(g1r_neg(G1R::from_affine(ld_f28(&row0[k].x), ld_f28(&row0[k].y))));
+  }
+  G1Affine a;
+  if (p.is_identity()) {   // cannot happen for a key from a real setup (tau^n != 1); keep the slot defined
+    for (int k = 0; k < 12; ++k) { a.x.l[k] = 0; a.y.l[k] = 0; }
+  } else {
+    Fp28 x, y;
+    g1r_to_affine(p, &x, &y);
+    a.x = x.to_fp();
+    a.y = y.to_fp();
+  }
+  st_aff(out + i, a);
+}
+
+int lagrange_points_device(Ctx* c, uint32_t L, G1Affine* out_dev) {
+  const uint64_t n = 1ull << L;
+  if (!c->srs_table || c->srs_n < n + 2) return (plonk::set_last_error("invalid argument", "Lagrange key needs size + 2 commit-key points", __FILE__, __LINE__), PLONK_ERR_DEGREE);
+  hipStream_t st = c->stream;
+  const G1AffineR* row0 = (const G1AffineR*)c->srs_table;   // window 0 = the key points themselves
+  G1RSlot* v = nullptr;
+  HIP_TRY(hipMalloc((void**)&v, sizeof(G1RSlot) * n));
+  hipLaunchKernelGGL(ecfft_load_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, row0, v, n);
+  Fr w = fr_root_of_unity();
+  for (uint32_t i = L; i < 32; ++i) w = w.sqr();
+  const Fr w_inv = w.inv();
+  for (uint64_t half = n / 2; half >= 1; half >>= 1)
+    hipLaunchKernelGGL(ecfft_stage_kernel, dim3((uint32_t)((n / 2 + 63) / 64)), dim3(64), 0, st, v, n, half, w_inv);
+  const Fr n_inv = Fr::from_u64(n).inv().from_mont();
+  hipLaunchKernelGGL(ecfft_finish_kernel, dim3((uint32_t)((n + 2 + 63) / 64)), dim3(64), 0, st, (const G1RSlot*)v, row0, n, L, n_inv, out_dev);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(v);
+  if (e != hipSuccess) { set_last_error("lagrange_points_device", hipGetErrorString(e), __FILE__, __LINE__); return PLONK_ERR_HIP; }
+  return PLONK_OK;
+}
+
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
   int rc = srs_table_begin(c, n);
   if (rc || n == 0) return rc;
@@ -530,12 +627,14 @@ void prof_end(Ctx* c, int slot);
 // `count` (<= MSM_MAX_BATCH) independent MSMs over the same bases, launched together: the
 // latency-bound reduction kernels run once per group instead of once per commitment
 // (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
-int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums) {
+int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums,
+                     const void* table, uint64_t table_n) {
   if (count <= 0) return PLONK_OK;
   if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (!table) { table = c->srs_table; table_n = c->srs_n; }
   uint64_t mmax = 0;
   for (int k = 0; k < count; ++k) {
-    if (m[k] > c->srs_n) return PLONK_ERR_DEGREE;
+    if (m[k] > table_n) return PLONK_ERR_DEGREE;
     if (m[k] > mmax) mmax = m[k];
   }
   hipStream_t st = c->stream;
@@ -545,7 +644,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
   }
-  if (!c->srs_table) return PLONK_ERR_NO_SRS;
+  if (!table) return PLONK_ERR_NO_SRS;
   int rc = msm_reserve(c, mmax);
   if (rc) return rc;
   MsmWork& w = c->msm;
@@ -554,6 +653,8 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   bt.ksl = msm_ksl(mmax);
   bt.cap_m = w.cap_m;
   bt.cap_slices = w.cap_slices;
+  bt.table = table;
+  bt.table_n = table_n;
   for (int k = 0; k < count; ++k) { bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k]; }
   prof_begin(c, 2);
   rc = msm_group_sort(c, bt, mmax);
@@ -563,7 +664,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   const uint64_t max_slices = (MSM_W * mmax) / bt.ksl + MSM_NB + 1;
   prof_begin(c, 1);
   hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
-                     (const G1AffineR*)c->srs_table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
+                     (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
   prof_begin(c, 2);
   {

@@ -301,7 +301,7 @@ int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   MsmWork& w = c->msm;
   hipStream_t st = c->stream;
   // intermediate word: 27-bit table index (MSM_W * srs_n entries)
-  if ((uint64_t)MSM_W * c->srs_n > (uint64_t)IDX_MASK + 1)
+  if ((uint64_t)MSM_W * bt.table_n > (uint64_t)IDX_MASK + 1)
     return (set_last_error("commit key too large for the bucket sort", "MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
   const uint32_t tiles = (uint32_t)((mmax + TILE - 1) / TILE);
   const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
@@ -309,7 +309,7 @@ int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   hipLaunchKernelGGL(msm_hist_kernel, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur);
   smem_opt_in(c, (const void*)msm_partition_kernel, PARTITION_LDS);
-  hipLaunchKernelGGL(msm_partition_kernel, dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, c->srs_n,
+  hipLaunchKernelGGL(msm_partition_kernel, dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
                      w.coarse_off, w.coarse_cur, w.tmp_words);
   hipLaunchKernelGGL(msm_fine_kernel, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, w.tmp_words,
                      w.entries, w.offsets);

@@ -54,6 +54,8 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   int count;
   uint32_t ksl;   // entries per slice of this launch
   uint64_t cap_m, cap_slices;
+  const void* table;   // window tables the entries index: the context's commit key, or a prover's Lagrange-basis key
+  uint64_t table_n;    // points per window row of `table`
 };
 
 struct MsmWork {   // per-context scratch, grown on demand
@@ -144,8 +146,14 @@ int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 // bit_sums = false: out[k] = the commitment (one XYZZ point).  true: out[k][0..16) = partial sums the
 // host combines with a short doubling chain (msm.hip msm_bits_kernel, prover.hip finish_bit_sums).
 static constexpr int MSM_BIT_SUMS = 16;
+// table == nullptr: the context's commit key; otherwise window tables built by srs_table_build (same layout)
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
-                     bool bit_sums = false);
+                     bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0);
+// window tables 2^(16 w) * P_i for n points given as G1Affine (caller frees *table_out with hipFree)
+int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out);
+// [L_i(tau)] G for the size-n domain (n = 2^L) from the context's commit key (needs n + 2 points), followed by the
+// two blinding points [tau^n] G - G and [tau^(n+1)] G - [tau] G: n + 2 affine points (an EC inverse FFT)
+int lagrange_points_device(Ctx* c, uint32_t L, G1Affine* out_dev);
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
 // host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);

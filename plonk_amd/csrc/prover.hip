@@ -90,6 +90,11 @@ struct Prover {
   Fr* Fbuf = nullptr;              // [cpr][n] per-class quotient evaluations -> remainders
   Fr* send = nullptr;              // [world][cpr][stride]
   Fr* recv = nullptr;
+  // Lagrange-basis commit key of the proving domain (single GPU): the wire commitments are taken from the wire
+  // VALUES, [L_i(tau)] G tables + the two blinding points, so small witness values cost few additions (zero
+  // digits never reach the accumulation) and the wire iNTTs leave the critical path
+  void* lag_table = nullptr;       // window tables over n + 2 points (lagrange_points_device)
+  Fr* wscal = nullptr;             // [4][n + 2] wire values followed by the column's two blinders
   Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
   Fr* scratch2 = nullptr;          // [np + 1]
   plonk_allgather_fn allgather = nullptr;
@@ -139,10 +144,15 @@ static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 16 bit su
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
 // [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
 // fetch_commitments.  With world == 1 this is the whole MSM.
-static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int count, int first_slot) {
+static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int count, int first_slot,
+                     const void* table = nullptr, uint64_t table_n = 0) {
   const Fr* sc[MSM_MAX_BATCH];
   uint64_t cnt[MSM_MAX_BATCH];
   G1* out[MSM_MAX_BATCH];
+  if (table) {   // a prover-owned key (Lagrange basis, single GPU): no point-range sharding
+    for (int k = 0; k < count; ++k) out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
+    return msm_batch_device(p->c, scalars, m, count, out, true, table, table_n);
+  }
   for (int k = 0; k < count; ++k) {
     if (m[k] > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
     const uint64_t lo = p->shard_lo;
@@ -190,7 +200,7 @@ static void prover_free(Prover* p) {
                   p->tparts, p->agg, p->wit, p->wit2, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
-  for (void* b : {(void*)p->fold, (void*)p->Fbuf, (void*)p->send, (void*)p->recv, (void*)p->agg2, (void*)p->scratch2}) if (b) (void)hipFree(b);
+  for (void* b : {(void*)p->fold, (void*)p->Fbuf, (void*)p->send, (void*)p->recv, (void*)p->agg2, (void*)p->scratch2, p->lag_table, (void*)p->wscal}) if (b) (void)hipFree(b);
   for (int k = 0; k < 8; ++k) { ntt_coset_free(&p->cs_fwd[k]); ntt_coset_free(&p->cs_inv[k]); }
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
@@ -414,6 +424,19 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
     }
     PTRY(fetch_commitments(p, 0, 15, p->vk));
   }
+  {
+    const char* wc = getenv("PLONK_WIRE_COMMIT");   // "coeff": commit to the coefficient form like the reference (A/B, fallback)
+    if (p->world == 1 && !(wc && wc[0] == 'c') && c->srs_n >= n + 2 && n >= 2) {
+      G1Affine* lag_pts = nullptr;
+      HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * (n + 2)));
+      int rc = lagrange_points_device(c, L, lag_pts);
+      if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table);
+      if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+      (void)hipFree(lag_pts);
+      if (rc) return rc;
+      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 4 * (n + 2)));
+    }
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   guard.p = nullptr;
   *out = p;
@@ -445,27 +468,46 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
 
   uint8_t comm[11][48];
   // ---- round 1 (prover.rs:444-479)
-  prof_begin(c, 4);   // slot 4: the polynomial work of rounds 1-2 (replicated on every rank of a multi-GPU run)
-  for (int k = 0; k < 4; ++k) {
-    Fr* wp = p->wpoly + k * np;
-    if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
-    PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
-    BlindArgs ba;
-    ba.count = 2;
-    ba.b[0] = bl[2 * k];
-    ba.b[1] = bl[2 * k + 1];
-    PTRY(poly_fill_zero(c, wp + n, np - n));
-    PTRY(poly_blind(c, wp, n, ba));
+  const bool lag = p->lag_table != nullptr;
+  // iNTT + blinding of the four columns and their lowest coefficients (quotient_low), on the CURRENT stream
+  auto wire_polynomials = [&](Fr* ntt_tmp) -> int {
+    prof_begin(c, 4);   // slot 4: the polynomial work of rounds 1-2 (replicated on every rank of a multi-GPU run)
+    for (int k = 0; k < 4; ++k) {
+      Fr* wp = p->wpoly + k * np;
+      if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
+      PTRY(ntt_device(c, wires_dev + k * n, wp, ntt_tmp, L, true, false, n));
+      BlindArgs ba;
+      ba.count = 2;
+      ba.b[0] = bl[2 * k];
+      ba.b[1] = bl[2 * k + 1];
+      PTRY(poly_fill_zero(c, wp + n, np - n));
+      PTRY(poly_blind(c, wp, n, ba));
+    }
+    prof_end(c, 4);
+    for (int k = 0; k < 4; ++k)
+      HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    return PLONK_OK;
+  };
+  if (!lag) {
+    PTRY(wire_polynomials(p->tmp8));
+  } else {
+    // Lagrange-basis key: a(X) = sum_i w_i L_i(X) + b0 (X^n - 1) + b1 (X^(n+1) - X)  (blind_poly, prover.rs:139-152), so the
+    // commitment is an MSM of the wire VALUES and the two blinders over [L_i(tau)] G, [tau^n] G - G, [tau^(n+1)] G - [tau] G
+    for (int k = 0; k < 4; ++k) {
+      if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));
+      Fr* ws = p->wscal + (uint64_t)k * (n + 2);
+      HIP_TRY(hipMemcpyAsync(ws, wires_dev + k * n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(hipMemcpyAsync(ws + n, bl + 2 * k, 2 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+    }
   }
-  prof_end(c, 4);
   SideJoin side_join{c};
   uint64_t pi_len = 0;
-  for (int k = 0; k < 4; ++k)   // lowest coefficients of the blinded wire polynomials (quotient_low)
-    HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
-    // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments below
+    // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments below; with the
+    // Lagrange key the wire polynomials themselves are only needed from round 3 on and move there too
     SideScope side(c, p->ev_ready);
+    if (lag) PTRY(wire_polynomials(p->tmp8b));
     for (int k = 0; k < 4; ++k)
       PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + p->lq, false, true, n + 2));
     PTRY(poly_fill_zero(c, p->pipoly, np));
@@ -488,9 +530,14 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     if (pi_len) PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + p->lq, false, true, pi_len));   // no public inputs: PI(X) = 0, nothing to transform or read
   }
   {
-    const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
-    PTRY(msm_group(p, sc, ms, 4, 0));   // commit_polynomials (prover.rs:187-210) as one group launch
+    if (lag) {
+      const Fr* sc[4] = {p->wscal, p->wscal + (n + 2), p->wscal + 2 * (n + 2), p->wscal + 3 * (n + 2)};
+      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, n + 2));
+    } else {
+      const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
+      PTRY(msm_group(p, sc, ms, 4, 0));   // commit_polynomials (prover.rs:187-210) as one group launch
+    }
   }
   PTRY(fetch_commitments(p, 0, 4, comm));
   tr.append_commitment("a_comm", comm[0]);
