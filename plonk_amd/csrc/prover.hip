@@ -488,9 +488,12 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     return PLONK_OK;
   };
-  if (!lag) {
-    PTRY(wire_polynomials(p->tmp8));
-  } else {
+  // Up to 2^18 gates the GPU is not saturated by the commitment pipeline and the wire polynomials (needed from round 3
+  // on) ride on the side stream under it; above, the accumulation owns the VALU and the side stream would only fall
+  // behind (A/B at 2^20, r02: +0.7 ms), so they keep their place in front of the commitment.
+  const bool polys_on_side = lag && L <= 18;
+  if (!polys_on_side) PTRY(wire_polynomials(p->tmp8));
+  if (lag) {
     // Lagrange-basis key: a(X) = sum_i w_i L_i(X) + b0 (X^n - 1) + b1 (X^(n+1) - X)  (blind_poly, prover.rs:139-152), so the
     // commitment is an MSM of the wire VALUES and the two blinders over [L_i(tau)] G, [tau^n] G - G, [tau^(n+1)] G - [tau] G
     for (int k = 0; k < 4; ++k) {
@@ -507,7 +510,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments below; with the
     // Lagrange key the wire polynomials themselves are only needed from round 3 on and move there too
     SideScope side(c, p->ev_ready);
-    if (lag) PTRY(wire_polynomials(p->tmp8b));
+    if (polys_on_side) PTRY(wire_polynomials(p->tmp8b));
     for (int k = 0; k < 4; ++k)
       PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + p->lq, false, true, n + 2));
     PTRY(poly_fill_zero(c, p->pipoly, np));
