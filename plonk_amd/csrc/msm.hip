@@ -248,15 +248,15 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
 
 // bucket[b] = sum of its slice partials.  Uniform scalars give ~16 slices per bucket: two lanes
 // per bucket (strided partial sums + one LDS step) keep the SIMDs busy without idling lanes in a
-// deep tree.  A bucket that attracted a large share of the scalars (equal coefficients => equal
-// digits: up to m/32 slices) is left to msm_bucket_heavy_kernel, where a whole workgroup
-// cooperates on it — m/8192 serial additions instead of m/64.  Lanes per bucket follow the expected
-// slice count: 1 (sparse), 2 (m ~ 2^20: 16 slices), 4, 8 (m >= 2^22).
-static constexpr uint32_t BS_HEAVY = 128;   // slices; never reached by uniformly distributed digits
+// deep tree.  Lanes per bucket follow the expected slice count: 1 (sparse), 2 (m ~ 2^20: 16 slices), 4, 8 (m >= 2^22).
+// A bucket with more than `heavy_thresh` slices is "heavy": its lanes here skip it and append it to a list; the
+// workgroups of msm_bucket_heavy_kernel take the listed buckets round-robin (skewed digits put the heavy buckets
+// next to each other — small values — so they must not be tied to a bucket range).
 template <int BS_G>   // lanes per bucket, chosen from the expected slices per bucket (msm_batch_device)
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
-                                                             G1RSlot* __restrict__ buckets_all) {
+                                                             G1RSlot* __restrict__ buckets_all, uint32_t heavy_thresh,
+                                                             uint32_t* __restrict__ nheavy_all, uint32_t* __restrict__ heavy_list_all) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -268,9 +268,11 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   bool heavy = false;
   if (b < MSM_NB) {
     const uint32_t beg = slice_off[b], end = slice_off[b + 1];
-    heavy = end - beg > BS_HEAVY;
+    heavy = end - beg > heavy_thresh;
     if (!heavy)
       for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
+    else if (g == 0)
+      heavy_list_all[(uint64_t)kb * MSM_NB + atomicAdd(&nheavy_all[kb], 1u)] = b;
   }
   for (int d = BS_G / 2; d >= 1; d >>= 1) {
     sh[threadIdx.x] = acc;
@@ -281,28 +283,23 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   if (g == 0 && b < MSM_NB && !heavy) st_g1r(buckets + b, acc);
 }
 
-// the heavy buckets: 256 workgroups sweep the bucket range; a workgroup that finds one sums it
-// with 256 lanes (strided) and an 8-step LDS tree.  Costs a few microseconds when there is none.
+// the heavy buckets: each is summed by a whole workgroup (256 lanes strided over its slices, then an 8-step LDS
+// tree); HEAVY_WGS workgroups take the list round-robin.  Costs a few microseconds when the list is empty.
+static constexpr uint32_t HEAVY_WGS = 512;
 __global__ void __launch_bounds__(256) msm_bucket_heavy_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                                const uint32_t* __restrict__ slice_off_all,
-                                                               G1RSlot* __restrict__ buckets_all) {
+                                                               G1RSlot* __restrict__ buckets_all,
+                                                               const uint32_t* __restrict__ nheavy_all,
+                                                               const uint32_t* __restrict__ heavy_list_all) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
   G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
+  const uint32_t* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
   __shared__ G1R sh[256];
-  __shared__ uint32_t heavy[MSM_NB / 256], nheavy;
-  constexpr uint32_t PER = MSM_NB / 256;   // buckets swept by one workgroup: one lane looks at each
-  if (threadIdx.x == 0) nheavy = 0;
-  __syncthreads();
-  if (threadIdx.x < PER) {
-    const uint32_t b = blockIdx.x * PER + threadIdx.x;
-    if (slice_off[b + 1] - slice_off[b] > BS_HEAVY) heavy[atomicAdd(&nheavy, 1u)] = b;
-  }
-  __syncthreads();
-  const uint32_t cnt = nheavy;
-  for (uint32_t i = 0; i < cnt; ++i) {
-    const uint32_t b = heavy[i];
+  const uint32_t cnt = nheavy_all[kb];
+  for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    const uint32_t b = list[i];
     const uint32_t beg = slice_off[b], end = slice_off[b + 1];
     G1R acc = G1R::identity();
     for (uint32_t k = beg + threadIdx.x; k < end; k += 256) acc = acc.add(ld_g1r(partial + k));
@@ -597,6 +594,8 @@ int msm_reserve(Ctx* c, uint64_t m) {
   if (!w.offsets) {
     HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1) * KB));
     HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
+    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * KB));
+    HIP_TRY(hipMalloc((void**)&w.heavy_list, sizeof(uint32_t) * MSM_NB * KB));
     { const int rc_s = msm_sort_reserve_fixed(c); if (rc_s) return rc_s; }
     HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB * KB));
     HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK) * KB));
@@ -669,16 +668,19 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   prof_begin(c, 2);
   {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
+    // heavy = far above the expected slice count (skewed digits): 4 x the uniform average, at least 32 slices
+    const uint32_t heavy_thresh = (uint32_t)(4 * avg_slices > 32 ? 4 * avg_slices : 32);
+    HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * MSM_MAX_BATCH, st));
 #define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128, count), dim3(128), 0, st, bt, \
-                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets)
+                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, w.heavy_list)
     if (avg_slices <= 4) BSUM(1);
     else if (avg_slices <= 16) BSUM(2);
     else if (avg_slices <= 32) BSUM(4);
     else BSUM(8);
 #undef BSUM
   }
-  hipLaunchKernelGGL(msm_bucket_heavy_kernel, dim3(256, count), dim3(256), 0, st, bt,
-                     (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets);
+  hipLaunchKernelGGL(msm_bucket_heavy_kernel, dim3(HEAVY_WGS, count), dim3(256), 0, st, bt,
+                     (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, w.nheavy, w.heavy_list);
   hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);
   if (bit_sums) {

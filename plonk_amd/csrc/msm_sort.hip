@@ -130,13 +130,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
 }
 
 // ---- level 1b: coarse offsets; also clears the run cursors of the partition pass ------------------
+// Skewed digits (many equal or small scalars: bits, quads, range accumulators of a real witness) put a large share
+// of the entries into a few coarse bins.  A bin above BIG_LIMIT words is not left to one workgroup: it is cut into
+// chunks of BIG_CHUNK words that msm_big_hist / msm_big_scatter process in parallel (chunk prefix in big_off).
+static constexpr uint32_t BIG_LIMIT = 1u << 16;
+static constexpr uint32_t BIG_CHUNK = 1u << 14;
+__device__ __forceinline__ uint32_t big_chunks(uint32_t cnt) { return cnt > BIG_LIMIT ? (cnt + BIG_CHUNK - 1) / BIG_CHUNK : 0u; }
+
 __global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t* __restrict__ coarse_cnt_all,
                                                                  uint32_t* __restrict__ coarse_off_all,
-                                                                 uint32_t* __restrict__ coarse_cur_all) {
+                                                                 uint32_t* __restrict__ coarse_cur_all,
+                                                                 uint32_t* __restrict__ big_off_all) {
   __shared__ uint32_t sh[SORT_T];
   const uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)blockIdx.x * COARSE;
   uint32_t* __restrict__ off = coarse_off_all + (uint64_t)blockIdx.x * (COARSE + 1);
   uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)blockIdx.x * COARSE;
+  uint32_t* __restrict__ big = big_off_all + (uint64_t)blockIdx.x * (COARSE + 1);
   const uint32_t t = threadIdx.x;
   const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
   uint32_t total;
@@ -146,6 +155,12 @@ __global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t*
   cur[2 * t] = 0;
   cur[2 * t + 1] = 0;
   if (t == SORT_T - 1) off[COARSE] = total;
+  const uint32_t b0 = big_chunks(c0), b1 = big_chunks(c1);
+  uint32_t btotal;
+  const uint32_t bex = block_exclusive_scan(b0 + b1, sh, &btotal);
+  big[2 * t] = bex;
+  big[2 * t + 1] = bex + b0;
+  if (t == SORT_T - 1) big[COARSE] = btotal;
 }
 
 // ---- level 1c: partition into the coarse bins -----------------------------------------------------
@@ -239,6 +254,7 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
   uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t beg = coff[bin], end = coff[bin + 1];
+  if (end - beg > BIG_LIMIT) return;   // oversized bin: msm_big_hist / msm_big_scatter
   if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
   __syncthreads();
   uint32_t cache[FINE_CACHE > 0 ? FINE_CACHE : 1];
@@ -271,6 +287,89 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
   for (uint32_t r = 0; r < FINE_CACHE; ++r)
     if (beg + t + r * FINE_T < end) place(cache[r]);
   for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) place(tmp[j]);
+}
+
+// ---- level 2 for oversized bins: one workgroup per BIG_CHUNK words --------------------------------
+// work item w -> (bin, chunk) through the chunk prefix big_off; returns false when w is beyond the last item
+__device__ __forceinline__ bool big_item(const uint32_t* __restrict__ big, const uint32_t* __restrict__ coff, uint32_t w,
+                                         uint32_t* bin, uint32_t* beg, uint32_t* end) {
+  if (w >= big[COARSE]) return false;
+  uint32_t lo = 0, hi = COARSE - 1;          // last bin with big[bin] <= w (bins without chunks share their successor's prefix)
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (big[mid] <= w) lo = mid; else hi = mid - 1;
+  }
+  *bin = lo;
+  const uint32_t b0 = coff[lo] + (w - big[lo]) * BIG_CHUNK, b1 = coff[lo + 1];
+  *beg = b0;
+  *end = b0 + BIG_CHUNK < b1 ? b0 + BIG_CHUNK : b1;
+  return true;
+}
+static constexpr uint32_t BIG_T = 512;
+static constexpr uint32_t BIG_PER = BIG_CHUNK / BIG_T;   // words per lane, held in registers
+__global__ void __launch_bounds__(BIG_T) msm_big_hist_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
+                                                             const uint32_t* __restrict__ big_off_all,
+                                                             const uint32_t* __restrict__ tmp_all, uint32_t* __restrict__ big_cnt_all) {
+  __shared__ uint32_t cnt[1u << FINE_BITS];
+  const int kb = blockIdx.y;
+  const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
+  const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
+  uint32_t bin, beg, end;
+  if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
+  const uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint32_t t = threadIdx.x;
+  if (t < (1u << FINE_BITS)) cnt[t] = 0;
+  __syncthreads();
+  for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[tmp[j] >> (IDX_BITS + 1)], 1u);
+  __syncthreads();
+  if (t < (1u << FINE_BITS) && cnt[t]) atomicAdd(&big_cnt_all[(uint64_t)kb * MSM_NB + (bin << FINE_BITS) + t], cnt[t]);
+}
+__global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
+                                                                const uint32_t* __restrict__ big_off_all,
+                                                                const uint32_t* __restrict__ tmp_all,
+                                                                const uint32_t* __restrict__ big_cnt_all, uint32_t* __restrict__ big_cur_all,
+                                                                uint32_t* __restrict__ entries_all, uint32_t* __restrict__ offsets_all) {
+  __shared__ uint32_t cnt[1u << FINE_BITS], base[1u << FINE_BITS], cur[1u << FINE_BITS];
+  const int kb = blockIdx.y;
+  const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
+  const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
+  uint32_t bin, beg, end;
+  if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
+  const uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ bcnt = big_cnt_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
+  uint32_t* __restrict__ bcur = big_cur_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
+  const uint32_t t = threadIdx.x;
+  if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
+  __syncthreads();
+  uint32_t cache[BIG_PER];
+#pragma unroll
+  for (uint32_t r = 0; r < BIG_PER; ++r) {
+    const uint32_t j = beg + t + r * BIG_T;
+    cache[r] = j < end ? tmp[j] : 0u;
+    if (j < end) atomicAdd(&cnt[cache[r] >> (IDX_BITS + 1)], 1u);
+  }
+  __syncthreads();
+  if (t == 0) {   // bucket starts inside the bin from the bin-wide counts; this chunk's run in every bucket by one atomic each
+    uint32_t run = coff[bin];
+    const bool first = beg == coff[bin];
+    for (uint32_t f = 0; f < (1u << FINE_BITS); ++f) {
+      if (first) offsets[(bin << FINE_BITS) + f] = run;
+      base[f] = run + (cnt[f] ? atomicAdd(&bcur[f], cnt[f]) : 0u);
+      run += bcnt[f];
+    }
+    if (first && bin == COARSE - 1) offsets[MSM_NB] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t r = 0; r < BIG_PER; ++r) {
+    if (beg + t + r * BIG_T < end) {
+      const uint32_t e = cache[r];
+      const uint32_t f = e >> (IDX_BITS + 1);
+      entries[base[f] + atomicAdd(&cur[f], 1u)] = (e & IDX_MASK) | (((e >> IDX_BITS) & 1u) << 31);
+    }
+  }
 }
 
 // ---- slice offsets: slice_off[b] = sum_{b' < b} ceil(count[b'] / ksl), one workgroup per commitment
@@ -307,12 +406,20 @@ int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
   hipLaunchKernelGGL(msm_hist_kernel, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
-  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur);
+  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
   smem_opt_in(c, (const void*)msm_partition_kernel, PARTITION_LDS);
   hipLaunchKernelGGL(msm_partition_kernel, dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
                      w.coarse_off, w.coarse_cur, w.tmp_words);
   hipLaunchKernelGGL(msm_fine_kernel, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, w.tmp_words,
                      w.entries, w.offsets);
+  {   // oversized bins (skewed digits): upper bound of the chunk count known on the host, surplus workgroups exit at once
+    const uint64_t words = (uint64_t)MSM_W * mmax;
+    const uint32_t big_wgs = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
+    HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
+    hipLaunchKernelGGL(msm_big_hist_kernel, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, w.tmp_words, w.big_cnt);
+    hipLaunchKernelGGL(msm_big_scatter_kernel, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, w.tmp_words,
+                       w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
+  }
   hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
@@ -324,6 +431,8 @@ int msm_sort_reserve_fixed(Ctx* c) {
   HIP_TRY(hipMalloc((void**)&w.coarse_cnt, sizeof(uint32_t) * COARSE * KB));
   HIP_TRY(hipMalloc((void**)&w.coarse_off, sizeof(uint32_t) * (COARSE + 1) * KB));
   HIP_TRY(hipMalloc((void**)&w.coarse_cur, sizeof(uint32_t) * COARSE * KB));
+  HIP_TRY(hipMalloc((void**)&w.big_off, sizeof(uint32_t) * (COARSE + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.big_cnt, sizeof(uint32_t) * 2 * MSM_NB * KB));   // bin-wide bucket counts, then the run cursors
   return PLONK_OK;
 }
 

@@ -65,11 +65,15 @@ struct MsmWork {   // per-context scratch, grown on demand
   uint32_t* coarse_cnt = nullptr;  // 2048 per commitment
   uint32_t* coarse_off = nullptr;  // 2049
   uint32_t* coarse_cur = nullptr;  // 2048
+  uint32_t* big_off = nullptr;     // 2049: chunk prefix of the oversized coarse bins (skewed digits)
+  uint32_t* big_cnt = nullptr;     // 2 x NB: bucket counts / run cursors of the oversized bins
   uint32_t* offsets = nullptr;     // NB + 1
   uint32_t* slice_off = nullptr;   // NB + 1
   uint64_t cap_slices = 0;
   void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
   void* buckets = nullptr;         // NB
+  uint32_t* nheavy = nullptr;      // per commitment: number of heavy buckets of this launch
+  uint32_t* heavy_list = nullptr;  // NB per commitment
   void* chunk = nullptr;           // row / column sums
   uint8_t* result = nullptr;       // 97 B device
   uint8_t* result_host = nullptr;  // pinned
