@@ -249,14 +249,19 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
 // bucket[b] = sum of its slice partials.  Uniform scalars give ~16 slices per bucket: two lanes
 // per bucket (strided partial sums + one LDS step) keep the SIMDs busy without idling lanes in a
 // deep tree.  Lanes per bucket follow the expected slice count: 1 (sparse), 2 (m ~ 2^20: 16 slices), 4, 8 (m >= 2^22).
-// A bucket with more than `heavy_thresh` slices is "heavy": its lanes here skip it and append it to a list; the
-// workgroups of msm_bucket_heavy_kernel take the listed buckets round-robin (skewed digits put the heavy buckets
-// next to each other — small values — so they must not be tied to a bucket range).
+// A bucket with more than `heavy_thresh` slices is "heavy" (skewed digits: equal or small scalars — the bits, quads and
+// range accumulators of a real witness).  Its lanes here skip it; lane 0 cuts it into segments of HEAVY_SEG slices and
+// appends (bucket, first segment, segment count) to a list.  msm_heavy_seg_kernel sums one segment per workgroup
+// (one slice per lane + an 8-step LDS tree), msm_heavy_bucket_kernel the segment sums of one bucket per workgroup:
+// ~14 dependent additions for a bucket of any size, and the heavy buckets — which sit next to each other at the
+// small bucket indices — are spread over the whole chip.
+static constexpr uint32_t HEAVY_SEG = 256;
+struct HeavyItem { uint32_t bucket, seg_base, nseg, pad; };
 template <int BS_G>   // lanes per bucket, chosen from the expected slices per bucket (msm_batch_device)
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all, uint32_t heavy_thresh,
-                                                             uint32_t* __restrict__ nheavy_all, uint32_t* __restrict__ heavy_list_all) {
+                                                             uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -269,10 +274,17 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   if (b < MSM_NB) {
     const uint32_t beg = slice_off[b], end = slice_off[b + 1];
     heavy = end - beg > heavy_thresh;
-    if (!heavy)
+    if (!heavy) {
       for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
-    else if (g == 0)
-      heavy_list_all[(uint64_t)kb * MSM_NB + atomicAdd(&nheavy_all[kb], 1u)] = b;
+    } else if (g == 0) {
+      const uint32_t nseg = (end - beg + HEAVY_SEG - 1) / HEAVY_SEG;
+      HeavyItem it;
+      it.bucket = b;
+      it.nseg = nseg;
+      it.seg_base = atomicAdd(&nheavy_all[2 * kb + 1], nseg);     // [2 kb]: heavy buckets, [2 kb + 1]: segments
+      it.pad = 0;
+      heavy_list_all[(uint64_t)kb * MSM_NB + atomicAdd(&nheavy_all[2 * kb], 1u)] = it;
+    }
   }
   for (int d = BS_G / 2; d >= 1; d >>= 1) {
     sh[threadIdx.x] = acc;
@@ -283,33 +295,66 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   if (g == 0 && b < MSM_NB && !heavy) st_g1r(buckets + b, acc);
 }
 
-// the heavy buckets: each is summed by a whole workgroup (256 lanes strided over its slices, then an 8-step LDS
-// tree); HEAVY_WGS workgroups take the list round-robin.  Costs a few microseconds when the list is empty.
-static constexpr uint32_t HEAVY_WGS = 512;
-__global__ void __launch_bounds__(256) msm_bucket_heavy_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
-                                                               const uint32_t* __restrict__ slice_off_all,
-                                                               G1RSlot* __restrict__ buckets_all,
-                                                               const uint32_t* __restrict__ nheavy_all,
-                                                               const uint32_t* __restrict__ heavy_list_all) {
+static constexpr uint32_t HEAVY_WGS = 1024;
+__device__ __forceinline__ G1R wg_tree_sum256(G1R acc, G1R* sh) {
+  for (int d = 128; d >= 1; d >>= 1) {
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < d) acc = acc.add(sh[threadIdx.x + d]);
+    __syncthreads();
+  }
+  return acc;
+}
+// stage 1: workgroup w of a commitment handles segment w, w + HEAVY_WGS, ... of the launch; an item's segments are
+// numbered contiguously from its seg_base, so the owner of a segment is found by one pass of the 256 lanes over the
+// (short, unordered) item list
+__global__ void __launch_bounds__(256) msm_heavy_seg_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
+                                                            const uint32_t* __restrict__ slice_off_all,
+                                                            const uint32_t* __restrict__ nheavy_all,
+                                                            const HeavyItem* __restrict__ heavy_list_all,
+                                                            G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
-  G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
-  const uint32_t* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
+  const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
+  G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
   __shared__ G1R sh[256];
-  const uint32_t cnt = nheavy_all[kb];
-  for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
-    const uint32_t b = list[i];
-    const uint32_t beg = slice_off[b], end = slice_off[b + 1];
-    G1R acc = G1R::identity();
-    for (uint32_t k = beg + threadIdx.x; k < end; k += 256) acc = acc.add(ld_g1r(partial + k));
-    for (int d = 128; d >= 1; d >>= 1) {
-      sh[threadIdx.x] = acc;
-      __syncthreads();
-      if ((int)threadIdx.x < d) acc = acc.add(sh[threadIdx.x + d]);
-      __syncthreads();
+  __shared__ uint32_t found[2];
+  const uint32_t nitems = nheavy_all[2 * kb], nsegs = nheavy_all[2 * kb + 1];
+  for (uint32_t sg = blockIdx.x; sg < nsegs; sg += gridDim.x) {
+    // which item owns segment sg: lanes test disjoint parts of the list
+    for (uint32_t i = threadIdx.x; i < nitems; i += 256) {
+      const HeavyItem it = list[i];
+      if (sg >= it.seg_base && sg < it.seg_base + it.nseg) { found[0] = it.bucket; found[1] = sg - it.seg_base; }
     }
-    if (threadIdx.x == 0) st_g1r(buckets + b, acc);
+    __syncthreads();
+    const uint32_t b = found[0], j = found[1];
+    const uint32_t beg = slice_off[b] + j * HEAVY_SEG, bend = slice_off[b + 1];
+    const uint32_t k = beg + threadIdx.x;
+    G1R acc = k < bend ? ld_g1r(partial + k) : G1R::identity();
+    acc = wg_tree_sum256(acc, sh);
+    if (threadIdx.x == 0) st_g1r(seg_sum + sg, acc);
+    __syncthreads();
+  }
+}
+// stage 2: one heavy bucket per workgroup: sum of its segment sums
+__global__ void __launch_bounds__(256) msm_heavy_bucket_kernel(const uint32_t* __restrict__ nheavy_all,
+                                                               const HeavyItem* __restrict__ heavy_list_all,
+                                                               const G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap,
+                                                               G1RSlot* __restrict__ buckets_all) {
+  const int kb = blockIdx.y;
+  const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
+  const G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
+  G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
+  __shared__ G1R sh[256];
+  const uint32_t nitems = nheavy_all[2 * kb];
+  for (uint32_t i = blockIdx.x; i < nitems; i += gridDim.x) {
+    const HeavyItem it = list[i];
+    G1R acc = G1R::identity();
+    for (uint32_t k = threadIdx.x; k < it.nseg; k += 256) acc = acc.add(ld_g1r(seg_sum + it.seg_base + k));
+    acc = wg_tree_sum256(acc, sh);
+    if (threadIdx.x == 0) st_g1r(buckets + it.bucket, acc);
+    __syncthreads();
   }
 }
 
@@ -594,8 +639,8 @@ int msm_reserve(Ctx* c, uint64_t m) {
   if (!w.offsets) {
     HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1) * KB));
     HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
-    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * KB));
-    HIP_TRY(hipMalloc((void**)&w.heavy_list, sizeof(uint32_t) * MSM_NB * KB));
+    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * 2 * KB));
+    HIP_TRY(hipMalloc((void**)&w.heavy_list, sizeof(HeavyItem) * MSM_NB * KB));
     { const int rc_s = msm_sort_reserve_fixed(c); if (rc_s) return rc_s; }
     HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB * KB));
     HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK) * KB));
@@ -608,13 +653,15 @@ int msm_reserve(Ctx* c, uint64_t m) {
     // that a failed reallocation cannot leave a stale cap_m pointing at freed memory
     HIP_TRY(hipStreamSynchronize(c->stream));
     w.cap_m = 0;
-    for (void** q : {(void**)&w.tmp_words, (void**)&w.entries, (void**)&w.partial}) {
+    for (void** q : {(void**)&w.tmp_words, (void**)&w.entries, (void**)&w.partial, &w.seg_sum}) {
       if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     }
     HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint32_t) * MSM_W * cap * KB));  // words grouped by coarse bin
     HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
     w.cap_slices = msm_slice_cap(cap);
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
+    w.cap_segs = w.cap_slices / HEAVY_SEG + MSM_NB + 1;   // sum over heavy buckets of ceil(slices / HEAVY_SEG)
+    HIP_TRY(hipMalloc((void**)&w.seg_sum, sizeof(G1RSlot) * w.cap_segs * KB));
     w.cap_m = cap;
   }
   return PLONK_OK;
@@ -668,19 +715,21 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   prof_begin(c, 2);
   {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
-    // heavy = far above the expected slice count (skewed digits): 4 x the uniform average, at least 32 slices
-    const uint32_t heavy_thresh = (uint32_t)(4 * avg_slices > 32 ? 4 * avg_slices : 32);
-    HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * MSM_MAX_BATCH, st));
+    // heavy = well above the expected slice count (skewed digits): twice the uniform average, at least 16 slices
+    const uint32_t heavy_thresh = (uint32_t)(2 * avg_slices > 16 ? 2 * avg_slices : 16);
+    HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 2 * MSM_MAX_BATCH, st));
 #define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128, count), dim3(128), 0, st, bt, \
-                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, w.heavy_list)
+                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list)
     if (avg_slices <= 4) BSUM(1);
     else if (avg_slices <= 16) BSUM(2);
     else if (avg_slices <= 32) BSUM(4);
     else BSUM(8);
 #undef BSUM
   }
-  hipLaunchKernelGGL(msm_bucket_heavy_kernel, dim3(HEAVY_WGS, count), dim3(256), 0, st, bt,
-                     (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, w.nheavy, w.heavy_list);
+  hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(HEAVY_WGS, count), dim3(256), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
+                     w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
+  hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
+                     (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
   hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);
   if (bit_sums) {

@@ -72,8 +72,10 @@ struct MsmWork {   // per-context scratch, grown on demand
   uint64_t cap_slices = 0;
   void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
   void* buckets = nullptr;         // NB
-  uint32_t* nheavy = nullptr;      // per commitment: number of heavy buckets of this launch
-  uint32_t* heavy_list = nullptr;  // NB per commitment
+  uint32_t* nheavy = nullptr;      // per commitment: number of heavy buckets / of their segments in this launch
+  void* heavy_list = nullptr;      // NB items per commitment (msm.hip HeavyItem)
+  void* seg_sum = nullptr;         // segment sums of the heavy buckets
+  uint64_t cap_segs = 0;
   void* chunk = nullptr;           // row / column sums
   uint8_t* result = nullptr;       // 97 B device
   uint8_t* result_host = nullptr;  // pinned
