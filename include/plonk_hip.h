@@ -121,7 +121,10 @@ void* plonk_ctx_stream(plonk_ctx* ctx); /* the hipStream_t of the context's main
  *   seed the transcript (widget.rs:218-258); NULL = commit to the polynomials on the GPU as
  *   Compiler::preprocess does (src/compiler.rs:213-232).
  * The 8n coset evaluations, sigma evaluations and vanishing inverses (compiler.rs:310-425,
- * prover.rs:78-100) are rebuilt on the device. */
+ * prover.rs:78-100) are rebuilt on the device.  On one GPU the prover also derives the Lagrange-basis form of the
+ * commit key ([L_i(tau)] G, an inverse FFT over the group — needs size + 2 key points) and takes the four wire
+ * commitments from the wire VALUES: the same group elements as CommitKey::commit of the blinded coefficient forms
+ * (prover.rs:139-152,187-210), cheaper the smaller the witness values are.  PLONK_WIRE_COMMIT=coeff disables it. */
 typedef struct plonk_prover plonk_prover;
 /* Multi-GPU (one process per GPU): rank r loads only SRS points [r*S, (r+1)*S), S = ceil(srs_total / world),
  * into its context (srs_total >= size + 7) and owns the same range of polynomial COEFFICIENTS:
