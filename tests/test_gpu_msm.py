@@ -177,3 +177,25 @@ def test_skewed_scalars_take_the_heavy_bucket_path(ctx):
                [Q - 1] * 9000):                                                     # all-negative digits
         k = g * sum(s * t for s, t in zip(sc, geo)) % Q
         assert ctx.msm(sc) == E.g1_mul(E.G1_GEN, k)
+
+
+def test_small_scalars_take_the_chunked_bin_and_segmented_bucket_paths(ctx):
+    """Witness-like scalars (bits, quads, small range accumulators): most digits are zero and dropped, the rest pile
+    into a handful of buckets — one coarse bin of the sort far above 2^16 words (msm_big_hist / msm_big_scatter) and
+    buckets of thousands of slices (msm_heavy_seg / msm_heavy_bucket).  Closed form on the [g tau^i] G key."""
+    r = random.Random(43)
+    n = 150000
+    tau, g = r.randrange(1, Q), r.randrange(1, Q)
+    buf = _gen_srs_dev(ctx, n, tau, g)
+    ctx.srs_load_dev(buf.ptr, n)
+    buf.free()
+    geo, p = [], 1
+    for _ in range(n):
+        geo.append(p)
+        p = p * tau % Q
+    for sc in ([r.randrange(4) for _ in range(n)],                                    # 2-bit quads: buckets 0..2 only
+               [r.randrange(4) if i % 2 else r.randrange(Q) for i in range(n)],       # the bench-like mix
+               [(1 << 16) * r.randrange(1, 3) + r.randrange(2) for _ in range(n)],    # two windows, both concentrated
+               [Q - 1 - r.randrange(3) for _ in range(n)]):                           # small negatives: every window, sign set
+        k = g * sum(s * t for s, t in zip(sc, geo)) % Q
+        assert ctx.msm(sc) == E.g1_mul(E.G1_GEN, k)

@@ -142,3 +142,38 @@ def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     expected = cp.prove(wires, [], b"", bl)
     cp.close()
     assert got == expected
+
+
+@pytest.mark.parametrize("profile,log_n", [("bench-like", 13), ("widgets", 13), ("dense", 12)])
+def test_wire_commitment_modes_agree_with_each_other_and_the_oracle(ctx, monkeypatch, profile, log_n):
+    """The wire commitments taken from the wire VALUES over the Lagrange-basis key (default on one GPU) and from the
+    blinded coefficient forms (PLONK_WIRE_COMMIT=coeff, the reference's way) are the same group elements: both modes
+    must reproduce the C oracle's proof bytes on bench.py's workloads, including the skewed `bench-like` witness."""
+    import bench_circuits as BC
+    import plonk_amd
+    monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    n = 1 << log_n
+    if profile == "widgets":
+        wires, cols, pi = BC.widget_circuit(log_n)
+        trivial = {}
+    else:
+        wires, cols, trivial = BC.arithmetic_circuit(log_n, profile)
+        pi = {}
+    polys = {k: C.fr_bytes(v) for k, v in trivial.items()}
+    for name, raw in cols.items():
+        polys[name] = cbind.ntt_bytes(raw, log_n, True, False, n)
+    srs = C.synthetic_srs(n + 7)
+    idx = sorted(pi)
+    case = dict(constraints=n, size=n, label=b"modes", polys=polys, wires=wires, pi=pi, pi_idx=idx,
+                pi_val=C.fr_bytes([pi[i] for i in idx]))
+    cp = cbind.CProver(n, b"modes", polys, srs)
+    bl = C.blinders(99)
+    expected = cp.prove(wires, idx, case["pi_val"], bl)
+    want_vk = cp.vk()
+    cp.close()
+    monkeypatch.delenv("PLONK_WIRE_COMMIT", raising=False)
+    lag, vk = gpu_proof(ctx, case, srs, bl)
+    monkeypatch.setenv("PLONK_WIRE_COMMIT", "coeff")
+    coeff, vk2 = gpu_proof(ctx, case, srs, bl)
+    assert vk == vk2 == want_vk
+    assert lag == expected and coeff == expected
