@@ -674,7 +674,7 @@ void prof_end(Ctx* c, int slot);
 // latency-bound reduction kernels run once per group instead of once per commitment
 // (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums,
-                     const void* table, uint64_t table_n) {
+                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split) {
   if (count <= 0) return PLONK_OK;
   if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   if (!table) { table = c->srs_table; table_n = c->srs_n; }
@@ -701,7 +701,11 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   bt.cap_slices = w.cap_slices;
   bt.table = table;
   bt.table_n = table_n;
-  for (int k = 0; k < count; ++k) { bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k]; }
+  for (int k = 0; k < count; ++k) {
+    bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k];
+    bt.tail[k] = tail_dev ? tail_dev[k] : nullptr;
+    bt.split[k] = (tail_dev && split) ? split[k] : ~0ull;
+  }
   prof_begin(c, 2);
   rc = msm_group_sort(c, bt, mmax);
   prof_end(c, 2);

@@ -42,6 +42,11 @@ static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
 static_assert(COARSE == 2 * SORT_T, "scan / reservation loops assume two coarse bins per thread");
 static_assert(IDX_BITS + 1 + FINE_BITS == 32, "intermediate word layout");
 
+__device__ __forceinline__ Fr ld_scalar(const Fr* p);
+// scalar i of commitment kb: the main array below the split, the tail array above
+__device__ __forceinline__ Fr ld_scalar_at(const MsmBatch& bt, int kb, uint64_t i) {
+  return i < bt.split[kb] ? ld_scalar(bt.scalars[kb] + i) : ld_scalar(bt.tail[kb] + (i - bt.split[kb]));
+}
 __device__ __forceinline__ Fr ld_scalar(const Fr* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   const uint4 a = q[0], b = q[1];
@@ -89,12 +94,11 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
   hist[t] = 0;
   hist[t + SORT_T] = 0;
   __syncthreads();
-  const Fr* __restrict__ scalars = bt.scalars[kb];
   Fr raw[HIST_PER];   // all loads of the thread in flight before the first conversion
 #pragma unroll
   for (uint32_t k = 0; k < HIST_PER; ++k) {
     const uint64_t i = base + t + (uint64_t)k * SORT_T;
-    if (i < m) raw[k] = ld_scalar(scalars + i);
+    if (i < m) raw[k] = ld_scalar_at(bt, kb, i);
   }
 #pragma unroll
   for (uint32_t k = 0; k < HIST_PER; ++k) {
@@ -185,7 +189,6 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
   hist[t] = 0;
   hist[t + SORT_T] = 0;
   __syncthreads();
-  const Fr* __restrict__ scalars = bt.scalars[kb];
   // words and (bin << 16 | rank) of this thread's entries stay in registers until the runs are known
   uint32_t word[PER_T][MSM_W], where[PER_T][MSM_W];
 #pragma unroll
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
     for (int w = 0; w < MSM_W; ++w) where[k][w] = 0xffffffffu;
     const uint64_t i = base + t + (uint64_t)k * SORT_T;
     if (i < m) {
-      const Fr s = scalar_canonical(ld_scalar(scalars + i));
+      const Fr s = scalar_canonical(ld_scalar_at(bt, kb, i));
       for_each_digit(s, [&](int w, uint32_t bucket, uint32_t sign) {
         const uint32_t bin = bucket >> FINE_BITS;
         const uint32_t rank = atomicAdd(&hist[bin], 1u);          // < TILE * MSM_W = 2^15

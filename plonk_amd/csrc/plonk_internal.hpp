@@ -56,6 +56,10 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   uint64_t cap_m, cap_slices;
   const void* table;   // window tables the entries index: the context's commit key, or a prover's Lagrange-basis key
   uint64_t table_n;    // points per window row of `table`
+  // scalars of commitment k: scalars[k][i] for i < split[k], tail[k][i - split[k]] above (a wire column in place + its
+  // blinders elsewhere); split[k] >= m[k] when the scalars are one array
+  const Fr* tail[MSM_MAX_BATCH];
+  uint64_t split[MSM_MAX_BATCH];
 };
 
 struct MsmWork {   // per-context scratch, grown on demand
@@ -154,7 +158,8 @@ int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 static constexpr int MSM_BIT_SUMS = 16;
 // table == nullptr: the context's commit key; otherwise window tables built by srs_table_build (same layout)
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
-                     bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0);
+                     bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0,
+                     const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr);
 // window tables 2^(16 w) * P_i for n points given as G1Affine (caller frees *table_out with hipFree)
 int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out);
 // [L_i(tau)] G for the size-n domain (n = 2^L) from the context's commit key (needs n + 2 points), followed by the

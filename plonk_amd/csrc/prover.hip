@@ -94,7 +94,7 @@ struct Prover {
   // VALUES, [L_i(tau)] G tables + the two blinding points, so small witness values cost few additions (zero
   // digits never reach the accumulation) and the wire iNTTs leave the critical path
   void* lag_table = nullptr;       // window tables over n + 2 points (lagrange_points_device)
-  Fr* wscal = nullptr;             // [4][n + 2] wire values followed by the column's two blinders
+  Fr* wscal = nullptr;             // [8] the wire blinders on the device (tail scalars of the four Lagrange-key MSMs)
   Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
   Fr* scratch2 = nullptr;          // [np + 1]
   plonk_allgather_fn allgather = nullptr;
@@ -145,13 +145,13 @@ static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 16 bit su
 // [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
 // fetch_commitments.  With world == 1 this is the whole MSM.
 static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int count, int first_slot,
-                     const void* table = nullptr, uint64_t table_n = 0) {
+                     const void* table = nullptr, uint64_t table_n = 0, const Fr* const* tail = nullptr, const uint64_t* split = nullptr) {
   const Fr* sc[MSM_MAX_BATCH];
   uint64_t cnt[MSM_MAX_BATCH];
   G1* out[MSM_MAX_BATCH];
   if (table) {   // a prover-owned key (Lagrange basis, single GPU): no point-range sharding
     for (int k = 0; k < count; ++k) out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
-    return msm_batch_device(p->c, scalars, m, count, out, true, table, table_n);
+    return msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split);
   }
   for (int k = 0; k < count; ++k) {
     if (m[k] > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
@@ -434,7 +434,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
       if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
       (void)hipFree(lag_pts);
       if (rc) return rc;
-      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 4 * (n + 2)));
+      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
     }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -496,12 +496,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   if (lag) {
     // Lagrange-basis key: a(X) = sum_i w_i L_i(X) + b0 (X^n - 1) + b1 (X^(n+1) - X)  (blind_poly, prover.rs:139-152), so the
     // commitment is an MSM of the wire VALUES and the two blinders over [L_i(tau)] G, [tau^n] G - G, [tau^(n+1)] G - [tau] G
-    for (int k = 0; k < 4; ++k) {
+    // (the values are read in place; only the eight blinders travel: bl[0..8) = a0 a1 b0 b1 c0 c1 d0 d1)
+    for (int k = 0; k < 4; ++k)
       if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));
-      Fr* ws = p->wscal + (uint64_t)k * (n + 2);
-      HIP_TRY(hipMemcpyAsync(ws, wires_dev + k * n, sizeof(Fr) * n, hipMemcpyDeviceToDevice, c->stream));
-      HIP_TRY(hipMemcpyAsync(ws + n, bl + 2 * k, 2 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
-    }
+    HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
   }
   SideJoin side_join{c};
   uint64_t pi_len = 0;
@@ -535,8 +533,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   {
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
     if (lag) {
-      const Fr* sc[4] = {p->wscal, p->wscal + (n + 2), p->wscal + 2 * (n + 2), p->wscal + 3 * (n + 2)};
-      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, n + 2));
+      const Fr* sc[4] = {wires_dev, wires_dev + n, wires_dev + 2 * n, wires_dev + 3 * n};
+      const Fr* tl[4] = {p->wscal, p->wscal + 2, p->wscal + 4, p->wscal + 6};
+      const uint64_t sp[4] = {n, n, n, n};
+      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, n + 2, tl, sp));
     } else {
       const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
       PTRY(msm_group(p, sc, ms, 4, 0));   // commit_polynomials (prover.rs:187-210) as one group launch
