@@ -163,7 +163,7 @@ def test_full_size_closed_form(ctx, logm):
 
 def test_skewed_scalars_take_the_heavy_bucket_path(ctx):
     """Equal coefficients put every term of a window into ONE bucket (m/32 slices): the
-    cooperative heavy-bucket kernel must give the same group element; mixed with uniform
+    segmented heavy-bucket kernels must give the same group element; mixed with uniform
     scalars so that both bucket-sum kernels contribute to the same commitment."""
     r = random.Random(41)
     n = 20000
