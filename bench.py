@@ -67,6 +67,18 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense"):
     n = 1 << log_n
     srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
+    lag_slice = None
+    if world in (2, 4, 8) and n >= 64 and os.environ.get("PLONK_WIRE_COMMIT", "")[:1] != "c" and os.environ.get("PLONK_SHARD_QUOTIENT", "")[:1] != "0":
+        # multi-GPU: the Lagrange-basis key needs the WHOLE commit key once (a group FFT); every rank derives it from the
+        # full synthetic key and keeps its slice (a real deployment computes it once and ships the slices)
+        full = ctx.alloc(96 * (n + 2))
+        ctx.srs_generate_dev(TAU, G_SCALAR, n + 2, full.ptr)
+        ctx.srs_load_dev(full.ptr, n + 2)
+        full.free()
+        key = ctx.lagrange_key(log_n)
+        llo, lhi = min(lo, n + 2), min(hi, n + 2)
+        lag_slice = key[96 * llo:96 * lhi]
+        del key
     # the rank's slice of the commit key is produced once (on the device: the reference's setup is O(n * 255)
     # group operations), parked in PINNED HOST memory like a key read from disk, and then STREAMED into the
     # context by plonk_srs_load (double-buffered 2^18-point chunks; BASELINE config 5)
@@ -80,7 +92,7 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense"):
     build_prover.srs_stream_s = time.perf_counter() - t0
     host.free()
     wires, polys, pi = circuit_polys(ctx, log_n, profile)
-    prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather)
+    prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather, lag_slice)
     wbuf = ctx.alloc(4 * 32 * n)
     for k in range(4):
         wbuf.upload(wires[k], 32 * n * k)

@@ -97,6 +97,11 @@ int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints);
  * tau and g_scalar are Fr (Montgomery).  Writes npoints x 96 B to out_dev. */
 int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t g_scalar[4],
                            uint64_t npoints, void* out_dev);
+/* The Lagrange-basis form of the context's commit key for the domain of size n = 1 << log_n (the key must hold n + 2
+ * points): out[i] = [L_i(tau)] G for i < n, then [tau^n] G - G and [tau^(n+1)] G - [tau] G — (n + 2) x 96 bytes, host
+ * memory.  An inverse FFT over the group on the GPU.  A single-GPU prover computes this itself; a multi-GPU run calls
+ * it once where the whole key is available and hands every rank its slice (plonk_prover_desc.lagrange_xy96). */
+int plonk_lagrange_key(plonk_ctx* ctx, uint32_t log_n, uint8_t* out_xy96);
 
 /* plain device memory helpers so callers need no HIP bindings of their own */
 int plonk_dev_alloc(plonk_ctx* ctx, uint64_t bytes, void** out);
@@ -151,6 +156,11 @@ typedef struct {
   uint64_t srs_total;            /* global SRS length (only read when shard_world > 1)  */
   plonk_allgather_fn allgather;
   void* allgather_user;
+  /* Multi-GPU only (ignored for shard_world <= 1, where the prover derives it itself): this rank's slice
+   * [shard_rank * S, shard_rank * S + lagrange_count) of the (size + 2)-point Lagrange-basis key that
+   * plonk_lagrange_key returns, S as above; NULL / 0 = commit to the wire polynomials in coefficient form. */
+  const uint8_t* lagrange_xy96;
+  uint64_t lagrange_count;
 } plonk_prover_desc;
 int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out);
 void plonk_prover_destroy(plonk_prover* p);

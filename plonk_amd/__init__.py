@@ -47,7 +47,7 @@ EXPORTS = [
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
-    "plonk_host_alloc", "plonk_host_free",
+    "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -58,7 +58,8 @@ class _ProverDesc(ctypes.Structure):
     _fields_ = [("constraints", ctypes.c_uint64), ("label", ctypes.c_char_p), ("label_len", ctypes.c_uint64),
                 ("polys", ctypes.c_void_p * 15), ("poly_len", ctypes.c_uint64 * 15),
                 ("vk_commitments", ctypes.c_char_p), ("shard_rank", ctypes.c_int), ("shard_world", ctypes.c_int),
-                ("srs_total", ctypes.c_uint64), ("allgather", ctypes.c_void_p), ("allgather_user", ctypes.c_void_p)]
+                ("srs_total", ctypes.c_uint64), ("allgather", ctypes.c_void_p), ("allgather_user", ctypes.c_void_p),
+                ("lagrange_xy96", ctypes.c_char_p), ("lagrange_count", ctypes.c_uint64)]
 
 
 class _BlobInfo(ctypes.Structure):
@@ -154,6 +155,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_prover_blob_check.argtypes = [vp, u64, ctypes.POINTER(_BlobInfo)]
     lib.plonk_prover_from_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
     lib.plonk_srs_validate.argtypes = [vp, vp, u64]
+    lib.plonk_lagrange_key.argtypes = [vp, u32, vp]
     lib.plonk_host_alloc.argtypes = [u64, ctypes.POINTER(vp)]
     lib.plonk_host_free.argtypes = [vp]
     lib.plonk_comm_unique_id.argtypes = [vp]
@@ -388,6 +390,12 @@ class Context:
         self._check(self.lib.plonk_srs_generate_dev(self.handle, fr_to_bytes_mont([tau]),
                                                     fr_to_bytes_mont([g_scalar]), npoints, out_ptr))
 
+    def lagrange_key(self, log_n: int) -> bytes:
+        """(n + 2) x 96 B: [L_i(tau)] G and the two blinding points, from the context's commit key (plonk_lagrange_key)."""
+        out = ctypes.create_string_buffer(96 * ((1 << log_n) + 2))
+        self._check(self.lib.plonk_lagrange_key(self.handle, log_n, out))
+        return out.raw
+
     def sync(self):
         self._check(self.lib.plonk_dev_sync(self.handle))
 
@@ -431,12 +439,15 @@ class Prover:
     (prover.rs:154-161,133-135,553-555) and returns Proof::to_bytes (1008 bytes)."""
 
     def __init__(self, ctx: Context, constraints: int, label: bytes, polys: dict, vk_commitments: bytes | None = None,
-                 rank: int = 0, world: int = 1, srs_total: int = 0, allgather=None):
-        """allgather(send: bytes) -> bytes (rank-major concatenation) when world > 1."""
+                 rank: int = 0, world: int = 1, srs_total: int = 0, allgather=None, lagrange_slice: bytes | None = None):
+        """allgather(send: bytes) -> bytes (rank-major concatenation) when world > 1 and the context has no RCCL
+        communicator; lagrange_slice: this rank's points of Context.lagrange_key (multi-GPU)."""
         self.ctx = ctx
         desc = _ProverDesc()
         self._cb = None
         if world > 1:
+            desc.shard_rank, desc.shard_world, desc.srs_total = rank, world, srs_total
+        if world > 1 and allgather is not None:
             def _cb(user, send, recv, nbytes):
                 try:
                     out = allgather(ctypes.string_at(send, nbytes))
@@ -462,6 +473,9 @@ class Prover:
             desc.polys[k] = ctypes.cast(buf, ctypes.c_void_p)
             desc.poly_len[k] = len(raw) // 32
         desc.vk_commitments = vk_commitments
+        if lagrange_slice is not None:   # an empty slice still selects the mode (every rank must take the same one)
+            desc.lagrange_xy96 = lagrange_slice if lagrange_slice else b"\0"
+            desc.lagrange_count = len(lagrange_slice) // 96
         h = ctypes.c_void_p()
         ctx._check(ctx.lib.plonk_prover_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
         self.handle = h

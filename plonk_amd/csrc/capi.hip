@@ -409,6 +409,21 @@ int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t
   return srs_generate_device(&ctx->c, t, g, npoints, (G1Affine*)out_dev);
 }
 
+int plonk_lagrange_key(plonk_ctx* ctx, uint32_t log_n, uint8_t* out_xy96) {
+  if (!ctx || !out_xy96 || log_n >= 27) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  HIP_TRY(hipSetDevice(c.device));
+  const uint64_t n = 1ull << log_n;
+  G1Affine* pts = nullptr;
+  HIP_TRY(hipMalloc((void**)&pts, sizeof(G1Affine) * (n + 2)));
+  int rc = lagrange_points_device(&c, log_n, pts);
+  if (rc == PLONK_OK && hipMemcpyAsync(out_xy96, pts, sizeof(G1Affine) * (n + 2), hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  if (hipStreamSynchronize(c.stream) != hipSuccess && rc == PLONK_OK) rc = PLONK_ERR_HIP;
+  (void)hipFree(pts);
+  return rc;
+}
+
 int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_dev) {
   if (!ctx || (!scalars && m) || !out97_dev) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);

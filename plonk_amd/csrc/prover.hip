@@ -93,7 +93,9 @@ struct Prover {
   // Lagrange-basis commit key of the proving domain (single GPU): the wire commitments are taken from the wire
   // VALUES, [L_i(tau)] G tables + the two blinding points, so small witness values cost few additions (zero
   // digits never reach the accumulation) and the wire iNTTs leave the critical path
-  void* lag_table = nullptr;       // window tables over n + 2 points (lagrange_points_device)
+  void* lag_table = nullptr;       // window tables over n + 2 points (lagrange_points_device), or over this rank's slice of them
+  uint64_t lag_n = 0;              // points in lag_table
+  bool lag_on = false;             // wire commitments over the Lagrange key (lag_n may be 0 for a rank without a slice)
   Fr* wscal = nullptr;             // [8] the wire blinders on the device (tail scalars of the four Lagrange-key MSMs)
   Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
   Fr* scratch2 = nullptr;          // [np + 1]
@@ -431,9 +433,31 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
       HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * (n + 2)));
       int rc = lagrange_points_device(c, L, lag_pts);
       if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table);
+      p->lag_n = n + 2;
+      p->lag_on = true;
       if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
       (void)hipFree(lag_pts);
       if (rc) return rc;
+      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
+    } else if (p->world > 1 && !(wc && wc[0] == 'c') && d->lagrange_xy96) {
+      // multi-GPU: the rank's slice [shard_lo, shard_lo + count) of the (n + 2)-point Lagrange key, computed where the whole
+      // commit key was available (plonk_lagrange_key)
+      const uint64_t lhi = p->shard_lo + p->per < n + 2 ? p->shard_lo + p->per : n + 2;
+      const uint64_t want = lhi > p->shard_lo ? lhi - p->shard_lo : 0;
+      if (!p->sharded || d->lagrange_count != want)
+        return (plonk::set_last_error("invalid argument", "lagrange_count is not this rank's slice of the size + 2 points", __FILE__, __LINE__), PLONK_ERR_ARG);
+      if (want) {
+        G1Affine* lag_pts = nullptr;
+        HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * want));
+        int rc = PLONK_OK;
+        if (hipMemcpyAsync(lag_pts, d->lagrange_xy96, sizeof(G1Affine) * want, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+        if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, want, &p->lag_table);
+        if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+        (void)hipFree(lag_pts);
+        if (rc) return rc;
+      }
+      p->lag_n = want;
+      p->lag_on = true;
       HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
     }
   }
@@ -468,7 +492,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
 
   uint8_t comm[11][48];
   // ---- round 1 (prover.rs:444-479)
-  const bool lag = p->lag_table != nullptr;
+  const bool lag = p->lag_on;
   // iNTT + blinding of the four columns and their lowest coefficients (quotient_low), on the CURRENT stream
   auto wire_polynomials = [&](Fr* ntt_tmp) -> int {
     prof_begin(c, 4);   // slot 4: the polynomial work of rounds 1-2 (replicated on every rank of a multi-GPU run)
@@ -536,7 +560,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       const Fr* sc[4] = {wires_dev, wires_dev + n, wires_dev + 2 * n, wires_dev + 3 * n};
       const Fr* tl[4] = {p->wscal, p->wscal + 2, p->wscal + 4, p->wscal + 6};
       const uint64_t sp[4] = {n, n, n, n};
-      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, n + 2, tl, sp));
+      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp));
     } else {
       const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
       PTRY(msm_group(p, sc, ms, 4, 0));   // commit_polynomials (prover.rs:187-210) as one group launch
@@ -931,7 +955,23 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
       for (uint32_t k = 0; k < cpr; ++k)
         PTRY(ntt_device(c, p->pipoly, p->cos + 5 * qn + k * n, p->tmp8b, L, false, true, n, &p->cs_fwd[k]));
   }
-  {
+  if (p->lag_on) {
+    // wire commitments from the wire VALUES over this rank's slice of the Lagrange-basis key (see prover_prove): values
+    // [lo_L, hi_L) of each column in place, the column's two blinders for the slice that reaches indices n, n + 1
+    const uint64_t lo_l = p->shard_lo, hi_l = p->shard_lo + p->lag_n;       // hi_l <= n + 2
+    HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+    const Fr* sc[4];
+    const Fr* tl[4];
+    uint64_t ms[4], sp[4];
+    for (int k = 0; k < 4; ++k) {
+      sc[k] = wires_dev + (uint64_t)k * n + (lo_l < n ? lo_l : 0);
+      sp[k] = lo_l < n ? n - lo_l : 0;                                      // scalars of the slice below index n
+      if (sp[k] > p->lag_n) sp[k] = p->lag_n;
+      tl[k] = p->wscal + 2 * k + (lo_l > n ? lo_l - n : 0);                 // blinder b_(index - n)
+      ms[k] = hi_l - lo_l;
+    }
+    PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp));
+  } else {
     const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
     PTRY(msm_group(p, sc, ms, 4, 0));
