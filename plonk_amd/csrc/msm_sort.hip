@@ -29,7 +29,13 @@ namespace plonk {
 
 static constexpr uint32_t FINE_BITS = 4;
 static constexpr uint32_t COARSE = MSM_NB >> FINE_BITS;          // 2048 coarse bins
-static constexpr uint32_t TILE = 2048;                           // scalars per workgroup (hist / partition)
+#ifndef PLONK_SORT_TILE
+#define PLONK_SORT_TILE 2048
+#endif
+#ifndef PLONK_PARTITION_DIRECT
+#define PLONK_PARTITION_DIRECT 0
+#endif
+static constexpr uint32_t TILE = PLONK_SORT_TILE;                // scalars per workgroup of the partition pass
 static constexpr uint32_t SORT_T = 1024;                         // threads per workgroup
 static constexpr uint32_t PER_T = TILE / SORT_T;                 // scalars per thread (partition)
 #ifndef PLONK_HIST_PER
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t*
 
 // ---- level 1c: partition into the coarse bins -----------------------------------------------------
 // dynamic LDS: stage[TILE * MSM_W] words, then hist / loff / gbase [COARSE] each
-static constexpr size_t PARTITION_LDS = ((size_t)TILE * MSM_W + 3 * COARSE) * sizeof(uint32_t);
+static constexpr size_t PARTITION_LDS = ((PLONK_PARTITION_DIRECT ? 0 : (size_t)TILE * MSM_W) + 3 * COARSE) * sizeof(uint32_t);
 
 __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint64_t srs_n,
                                                                const uint32_t* __restrict__ coarse_off_all,
@@ -177,7 +183,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
                                                                uint32_t* __restrict__ tmp_all) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* stage = lds;                          // TILE * MSM_W
-  uint32_t* hist = lds + TILE * MSM_W;            // COARSE: entries of this tile per bin
+  uint32_t* hist = lds + (PLONK_PARTITION_DIRECT ? 0 : TILE * MSM_W);   // COARSE: entries of this tile per bin
   uint32_t* loff = hist + COARSE;                 // COARSE: start of the bin's run inside `stage`
   uint32_t* gbase = loff + COARSE;                // COARSE: start of the run in the global array
   __shared__ uint32_t sh[SORT_T];
@@ -220,6 +226,15 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
     gbase[2 * t + 1] = c1 ? coff[2 * t + 1] + atomicAdd(&cur[2 * t + 1], c1) : 0;
   }
   __syncthreads();
+  uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+#if PLONK_PARTITION_DIRECT
+  // variant: straight from the registers into the runs (scattered 4-byte stores, merged by the L2)
+#pragma unroll
+  for (uint32_t k = 0; k < PER_T; ++k)
+#pragma unroll
+    for (int w = 0; w < MSM_W; ++w)
+      if (where[k][w] != 0xffffffffu) tmp[gbase[where[k][w] >> 16] + (where[k][w] & 0xffffu)] = word[k][w];
+#else
 #pragma unroll
   for (uint32_t k = 0; k < PER_T; ++k)
 #pragma unroll
@@ -227,12 +242,12 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
       if (where[k][w] != 0xffffffffu) stage[loff[where[k][w] >> 16] + (where[k][w] & 0xffffu)] = word[k][w];
   __syncthreads();
   // write the runs: 16 lanes per bin, 64 bins per sweep of the workgroup
-  uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint32_t sub = t & 15;
   for (uint32_t bin = t >> 4; bin < COARSE; bin += SORT_T / 16) {
     const uint32_t cnt = hist[bin], lo = loff[bin], gb = gbase[bin];
     for (uint32_t j = sub; j < cnt; j += 16) tmp[gb + j] = stage[lo + j];
   }
+#endif
 }
 
 // ---- level 2: fine buckets inside a coarse bin ----------------------------------------------------
