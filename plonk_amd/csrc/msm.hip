@@ -308,31 +308,40 @@ __device__ __forceinline__ G1R wg_tree_sum256(G1R acc, G1R* sh) {
 // stage 1: workgroup w of a commitment handles segment w, w + HEAVY_WGS, ... of the launch; an item's segments are
 // numbered contiguously from its seg_base, so the owner of a segment is found by one pass of the 256 lanes over the
 // (short, unordered) item list
-__global__ void __launch_bounds__(256) msm_heavy_seg_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
-                                                            const uint32_t* __restrict__ slice_off_all,
-                                                            const uint32_t* __restrict__ nheavy_all,
-                                                            const HeavyItem* __restrict__ heavy_list_all,
-                                                            G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap) {
+__global__ void __launch_bounds__(64) msm_heavy_seg_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
+                                                           const uint32_t* __restrict__ slice_off_all,
+                                                           const uint32_t* __restrict__ nheavy_all,
+                                                           const HeavyItem* __restrict__ heavy_list_all,
+                                                           G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap) {
+  // one WAVE per segment: 4 slices per lane, then a 6-step tree over 14 KiB of LDS — ~11 segments in flight per CU
+  // (a 256-lane workgroup with its 57 KiB tree buffer allowed 2, and the segment pass was occupancy-bound)
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
   const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
   G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
-  __shared__ G1R sh[256];
+  __shared__ G1R sh[64];
   __shared__ uint32_t found[2];
   const uint32_t nitems = nheavy_all[2 * kb], nsegs = nheavy_all[2 * kb + 1];
   for (uint32_t sg = blockIdx.x; sg < nsegs; sg += gridDim.x) {
-    // which item owns segment sg: lanes test disjoint parts of the list
-    for (uint32_t i = threadIdx.x; i < nitems; i += 256) {
+    for (uint32_t i = threadIdx.x; i < nitems; i += 64) {   // which item owns segment sg
       const HeavyItem it = list[i];
       if (sg >= it.seg_base && sg < it.seg_base + it.nseg) { found[0] = it.bucket; found[1] = sg - it.seg_base; }
     }
     __syncthreads();
     const uint32_t b = found[0], j = found[1];
     const uint32_t beg = slice_off[b] + j * HEAVY_SEG, bend = slice_off[b + 1];
-    const uint32_t k = beg + threadIdx.x;
-    G1R acc = k < bend ? ld_g1r(partial + k) : G1R::identity();
-    acc = wg_tree_sum256(acc, sh);
+    G1R acc = G1R::identity();
+    for (uint32_t q = 0; q < HEAVY_SEG / 64; ++q) {
+      const uint32_t k = beg + threadIdx.x + 64 * q;
+      if (k < bend) acc = acc.add(ld_g1r(partial + k));
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+      sh[threadIdx.x] = acc;
+      __syncthreads();
+      if ((int)threadIdx.x < d) acc = acc.add(sh[threadIdx.x + d]);
+      __syncthreads();
+    }
     if (threadIdx.x == 0) st_g1r(seg_sum + sg, acc);
     __syncthreads();
   }
@@ -730,7 +739,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     else BSUM(8);
 #undef BSUM
   }
-  hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(HEAVY_WGS, count), dim3(256), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
+  hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(4 * HEAVY_WGS, count), dim3(64), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
                      w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
   hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
                      (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
