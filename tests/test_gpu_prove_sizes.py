@@ -144,7 +144,8 @@ def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     assert got == expected
 
 
-@pytest.mark.parametrize("profile,log_n", [("bench-like", 13), ("widgets", 13), ("dense", 12)])
+@pytest.mark.parametrize("profile,log_n", [("bench-like", 13), ("widgets", 13), ("dense", 12),
+                                            pytest.param("bench-like", 17, marks=pytest.mark.slow)])   # 2^17: chunked coarse bins inside prove()
 def test_wire_commitment_modes_agree_with_each_other_and_the_oracle(ctx, monkeypatch, profile, log_n):
     """The wire commitments taken from the wire VALUES over the Lagrange-basis key (default on one GPU) and from the
     blinded coefficient forms (PLONK_WIRE_COMMIT=coeff, the reference's way) are the same group elements: both modes
