@@ -467,6 +467,89 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   return PLONK_OK;
 }
 
+// ---- pieces shared by the single-GPU and the sharded prove() ---------------------------------------------------
+// transcript_for_version(V3) = Transcript::base_v3 (transcript.rs:131-145) + VerifierKey::seed_transcript
+// (widget.rs:218-258) + the public inputs (prover.rs:440-442)
+static void seed_transcript(Transcript& tr, const Prover* p, const Fr* pi_val, uint64_t pi_count) {
+  tr.circuit_domain_sep(p->constraints);
+  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[VK_ORDER[k]]);
+  tr.circuit_domain_sep(p->constraints);   // vk.n == constraints (compiler.rs:279)
+  for (uint64_t i = 0; i < pi_count; ++i) tr.append_scalar("pi", pi_val[i]);
+}
+// prover.rs:623-632,650-658
+static void append_evaluations(Transcript& tr, const Evals& ev) {
+  tr.append_scalar("a_eval", ev.a);
+  tr.append_scalar("b_eval", ev.b);
+  tr.append_scalar("c_eval", ev.c);
+  tr.append_scalar("d_eval", ev.d);
+  tr.append_scalar("s_sigma_1_eval", ev.s1);
+  tr.append_scalar("s_sigma_2_eval", ev.s2);
+  tr.append_scalar("s_sigma_3_eval", ev.s3);
+  tr.append_scalar("z_eval", ev.z);
+  tr.append_scalar("a_w_eval", ev.a_w);
+  tr.append_scalar("b_w_eval", ev.b_w);
+  tr.append_scalar("d_w_eval", ev.d_w);
+  tr.append_scalar("q_arith_eval", ev.q_arith);
+  tr.append_scalar("q_c_eval", ev.q_c);
+  tr.append_scalar("q_l_eval", ev.q_l);
+  tr.append_scalar("q_r_eval", ev.q_r);
+}
+// Proof::to_bytes (proof.rs:137-162, linearization_poly.rs:98-124)
+static void write_proof(uint8_t proof[1008], const uint8_t (*comm)[48], const Evals& ev) {
+  memcpy(proof, comm, 11 * 48);
+  const Fr* order[15] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.a_w, &ev.b_w, &ev.d_w, &ev.q_arith, &ev.q_c, &ev.q_l,
+                         &ev.q_r, &ev.s1, &ev.s2, &ev.s3, &ev.z};
+  for (int k = 0; k < 15; ++k) fr_to_bytes(*order[k], proof + 11 * 48 + 32 * k);
+}
+// public-input evaluation at z (compute_barycentric_eval, proof.rs:1041-1088): one shared inversion for all
+// denominators (Montgomery's trick); a zero denominator means z is a root of unity (probability n/q) and
+// contributes nothing, like the reference's skip.  zh = z^n - 1.
+static Fr public_input_eval(const Prover* p, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count, const Fr& z_ch, const Fr& zh) {
+  if (!pi_count) return Fr::zero();
+  const Fr one = Fr::one();
+  std::vector<Fr> den(pi_count), pre(pi_count);
+  Fr run = one;
+  for (uint64_t i = 0; i < pi_count; ++i) {
+    den[i] = p->omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
+    pre[i] = run;
+    if (!pi_val[i].is_zero() && !den[i].is_zero()) run = run * den[i];
+  }
+  Fr inv = run.inv(), acc = Fr::zero();
+  for (uint64_t i = pi_count; i-- > 0;) {
+    if (pi_val[i].is_zero() || den[i].is_zero()) continue;
+    acc = acc + inv * pre[i] * pi_val[i];
+    inv = inv * den[i];
+  }
+  return acc * (zh * p->n_inv);
+}
+// num(z) = t(z) Z_H(z)  <=>  r(z) = alpha^2 L1(z) + alpha (a + beta s1 + gamma)(b + beta s2 + gamma)(c + beta s3 + gamma)
+// (d + gamma) z(omega z)  (the constant the verifier calls pi(z) - r_0, proof.rs:290-310); the W_z numerator adds
+// sum_i v^i eval_i to r.  A mismatch means the witness does not satisfy the circuit (Error::CircuitUnsatisfied).
+static bool quotient_identity_holds(const Fr& numerator_at_z, const Evals& ev, const Fr& alpha, const Fr& beta, const Fr& gamma,
+                                    const Fr& l1_z, const Fr* vp /* v^0 .. v^11 */) {
+  Fr expect = alpha.sqr() * l1_z + (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) *
+                                       (ev.c + beta * ev.s3 + gamma) * (ev.d + gamma) * ev.z * alpha;
+  const Fr* evs[11] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.s1, &ev.s2, &ev.s3, &ev.q_arith, &ev.q_c, &ev.q_l, &ev.q_r};
+  for (int k = 0; k < 11; ++k) expect = expect + vp[k + 1] * *evs[k];
+  return numerator_at_z == expect;
+}
+// the sparse public inputs -> dense evaluation vector -> PI(X) in coefficient form, on the current stream
+static int public_input_polynomial(Prover* p, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count, Fr* ntt_tmp) {
+  Ctx* c = p->c;
+  const uint64_t n = p->n;
+  if (pi_count > p->pi_cap) {
+    if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); p->pi_idx_dev = nullptr; p->pi_val_dev = nullptr; p->pi_cap = 0; }
+    HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
+    HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
+    p->pi_cap = pi_count;
+  }
+  for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", "public input row beyond the domain", __FILE__, __LINE__), PLONK_ERR_ARG);
+  HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
+  PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
+  return ntt_device(c, p->pipoly, p->pipoly, ntt_tmp, p->logn, true, false, n);
+}
+
 static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
                                 const Fr* bl, uint8_t proof[1008]);
 
@@ -485,10 +568,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
 
   // transcript_for_version(V3) = Transcript::base_v3 (transcript.rs:131-145, widget.rs:218-258)
   Transcript tr((const uint8_t*)p->label.data(), p->label.size());
-  tr.circuit_domain_sep(p->constraints);
-  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[VK_ORDER[k]]);
-  tr.circuit_domain_sep(p->constraints);   // vk.n == constraints (compiler.rs:279)
-  for (uint64_t i = 0; i < pi_count; ++i) tr.append_scalar("pi", pi_val[i]);   // prover.rs:440-442
+  seed_transcript(tr, p, pi_val, pi_count);
 
   uint8_t comm[11][48];
   // ---- round 1 (prover.rs:444-479)
@@ -537,17 +617,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + p->lq, false, true, n + 2));
     PTRY(poly_fill_zero(c, p->pipoly, np));
     if (pi_count) {
-      if (pi_count > p->pi_cap) {
-        if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); }
-        HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
-        HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
-        p->pi_cap = pi_count;
-      }
-      for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-      HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
-      PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
-      PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8b, L, true, false, n));
+      PTRY(public_input_polynomial(p, pi_idx, pi_val, pi_count, p->tmp8b));
       pi_len = n;
     }
     HIP_TRY(hipMemcpyAsync(p->low_host + 35, p->pipoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
@@ -723,21 +793,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     ev.a = h[0]; ev.b = h[1]; ev.c = h[2]; ev.d = h[3]; ev.a_w = h[4]; ev.b_w = h[5]; ev.d_w = h[6];
     ev.q_arith = h[7]; ev.q_c = h[8]; ev.q_l = h[9]; ev.q_r = h[10]; ev.s1 = h[11]; ev.s2 = h[12]; ev.s3 = h[13]; ev.z = h[14];
   }
-  tr.append_scalar("a_eval", ev.a);
-  tr.append_scalar("b_eval", ev.b);
-  tr.append_scalar("c_eval", ev.c);
-  tr.append_scalar("d_eval", ev.d);
-  tr.append_scalar("s_sigma_1_eval", ev.s1);
-  tr.append_scalar("s_sigma_2_eval", ev.s2);
-  tr.append_scalar("s_sigma_3_eval", ev.s3);
-  tr.append_scalar("z_eval", ev.z);
-  tr.append_scalar("a_w_eval", ev.a_w);
-  tr.append_scalar("b_w_eval", ev.b_w);
-  tr.append_scalar("d_w_eval", ev.d_w);
-  tr.append_scalar("q_arith_eval", ev.q_arith);
-  tr.append_scalar("q_c_eval", ev.q_c);
-  tr.append_scalar("q_l_eval", ev.q_l);
-  tr.append_scalar("q_r_eval", ev.q_r);
+  append_evaluations(tr, ev);
 
   // ---- round 5 (prover.rs:678-739)
   const Fr v = tr.challenge_scalar("v_challenge");
@@ -755,27 +811,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     inv_z = iab * b;
     inv_zm1 = iab * a;
   }
-  // public-input evaluation (compute_barycentric_eval, proof.rs:1041-1088)
-  Fr pi_eval = Fr::zero();
-  if (pi_count) {
-    const Fr omega_inv = p->omega_inv;
-    // one shared inversion for all denominators (Montgomery's trick); a zero denominator means
-    // z is a root of unity (probability n/q) and contributes nothing, like the reference's skip
-    std::vector<Fr> den(pi_count), pre(pi_count);
-    Fr run = one;
-    for (uint64_t i = 0; i < pi_count; ++i) {
-      den[i] = omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
-      pre[i] = run;
-      if (!pi_val[i].is_zero() && !den[i].is_zero()) run = run * den[i];
-    }
-    Fr inv = run.inv(), acc = Fr::zero();
-    for (uint64_t i = pi_count; i-- > 0;) {
-      if (pi_val[i].is_zero() || den[i].is_zero()) continue;
-      acc = acc + inv * pre[i] * pi_val[i];
-      inv = inv * den[i];
-    }
-    pi_eval = acc * (zh * n_inv);
-  }
+  const Fr pi_eval = public_input_eval(p, pi_idx, pi_val, pi_count, z_ch, zh);
   // permutation linearisation scalars (permutation/proverkey.rs:127-269)
   const Fr bz = beta * z_ch;
   const Fr lin_a = (ev.a + bz + gamma) * (ev.b + fr_small(7) * bz + gamma) * (ev.c + fr_small(13) * bz + gamma) *
@@ -859,23 +895,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(msm_group(p, sc, ms, 2, 9));
   }
   PTRY(fetch_commitments(p, 9, 2, comm + 9));
-  {
-    // num(z) = t(z) Z_H(z)  <=>  r(z) = alpha^2 L1(z) + alpha (a + beta s1 + gamma)(b + beta s2 + gamma)
-    // (c + beta s3 + gamma)(d + gamma) z(omega z)  (the constant the verifier calls pi(z) - r_0, proof.rs:290-310);
-    // the W_z numerator adds sum_i v^i eval_i to r.  A mismatch means the witness does not
-    // satisfy the circuit (Error::CircuitUnsatisfied).
-    Fr expect = alpha.sqr() * l1_z + (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) *
-                                         (ev.c + beta * ev.s3 + gamma) * (ev.d + gamma) * ev.z * alpha;
-    const Fr* evs[11] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.s1, &ev.s2, &ev.s3, &ev.q_arith, &ev.q_c, &ev.q_l, &ev.q_r};
-    for (int k = 0; k < 11; ++k) expect = expect + vp[k + 1] * *evs[k];
-    if (p->ev_host[15] != expect) return PLONK_ERR_UNSAT;
-  }
+  if (!quotient_identity_holds(p->ev_host[15], ev, alpha, beta, gamma, l1_z, vp)) return PLONK_ERR_UNSAT;
 
   // ---- Proof::to_bytes (proof.rs:137-162, linearization_poly.rs:98-124)
-  memcpy(proof, comm, 11 * 48);
-  const Fr* order[15] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.a_w, &ev.b_w, &ev.d_w, &ev.q_arith, &ev.q_c, &ev.q_l,
-                         &ev.q_r, &ev.s1, &ev.s2, &ev.s3, &ev.z};
-  for (int k = 0; k < 15; ++k) fr_to_bytes(*order[k], proof + 11 * 48 + 32 * k);
+  write_proof(proof, comm, ev);
   return PLONK_OK;
 }
 
@@ -901,10 +924,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   };
 
   Transcript tr((const uint8_t*)p->label.data(), p->label.size());
-  tr.circuit_domain_sep(p->constraints);
-  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[VK_ORDER[k]]);
-  tr.circuit_domain_sep(p->constraints);
-  for (uint64_t i = 0; i < pi_count; ++i) tr.append_scalar("pi", pi_val[i]);
+  seed_transcript(tr, p, pi_val, pi_count);
 
   uint8_t comm[11][48];
   // ---- round 1 (replicated polynomials, sharded commitments)
@@ -936,17 +956,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
       }
     PTRY(poly_fill_zero(c, p->pipoly, np));
     if (pi_count) {
-      if (pi_count > p->pi_cap) {
-        if (p->pi_idx_dev) { HIP_TRY(hipFree(p->pi_idx_dev)); HIP_TRY(hipFree(p->pi_val_dev)); }
-        HIP_TRY(hipMalloc((void**)&p->pi_idx_dev, sizeof(uint64_t) * pi_count));
-        HIP_TRY(hipMalloc((void**)&p->pi_val_dev, sizeof(Fr) * pi_count));
-        p->pi_cap = pi_count;
-      }
-      for (uint64_t i = 0; i < pi_count; ++i) if (pi_idx[i] >= n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-      HIP_TRY(hipMemcpyAsync(p->pi_idx_dev, pi_idx, sizeof(uint64_t) * pi_count, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(hipMemcpyAsync(p->pi_val_dev, pi_val, sizeof(Fr) * pi_count, hipMemcpyHostToDevice, c->stream));
-      PTRY(poly_scatter_pi(c, p->pipoly, p->pi_idx_dev, p->pi_val_dev, pi_count));
-      PTRY(ntt_device(c, p->pipoly, p->pipoly, p->tmp8b, L, true, false, n));
+      PTRY(public_input_polynomial(p, pi_idx, pi_val, pi_count, p->tmp8b));
       pi_len = n;
     }
     HIP_TRY(hipMemcpyAsync(p->low_host + 35, p->pipoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
@@ -1141,21 +1151,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     ev.a = h[0]; ev.b = h[1]; ev.c = h[2]; ev.d = h[3]; ev.a_w = h[4]; ev.b_w = h[5]; ev.d_w = h[6];
     ev.q_arith = h[7]; ev.q_c = h[8]; ev.q_l = h[9]; ev.q_r = h[10]; ev.s1 = h[11]; ev.s2 = h[12]; ev.s3 = h[13]; ev.z = h[14];
   }
-  tr.append_scalar("a_eval", ev.a);
-  tr.append_scalar("b_eval", ev.b);
-  tr.append_scalar("c_eval", ev.c);
-  tr.append_scalar("d_eval", ev.d);
-  tr.append_scalar("s_sigma_1_eval", ev.s1);
-  tr.append_scalar("s_sigma_2_eval", ev.s2);
-  tr.append_scalar("s_sigma_3_eval", ev.s3);
-  tr.append_scalar("z_eval", ev.z);
-  tr.append_scalar("a_w_eval", ev.a_w);
-  tr.append_scalar("b_w_eval", ev.b_w);
-  tr.append_scalar("d_w_eval", ev.d_w);
-  tr.append_scalar("q_arith_eval", ev.q_arith);
-  tr.append_scalar("q_c_eval", ev.q_c);
-  tr.append_scalar("q_l_eval", ev.q_l);
-  tr.append_scalar("q_r_eval", ev.q_r);
+  append_evaluations(tr, ev);
 
   // ---- round 5: linearisation + both opening quotients on the owned coefficient range
   const Fr v = tr.challenge_scalar("v_challenge");
@@ -1167,23 +1163,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   const Fr zm1 = z_ch - one;
   const Fr iab = (z_ch * (zm1.is_zero() ? one : zm1)).inv();
   const Fr inv_z = iab * (zm1.is_zero() ? one : zm1), inv_zm1 = iab * z_ch;
-  Fr pi_eval = Fr::zero();
-  if (pi_count) {
-    std::vector<Fr> den(pi_count), pre(pi_count);
-    Fr run = one;
-    for (uint64_t i = 0; i < pi_count; ++i) {
-      den[i] = p->omega_inv.pow_u64(pi_idx[i]) * z_ch - one;
-      pre[i] = run;
-      if (!pi_val[i].is_zero() && !den[i].is_zero()) run = run * den[i];
-    }
-    Fr inv = run.inv(), acc = Fr::zero();
-    for (uint64_t i = pi_count; i-- > 0;) {
-      if (pi_val[i].is_zero() || den[i].is_zero()) continue;
-      acc = acc + inv * pre[i] * pi_val[i];
-      inv = inv * den[i];
-    }
-    pi_eval = acc * (zh * n_inv);
-  }
+  const Fr pi_eval = public_input_eval(p, pi_idx, pi_val, pi_count, z_ch, zh);
   const Fr bz = beta * z_ch;
   const Fr lin_a = (ev.a + bz + gamma) * (ev.b + fr_small(7) * bz + gamma) * (ev.c + fr_small(13) * bz + gamma) *
                    (ev.d + fr_small(17) * bz + gamma) * alpha;
@@ -1269,18 +1249,8 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     PTRY(msm_group(p, sc, ms, 2, 9));
   }
   PTRY(fetch_commitments(p, 9, 2, comm + 9));
-  {
-    // quotient identity at z (see prover_prove): a mismatch means the witness does not satisfy the circuit
-    Fr expect = alpha.sqr() * l1_z + (ev.a + beta * ev.s1 + gamma) * (ev.b + beta * ev.s2 + gamma) *
-                                         (ev.c + beta * ev.s3 + gamma) * (ev.d + gamma) * ev.z * alpha;
-    const Fr* evs[11] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.s1, &ev.s2, &ev.s3, &ev.q_arith, &ev.q_c, &ev.q_l, &ev.q_r};
-    for (int k = 0; k < 11; ++k) expect = expect + vp[k + 1] * *evs[k];
-    if (num_at_z != expect) return PLONK_ERR_UNSAT;
-  }
-  memcpy(proof, comm, 11 * 48);
-  const Fr* order[15] = {&ev.a, &ev.b, &ev.c, &ev.d, &ev.a_w, &ev.b_w, &ev.d_w, &ev.q_arith, &ev.q_c, &ev.q_l,
-                         &ev.q_r, &ev.s1, &ev.s2, &ev.s3, &ev.z};
-  for (int k = 0; k < 15; ++k) fr_to_bytes(*order[k], proof + 11 * 48 + 32 * k);
+  if (!quotient_identity_holds(num_at_z, ev, alpha, beta, gamma, l1_z, vp)) return PLONK_ERR_UNSAT;
+  write_proof(proof, comm, ev);
   return PLONK_OK;
 }
 
