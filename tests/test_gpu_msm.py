@@ -199,3 +199,39 @@ def test_small_scalars_take_the_chunked_bin_and_segmented_bucket_paths(ctx):
                [Q - 1 - r.randrange(3) for _ in range(n)]):                           # small negatives: every window, sign set
         k = g * sum(s * t for s, t in zip(sc, geo)) % Q
         assert ctx.msm(sc) == E.g1_mul(E.G1_GEN, k)
+
+
+def test_lagrange_key_matches_the_definition_and_commits_like_the_monomial_key(ctx):
+    """plonk_lagrange_key: out[i] = [L_i(tau)] G on the size-n domain, then [tau^n] G - G and [tau^(n+1)] G - [tau] G.
+    With the key [g tau^j] G the points are known in closed form (L_i(tau) = w^i (tau^n - 1) / (n (tau - w^i))), and
+    committing to evaluations over the Lagrange key must equal committing to the interpolated coefficients over
+    the monomial key (what the prover relies on for the wire commitments)."""
+    import plonk_amd
+    from oracle.fft import EvaluationDomain
+    r = random.Random(61)
+    L = 6
+    n = 1 << L
+    tau, g = r.randrange(2, Q), r.randrange(1, Q)
+    buf = _gen_srs_dev(ctx, n + 5, tau, g)
+    ctx.srs_load_dev(buf.ptr, n + 5)
+    buf.free()
+    key = ctx.lagrange_key(L)
+    assert len(key) == 96 * (n + 2)
+    d = EvaluationDomain(n)
+    w = d.group_gen
+    tn = pow(tau, n, Q)
+    for i in (0, 1, 5, n - 1):
+        wi = pow(w, i, Q)
+        li = wi * (tn - 1) % Q * pow(n * (tau - wi) % Q, -1, Q) % Q
+        assert E.g1_from_raw96(key[96 * i:96 * i + 96]) == E.g1_mul(E.G1_GEN, g * li % Q), i
+    assert E.g1_from_raw96(key[96 * n:96 * n + 96]) == E.g1_mul(E.G1_GEN, g * (tn - 1) % Q)
+    assert E.g1_from_raw96(key[96 * (n + 1):96 * (n + 2)]) == E.g1_mul(E.G1_GEN, g * (tn * tau - tau) % Q)
+    evals = [r.randrange(Q) for _ in range(n)]
+    coeffs = d.ifft(evals)
+    want = ctx.msm(coeffs)                                        # monomial key, coefficient form
+    ctx.srs_load_bytes(key[:96 * n], n)                           # the Lagrange points as a commit key
+    assert ctx.msm(evals) == want
+    # a key that is too short for the domain is refused like an oversized polynomial
+    ctx.srs_load_bytes(key[:96 * 10], 10)
+    with pytest.raises(plonk_amd.PolynomialDegreeTooLarge):
+        ctx.lagrange_key(L)

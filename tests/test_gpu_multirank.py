@@ -91,3 +91,19 @@ def test_rccl_transport_single_rank_communicator():
         ctx.comm_selftest()
     assert ctx.ntt([1, 2, 3, 4], 2) is not None
     ctx.close()
+
+
+def test_comm_api_misuse_is_refused():
+    import plonk_amd
+    ctx = plonk_amd.Context(0)
+    with pytest.raises(plonk_amd.PlonkError):          # no communicator yet
+        ctx.comm_selftest()
+    uid = plonk_amd.Context.comm_unique_id()
+    with pytest.raises(plonk_amd.PlonkError):          # rank outside the world
+        ctx.comm_init(uid, 2, 2)
+    ctx.comm_destroy()                                 # destroying nothing is fine
+    # a sharded prover without a communicator and without an all-gather callback cannot be built
+    ctx.srs_load_bytes(bytes(96) * 0 + b"", 0)
+    with pytest.raises(plonk_amd.PlonkError):
+        plonk_amd.Prover(ctx, 64, b"x", {}, None, 0, 2, 71, None)
+    ctx.close()
