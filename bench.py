@@ -218,6 +218,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads / leaf costs of the N=1 line")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): everything else this process or its libraries print — RCCL's version
+    # banner sits in the C stdio buffer until exit and would land AFTER the JSON line — goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -406,7 +412,8 @@ def main():
                     out["cpu_baseline"]["proof_matches_gpu"] = bool(cpu_proof == proof)
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if dist is not None:
         barrier()
         dist.destroy_process_group()
