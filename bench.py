@@ -63,7 +63,7 @@ def circuit_polys(ctx, log_n, profile):
     return wires, polys, pi
 
 
-def build_prover(ctx, log_n, rank, world, allgather, profile="dense"):
+def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circuit=False):
     n = 1 << log_n
     srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
@@ -91,8 +91,21 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense"):
     ctx.srs_load_host_ptr(host.ptr, hi - lo)
     build_prover.srs_stream_s = time.perf_counter() - t0
     host.free()
-    wires, polys, pi = circuit_polys(ctx, log_n, profile)
-    prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather, lag_slice)
+    build_prover.witness_values = None
+    if from_circuit:
+        # Compiler::preprocess on the device (plonk_compile): gate columns + witness indices in, prover + VerifierKey out
+        cc = BC.widget_columns(log_n) if profile == "widgets" else BC.arithmetic_columns(log_n, profile, workers=8 if log_n > 20 else 0)
+        wires, pi = cc["columns"], cc["public_inputs"]
+        t0 = time.perf_counter()
+        prover = plonk_amd.Prover.compile(ctx, b"bench", cc["selectors"], cc["wires"], cc["witnesses"], rank, world, srs_total,
+                                          allgather, lag_slice)
+        build_prover.compile_s = time.perf_counter() - t0
+        build_prover.witness_values = cc["values"]
+    else:
+        wires, polys, pi = circuit_polys(ctx, log_n, profile)
+        t0 = time.perf_counter()
+        prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather, lag_slice)
+        build_prover.create_s = time.perf_counter() - t0
     wbuf = ctx.alloc(4 * 32 * n)
     for k in range(4):
         wbuf.upload(wires[k], 32 * n * k)
@@ -113,6 +126,40 @@ def time_profile(ctx, log_n, profile, steps, blinders):
     prover.close()
     wbuf.free()
     return round(ms, 3)
+
+
+def compile_costs(ctx, log_n, blinders):
+    """Compiler::preprocess on the device (plonk_compile, `dense` gate columns from host memory) beside the
+    coefficient-form constructor, and a proof that starts from the witness table in pinned host memory."""
+    n = 1 << log_n
+    pts = ctx.alloc(96 * (n + 7))
+    ctx.srs_generate_dev(TAU, G_SCALAR, n + 7, pts.ptr)
+    ctx.srs_load_dev(pts.ptr, n + 7)
+    pts.free()
+    cc = BC.arithmetic_columns(log_n, "dense")
+    ctx.sync()
+    t0 = time.perf_counter()
+    prover = plonk_amd.Prover.compile(ctx, b"bench", cc["selectors"], cc["wires"], cc["witnesses"])
+    t_compile = time.perf_counter() - t0
+    host = plonk_amd.PinnedBuffer(len(cc["values"]))
+    host.write(cc["values"])
+    proof = prover.prove_witnesses_ptr(host.ptr, cc["witnesses"], {}, blinders)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        prover.prove_witnesses_ptr(host.ptr, cc["witnesses"], {}, blinders)
+    ctx.sync()
+    t_prove = (time.perf_counter() - t0) / 3
+    vk = prover.vk_commitments()
+    prover.close()
+    host.free()
+    return {"gates": n, "plonk_compile_ms": round(t_compile * 1e3, 1),
+            "of_which": "11 selector + 4 sigma interpolations, host pass over the copy constraints, 15 commitments, "
+                        "16 coset transforms, Lagrange-basis key (group FFT) — host gate columns in pageable memory",
+            "prove_ms_from_witness_table_pinned": round(t_prove * 1e3, 3),
+            "witness_table_mb": round(len(cc["values"]) / 2**20, 1),
+            "proof_blake2b": hashlib.blake2b(proof).hexdigest()[:32],
+            "vk_blake2b": hashlib.blake2b(vk).hexdigest()[:32]}
 
 
 def leaf_costs(ctx, log_n):
@@ -216,6 +263,9 @@ def main():
     ap.add_argument("--profile", default="dense", choices=["dense", "bench-like", "widgets"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads / leaf costs of the N=1 line")
+    ap.add_argument("--from-circuit", action="store_true",
+                    help="build the prover with plonk_compile from gate columns (Compiler::preprocess on the device) instead of "
+                         "from coefficient forms, and check plonk_prover_prove_witnesses against the column entry point")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): everything else this process or its libraries print — RCCL's version
@@ -273,8 +323,9 @@ def main():
                 return out.numpy().tobytes()
 
     t_setup = time.perf_counter()
-    prover, wbuf, srs_total = build_prover(ctx, log_n, rank, world, allgather, args.profile)
+    prover, wbuf, srs_total = build_prover(ctx, log_n, rank, world, allgather, args.profile, args.from_circuit)
     t_setup = time.perf_counter() - t_setup
+    witness_values = build_prover.witness_values
     pi = prover.public_inputs
     blinders = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
 
@@ -286,6 +337,10 @@ def main():
     proof = None
     for _ in range(args.warmup):
         proof = prover.prove_dev(wbuf.ptr, pi, blinders)
+    if witness_values is not None:   # every rank: the proof from the witness table equals the proof from the wire columns
+        assert prover.prove_witnesses(witness_values, pi, blinders) == prover.prove_dev(wbuf.ptr, pi, blinders)
+        if proof is None:
+            proof = prover.prove_dev(wbuf.ptr, pi, blinders)
     # timed region: exactly K proofs, hipEvent pairs recorded around the dominant kernels
     ctx.profile(True)
     ctx.profile_reset()
@@ -358,7 +413,8 @@ def main():
                                        if world in (2, 4, 8) else "x%d: MSM by SRS point range" % world),
                        "srs": "rank's point range streamed from pinned host memory in 2^18-point chunks (upload of chunk k+1 under "
                               "the window-table build of chunk k): %d points in %.2f s" % (min(per, srs_total), build_prover.srs_stream_s),
-                       "collective": collective, "setup_s": round(t_setup, 1)},
+                       "collective": collective, "setup_s": round(t_setup, 1),
+                       "prover_built_by": "plonk_compile (gate columns)" if args.from_circuit else "plonk_prover_create (coefficient forms)"},
             # whole-job MSM rate: all 11 x (n + 6) terms of a proof over the time rank 0 spends in its (sharded) MSM kernels
             "msm_mscalar_per_s": round(11 * (n + 6) / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),
             "proof_blake2b": hashlib.blake2b(proof).hexdigest()[:32],
@@ -403,6 +459,9 @@ def main():
                 out["prove_ms_all_widgets_pi"] = time_profile(ctx, log_n, "widgets", k, blinders)
                 if log_n != 16:
                     out["prove_ms_2p16"] = time_profile(ctx, 16, "dense", 2 * k, blinders)
+                out["compile"] = compile_costs(ctx, log_n if log_n <= 20 else 20, blinders)
+                if log_n <= 20:   # same circuit, key and blinders as the timed run, built the other way
+                    out["compile"]["proof_matches_timed_run"] = bool(out["compile"]["proof_blake2b"] == out["proof_blake2b"])
             except Exception as e:   # noqa: BLE001
                 out["extras_error"] = repr(e)
         if world == 1 and not args.no_cpu_baseline and args.profile == "dense":

@@ -264,13 +264,8 @@ def widget_block(blk: int, seed: int = 0x5EED0003) -> _Rows:
     return rows
 
 
-def widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
-    """n = 2^log_n rows: tiles of 2^blk_log rows drawn at random from a pool of `pool` different blocks (different
-    witnesses), so no column is periodic and every polynomial is dense.  Position (column, row) of a tile is
-    copy-constrained to the same position of the next tile built from the same block (equal values by
-    construction): the permutation is a product of long cycles; two public inputs sit on the last two rows
-    of tile 0.
-    Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, public inputs {row: value})."""
+def _widget_layout(log_n, blk_log, pool):
+    """(rows per tile, tiles, blocks in the pool, block id of every tile, the blocks' rows)"""
     n = 1 << log_n
     blk = 1 << min(blk_log, log_n)
     tiles = n // blk
@@ -279,6 +274,18 @@ def widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
     blocks = [widget_block(blk, 0x5EED0003 + 7919 * b).rows for b in range(pool)]
     ids = [t % pool for t in range(tiles)]
     rnd.shuffle(ids)
+    return blk, tiles, pool, ids, blocks
+
+
+def widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
+    """n = 2^log_n rows: tiles of 2^blk_log rows drawn at random from a pool of `pool` different blocks (different
+    witnesses), so no column is periodic and every polynomial is dense.  Position (column, row) of a tile is
+    copy-constrained to the same position of the next tile built from the same block (equal values by
+    construction): the permutation is a product of long cycles; two public inputs sit on the last two rows
+    of tile 0.
+    Returns (wires[4] bytes, key columns {name: bytes} in evaluation form, public inputs {row: value})."""
+    n = 1 << log_n
+    blk, tiles, pool, ids, blocks = _widget_layout(log_n, blk_log, pool)
     mont = lambda v: v % Q * R % Q   # noqa: E731
     wcols = [[_bytes([mont(rw[0][col]) for rw in rows]) for rows in blocks] for col in range(4)]
     wires = [b"".join(wcols[col][b] for b in ids) for col in range(4)]
@@ -317,6 +324,49 @@ def widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
             out.append(_bytes(seg if k == 0 else [ks[k] * v % Q for v in seg]))
         cols[f"s_sigma_{k + 1}"] = b"".join(out)
     return wires, {k: bytes(v) for k, v in cols.items()}, pi
+
+
+# ---- the same circuits as gate columns: what Compiler::preprocess starts from (reference src/compiler.rs:145-175,
+# src/composer.rs:119-167) — per-gate selector values, the witness index on every wire, the witness values ---------
+def arithmetic_columns(log_n: int, profile: str = "dense", workers: int = 0) -> dict:
+    """arithmetic_circuit(log_n, profile) with its copy constraints expressed through witnesses: gate i owns the
+    witnesses 3i (output c), 3i + 1 (b), 3i + 2 (d); its input a is the output witness of gate i - 1, or an own
+    witness 3n + k at the head of chain k.  Returns {selectors: {name: bytes}, wires: [4 x uint32 bytes],
+    witnesses: count, values: bytes (Montgomery)} plus the padded wire columns under `columns`."""
+    import numpy as np
+    n = 1 << log_n
+    seg = min(n, 1 << 20)
+    wires, cols, _trivial = arithmetic_circuit(log_n, profile, workers)
+    i = np.arange(n, dtype=np.int64)
+    head = i % seg == 0
+    ids = [np.where(head, 3 * n + i // seg, 3 * (i - 1)), 3 * i + 1, 3 * i, 3 * i + 2]   # a, b, c, d
+    count = 3 * n + n // seg
+    vals = np.zeros((count, 32), np.uint8)
+    for col in (0, 1, 3, 2):   # c last: inside a chain a[i] and c[i - 1] are the same witness with the same value
+        vals[ids[col]] = np.frombuffer(wires[col], np.uint8).reshape(n, 32)
+    one = int.to_bytes(R, 32, "little")
+    minus_one = int.to_bytes((Q - 1) * R % Q, 32, "little")
+    selectors = {k: v for k, v in cols.items() if k.startswith("q_")}
+    selectors["q_o"] = minus_one * n
+    selectors["q_arith"] = one * n
+    return dict(selectors=selectors, wires=[x.astype(np.uint32).tobytes() for x in ids], witnesses=count,
+                values=vals.tobytes(), columns=wires, public_inputs={})
+
+
+def widget_columns(log_n: int, blk_log: int = 8, pool: int = 64) -> dict:
+    """widget_circuit(log_n) the same way: position (column, row) of pool block b is ONE witness shared by every tile
+    drawn from b — the copy constraints widget_circuit writes into the sigma columns directly."""
+    import numpy as np
+    n = 1 << log_n
+    blk, tiles, pool, ids, blocks = _widget_layout(log_n, blk_log, pool)
+    wires, cols, pi = widget_circuit(log_n, blk_log, pool)
+    tile_ids = np.repeat(np.asarray(ids, dtype=np.int64), blk)
+    row = np.tile(np.arange(blk, dtype=np.int64), tiles)
+    idx = [((tile_ids * 4 + col) * blk + row).astype(np.uint32).tobytes() for col in range(4)]
+    mont = lambda v: v % Q * R % Q   # noqa: E731
+    vals = b"".join(_bytes([mont(rw[0][col]) for rw in blocks[b]]) for b in range(pool) for col in range(4))
+    return dict(selectors={k: v for k, v in cols.items() if k.startswith("q_")}, wires=idx, witnesses=pool * 4 * blk,
+                values=vals, columns=wires, public_inputs=pi)
 
 
 if __name__ == "__main__":   # chunk worker of arithmetic_circuit: <profile> <seed> <count> <output file>

@@ -156,9 +156,11 @@ typedef struct {
   uint64_t srs_total;            /* global SRS length (only read when shard_world > 1)  */
   plonk_allgather_fn allgather;
   void* allgather_user;
-  /* Multi-GPU only (ignored for shard_world <= 1, where the prover derives it itself): this rank's slice
-   * [shard_rank * S, shard_rank * S + lagrange_count) of the (size + 2)-point Lagrange-basis key that
-   * plonk_lagrange_key returns, S as above; NULL / 0 = commit to the wire polynomials in coefficient form. */
+  /* The Lagrange-basis key of plonk_lagrange_key, or this rank's part of it.
+   * shard_world <= 1: all size + 2 points (lagrange_count == size + 2) of a key computed earlier for the same
+   *   commit key and size — the prover then skips the group FFT (the bulk of its build time); NULL = derive it.
+   * shard_world > 1: the slice [shard_rank * S, shard_rank * S + lagrange_count) of those points, S as above;
+   *   NULL / 0 = commit to the wire polynomials in coefficient form. */
   const uint8_t* lagrange_xy96;
   uint64_t lagrange_count;
 } plonk_prover_desc;
@@ -187,6 +189,46 @@ int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const ui
 int plonk_prover_prove_dev(plonk_prover* p, const void* wires_dev, const uint64_t* pi_idx,
                            const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
                            uint8_t proof[1008]);
+
+/* ---- Compiler::preprocess on the device -------------------------------------------------
+ * plonk_compile replaces Compiler::preprocess (src/compiler.rs:132-461) for a circuit the caller has
+ * already laid out as gates: what Composer holds after Circuit::circuit ran (src/composer.rs:119-167 —
+ * per gate the 11 selector values and the witness index on each of its four wires).  On the device:
+ * the 11 selector interpolations (compiler.rs:177-187), the four sigma polynomials
+ * (Permutation::compute_sigma_polynomials, src/composer/permutation.rs:106-211), the 15 VerifierKey
+ * commitments (compiler.rs:213-232) and the evaluation arrays of the ProverKey (compiler.rs:310-425; on the
+ * quotient domain this library uses, see plonk_prover_create).  The result is a prover like the one
+ * plonk_prover_create builds from coefficient forms; plonk_prover_vk returns the commitments.
+ *
+ * selectors[k]: `constraints` Fr values (Montgomery limbs) of selector k in plonk_prover_desc.polys order
+ *   (q_m q_l q_r q_o q_f q_c q_arith q_range q_logic q_fixed_group_add q_variable_group_add); NULL = zero.
+ * wires[w]: `constraints` witness indices (Witness::index) on wires a, b, c, d; every index < witnesses.
+ * The shard_* / allgather / lagrange_* fields mean what they mean in plonk_prover_desc.
+ * Errors: PLONK_ERR_ARG (NULL wires, index out of range, fewer than 2 gates), PLONK_ERR_DEGREE (commit key
+ * shorter than the domain), PLONK_ERR_NO_SRS. */
+typedef struct {
+  uint64_t constraints;
+  const uint8_t* label;
+  uint64_t label_len;
+  const uint64_t* selectors[11];
+  const uint32_t* wires[4];
+  uint64_t witnesses;            /* number of witnesses the composer allocated                */
+  int shard_rank;
+  int shard_world;
+  uint64_t srs_total;
+  plonk_allgather_fn allgather;
+  void* allgather_user;
+  const uint8_t* lagrange_xy96;
+  uint64_t lagrange_count;
+} plonk_circuit_desc;
+int plonk_compile(plonk_ctx* ctx, const plonk_circuit_desc* circuit, plonk_prover** out);
+/* Prove from the witness VALUES (count x Fr, count == circuit.witnesses) on a prover built by plonk_compile:
+ * the four wire columns of prove_inner (prover.rs:446-460) are gathered in HBM from the witness table, so
+ * only the distinct values cross PCIe.  Everything else as plonk_prover_prove.  PLONK_ERR_STATE on a prover
+ * that was not compiled from a circuit. */
+int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uint64_t count, const uint64_t* pi_idx,
+                                 const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
+                                 uint8_t proof[1008]);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------------
  * Rank 0 calls plonk_comm_unique_id and hands the 128 bytes (an ncclUniqueId) to the other ranks by

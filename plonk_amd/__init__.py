@@ -48,6 +48,7 @@ EXPORTS = [
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
+    "plonk_compile", "plonk_prover_prove_witnesses",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -58,6 +59,14 @@ class _ProverDesc(ctypes.Structure):
     _fields_ = [("constraints", ctypes.c_uint64), ("label", ctypes.c_char_p), ("label_len", ctypes.c_uint64),
                 ("polys", ctypes.c_void_p * 15), ("poly_len", ctypes.c_uint64 * 15),
                 ("vk_commitments", ctypes.c_char_p), ("shard_rank", ctypes.c_int), ("shard_world", ctypes.c_int),
+                ("srs_total", ctypes.c_uint64), ("allgather", ctypes.c_void_p), ("allgather_user", ctypes.c_void_p),
+                ("lagrange_xy96", ctypes.c_char_p), ("lagrange_count", ctypes.c_uint64)]
+
+
+class _CircuitDesc(ctypes.Structure):
+    _fields_ = [("constraints", ctypes.c_uint64), ("label", ctypes.c_char_p), ("label_len", ctypes.c_uint64),
+                ("selectors", ctypes.c_void_p * 11), ("wires", ctypes.c_void_p * 4), ("witnesses", ctypes.c_uint64),
+                ("shard_rank", ctypes.c_int), ("shard_world", ctypes.c_int),
                 ("srs_total", ctypes.c_uint64), ("allgather", ctypes.c_void_p), ("allgather_user", ctypes.c_void_p),
                 ("lagrange_xy96", ctypes.c_char_p), ("lagrange_count", ctypes.c_uint64)]
 
@@ -156,6 +165,8 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_prover_from_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
     lib.plonk_srs_validate.argtypes = [vp, vp, u64]
     lib.plonk_lagrange_key.argtypes = [vp, u32, vp]
+    lib.plonk_compile.argtypes = [vp, ctypes.POINTER(_CircuitDesc), ctypes.POINTER(vp)]
+    lib.plonk_prover_prove_witnesses.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp]
     lib.plonk_host_alloc.argtypes = [u64, ctypes.POINTER(vp)]
     lib.plonk_host_free.argtypes = [vp]
     lib.plonk_comm_unique_id.argtypes = [vp]
@@ -444,23 +455,7 @@ class Prover:
         communicator; lagrange_slice: this rank's points of Context.lagrange_key (multi-GPU)."""
         self.ctx = ctx
         desc = _ProverDesc()
-        self._cb = None
-        if world > 1:
-            desc.shard_rank, desc.shard_world, desc.srs_total = rank, world, srs_total
-        if world > 1 and allgather is not None:
-            def _cb(user, send, recv, nbytes):
-                try:
-                    out = allgather(ctypes.string_at(send, nbytes))
-                    assert len(out) == nbytes * world
-                    ctypes.memmove(recv, out, len(out))
-                    return 0
-                except Exception:   # never unwind through the C frame
-                    import traceback
-                    traceback.print_exc()
-                    return 1
-            self._cb = ALLGATHER_FN(_cb)
-            desc.shard_rank, desc.shard_world, desc.srs_total = rank, world, srs_total
-            desc.allgather = ctypes.cast(self._cb, ctypes.c_void_p)
+        self._shard(desc, rank, world, srs_total, allgather, lagrange_slice)
         desc.constraints = constraints
         desc.label = label
         desc.label_len = len(label)
@@ -473,9 +468,6 @@ class Prover:
             desc.polys[k] = ctypes.cast(buf, ctypes.c_void_p)
             desc.poly_len[k] = len(raw) // 32
         desc.vk_commitments = vk_commitments
-        if lagrange_slice is not None:   # an empty slice still selects the mode (every rank must take the same one)
-            desc.lagrange_xy96 = lagrange_slice if lagrange_slice else b"\0"
-            desc.lagrange_count = len(lagrange_slice) // 96
         h = ctypes.c_void_p()
         ctx._check(ctx.lib.plonk_prover_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
         self.handle = h
@@ -494,6 +486,82 @@ class Prover:
         self.handle = h
         self.size = ctx.lib.plonk_prover_size(h)
         return self
+
+    def _shard(self, desc, rank, world, srs_total, allgather, lagrange_slice):
+        self._cb = None
+        if world > 1:
+            desc.shard_rank, desc.shard_world, desc.srs_total = rank, world, srs_total
+        if world > 1 and allgather is not None:
+            def _cb(user, send, recv, nbytes):
+                try:
+                    out = allgather(ctypes.string_at(send, nbytes))
+                    assert len(out) == nbytes * world
+                    ctypes.memmove(recv, out, len(out))
+                    return 0
+                except Exception:   # never unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = ALLGATHER_FN(_cb)
+            desc.allgather = ctypes.cast(self._cb, ctypes.c_void_p)
+        if lagrange_slice is not None:   # an empty slice still selects the mode (every rank must take the same one)
+            desc.lagrange_xy96 = lagrange_slice if lagrange_slice else b"\0"
+            desc.lagrange_count = len(lagrange_slice) // 96
+
+    @classmethod
+    def compile(cls, ctx: Context, label: bytes, selectors: dict, wires, witnesses: int, rank: int = 0, world: int = 1,
+                srs_total: int = 0, allgather=None, lagrange_slice: bytes | None = None) -> "Prover":
+        """Compiler::preprocess (reference src/compiler.rs:132-461) on the device.  selectors: {name: per-gate values},
+        names from POLY_ORDER[:11], values as ints or Montgomery bytes, missing = zero; wires: four sequences of witness
+        indices (one per gate); witnesses: how many witnesses the composer allocated."""
+        self = cls.__new__(cls)
+        self.ctx, self._keep = ctx, []
+        desc = _CircuitDesc()
+        self._shard(desc, rank, world, srs_total, allgather, lagrange_slice)
+        def u32_bytes(w):   # list of ints, raw little-endian uint32 bytes, or anything with tobytes() (a uint32 array)
+            if isinstance(w, (bytes, bytearray)):
+                return bytes(w)
+            if hasattr(w, "tobytes"):
+                assert getattr(w, "itemsize", 4) == 4
+                return w.tobytes()
+            return bytes((ctypes.c_uint32 * len(w))(*w))
+        wire_raw = [u32_bytes(w) for w in wires]
+        constraints = len(wire_raw[0]) // 4
+        desc.constraints, desc.label, desc.label_len, desc.witnesses = constraints, label, len(label), witnesses
+        for k, name in enumerate(POLY_ORDER[:11]):
+            col = selectors.get(name)
+            if col is None or len(col) == 0:
+                continue
+            raw = bytes(col) if isinstance(col, (bytes, bytearray)) else fr_to_bytes_mont(col)
+            assert len(raw) == 32 * constraints, name
+            self._keep.append(raw)   # the library reads the bytes object in place
+            desc.selectors[k] = ctypes.cast(ctypes.c_char_p(raw), ctypes.c_void_p)
+        for w in range(4):
+            assert len(wire_raw[w]) == 4 * constraints
+            desc.wires[w] = ctypes.cast(ctypes.c_char_p(wire_raw[w]), ctypes.c_void_p)
+        h = ctypes.c_void_p()
+        ctx._check(ctx.lib.plonk_compile(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
+        self.handle = h
+        self.size = ctx.lib.plonk_prover_size(h)
+        self._keep = None
+        return self
+
+    def prove_witnesses(self, witnesses, public_inputs, blinders) -> bytes:
+        """Proof from the witness values (ints or Montgomery bytes) on a compiled prover (prover.rs:446-460 on the device)."""
+        raw = bytes(witnesses) if isinstance(witnesses, (bytes, bytearray)) else fr_to_bytes_mont(witnesses)
+        bl = bytes(blinders) if isinstance(blinders, (bytes, bytearray)) else fr_to_bytes_mont(blinders)
+        assert len(bl) == 14 * 32
+        idx, val, cnt = self._pi(public_inputs)
+        proof = ctypes.create_string_buffer(1008)
+        self.ctx._check(self.ctx.lib.plonk_prover_prove_witnesses(self.handle, raw, len(raw) // 32, idx, val, cnt, bl, proof))
+        return proof.raw
+
+    def prove_witnesses_ptr(self, values_ptr: int, count: int, public_inputs, blinders_mont: bytes) -> bytes:
+        """prove_witnesses on a raw host address (e.g. PinnedBuffer.ptr) holding count x 32 bytes."""
+        idx, val, cnt = self._pi(public_inputs)
+        proof = ctypes.create_string_buffer(1008)
+        self.ctx._check(self.ctx.lib.plonk_prover_prove_witnesses(self.handle, values_ptr, count, idx, val, cnt, blinders_mont, proof))
+        return proof.raw
 
     def vk_commitments(self) -> bytes:
         out = ctypes.create_string_buffer(15 * 48)

@@ -88,6 +88,32 @@ __global__ void __launch_bounds__(256) trimmed_len_kernel(const Fr* __restrict__
   if (threadIdx.x == 0 && sh[0]) atomicMax(out, sh[0]);
 }
 
+// ---------------------------------------------------------------------------
+// Compiler::preprocess pieces (prover.hip plonk_compile)
+// ---------------------------------------------------------------------------
+// Permutation::compute_permutation_lagrange (src/composer/permutation.rs:141-175): the packed position
+// (column << 30 | row, permutation.hpp) that wire (col, i) maps to becomes K_column * w^row; `roots` holds
+// w^row for row < n.  out has one array of n values per column, `stride` elements apart.
+__global__ void __launch_bounds__(256) sigma_evals_kernel(const uint32_t* __restrict__ map, const Fr* __restrict__ roots,
+                                                          Fr* __restrict__ out, uint64_t n, uint64_t stride, SigmaArgs a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t col = blockIdx.y;
+  if (i >= n) return;
+  const uint32_t m = map[(uint64_t)col * n + i];
+  const uint32_t to = m >> 30;
+  const Fr r = ldf(roots + (m & 0x3FFFFFFFu));
+  stf(out + (uint64_t)col * stride + i, to ? r * a.ks[to] : r);
+}
+// Wire columns of a proof from the witness values (prover.rs:446-460): column `col`, row i takes the value
+// of witness idx[col][i]; rows past the last gate are zero.
+__global__ void __launch_bounds__(256) gather_wires_kernel(const uint32_t* __restrict__ idx, const Fr* __restrict__ values,
+                                                           Fr* __restrict__ wires, uint64_t constraints, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t col = blockIdx.y;
+  if (i >= n) return;
+  stf(wires + (uint64_t)col * n + i, i < constraints ? ldf(values + idx[(uint64_t)col * constraints + i]) : Fr::zero());
+}
+
 __global__ void scatter_pi_kernel(Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) stf(dense + idx[i], ldf(val + i));
@@ -924,6 +950,20 @@ int poly_split_t(Ctx* c, Fr* t, uint64_t n, uint64_t np, Fr* out, const SplitArg
 int poly_trimmed_len(Ctx* c, const Fr* p, uint64_t n, unsigned long long* out_dev) {
   HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(trimmed_len_kernel, grid1(n, 256), dim3(256), 0, c->stream, p, n, out_dev);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_sigma_evals(Ctx* c, const uint32_t* map_dev, const Fr* roots, Fr* out, uint64_t n, uint64_t stride, const SigmaArgs& a) {
+  dim3 grid = grid1(n, 256);
+  grid.y = 4;
+  hipLaunchKernelGGL(sigma_evals_kernel, grid, dim3(256), 0, c->stream, map_dev, roots, out, n, stride, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_gather_wires(Ctx* c, const uint32_t* idx_dev, const Fr* values, Fr* wires, uint64_t constraints, uint64_t n) {
+  dim3 grid = grid1(n, 256);
+  grid.y = 4;
+  hipLaunchKernelGGL(gather_wires_kernel, grid, dim3(256), 0, c->stream, idx_dev, values, wires, constraints, n);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

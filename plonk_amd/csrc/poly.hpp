@@ -54,6 +54,9 @@ struct L1Args {
   Fr vh[8];
   Fr n_inv;
 };
+struct SigmaArgs {
+  Fr ks[4];   // 1, K1, K2, K3 (src/composer/permutation/constants.rs)
+};
 struct EvalItem {
   const Fr* poly;
   uint64_t len;
@@ -113,6 +116,9 @@ int poly_blind(Ctx* c, Fr* coeffs, uint64_t n, const BlindArgs& a);
 int poly_split_t(Ctx* c, Fr* t, uint64_t n, uint64_t np, Fr* out, const SplitArgs& a);
 int poly_trimmed_len(Ctx* c, const Fr* p, uint64_t n, unsigned long long* out_dev);
 int poly_scatter_pi(Ctx* c, Fr* dense, const uint64_t* idx, const Fr* val, uint64_t count);
+// Compiler::preprocess: sigma evaluations from the packed mappings of permutation.hpp; wire columns from witness values
+int poly_sigma_evals(Ctx* c, const uint32_t* map_dev, const Fr* roots, Fr* out, uint64_t n, uint64_t stride, const SigmaArgs& a);
+int poly_gather_wires(Ctx* c, const uint32_t* idx_dev, const Fr* values, Fr* wires, uint64_t constraints, uint64_t n);
 int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n, bool twiddle_form = false);
 int poly_perm_terms(Ctx* c, const PermArgs& a);
 int poly_mul_arrays(Ctx* c, Fr* a, const Fr* b, uint64_t n, int* zero_flag);   // operands in twiddle form

@@ -10,11 +10,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "poly.hpp"
 #include "transcript.hpp"
 #include "hostg1.hpp"
 #include "widgets.hpp"
+#include "permutation.hpp"
 
 static_assert(plonk::WQS_RANGE == plonk::QS_RANGE && plonk::WQS_LOGIC == plonk::QS_LOGIC && plonk::WQS_FIXED == plonk::QS_FIXED &&
               plonk::WQS_VAR == plonk::QS_VAR && plonk::WQS_COUNT == plonk::QS_COUNT, "widgets.hpp selector ids");
@@ -110,6 +112,10 @@ struct Prover {
   Fr* pi_val_dev = nullptr;
   uint64_t pi_cap = 0;
   uint32_t ev_max_blocks = 0;
+  // built by plonk_compile: the witness index behind every wire, so a proof can start from the witness values
+  uint32_t* wire_idx = nullptr;    // [4][constraints]
+  uint64_t witnesses = 0;
+  Fr* wit_vals = nullptr;          // [witnesses] staging of one proof's values
 };
 
 // ---- host helpers -------------------------------------------------------------------
@@ -203,6 +209,7 @@ static void prover_free(Prover* p) {
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
   for (void* b : {(void*)p->fold, (void*)p->Fbuf, (void*)p->send, (void*)p->recv, (void*)p->agg2, (void*)p->scratch2, p->lag_table, (void*)p->wscal}) if (b) (void)hipFree(b);
+  for (void* b : {(void*)p->wire_idx, (void*)p->wit_vals}) if (b) (void)hipFree(b);
   for (int k = 0; k < 8; ++k) { ntt_coset_free(&p->cs_fwd[k]); ntt_coset_free(&p->cs_inv[k]); }
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
@@ -222,7 +229,73 @@ struct BuildGuard {   // every early return of prover_build releases what was al
   ~BuildGuard() { if (p) prover_free(p); }
 };
 
-static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
+// What Compiler::preprocess starts from (compiler.rs:132-175): the composer's gates as columns
+struct CircuitSrc {
+  const Fr* selectors[QS_COUNT];   // per-gate selector values, nullptr = identically zero
+  const uint32_t* wires[4];        // witness index on wires a, b, c, d of every gate
+  uint64_t witnesses;
+};
+
+struct DevFree {   // scratch of one build step
+  void* p = nullptr;
+  ~DevFree() { if (p) (void)hipFree(p); }
+};
+
+// Compiler::preprocess steps 1-2 (compiler.rs:139-207) on the device: the selector columns are uploaded as they are
+// (zero beyond the last gate) and interpolated in place; the sigma mappings are worked out on the host in one pass over
+// the gates (permutation.hpp), turned into K_col * w^row evaluations by a kernel (permutation.rs:141-175) and
+// interpolated the same way.  Leaves p->polys / poly_len / key_low as the coefficient-form path does.
+static int compile_polynomials(Prover* p, const CircuitSrc* s) {
+  Ctx* c = p->c;
+  const uint64_t n = p->n, np = p->np, m = p->constraints;
+  const uint32_t L = p->logn;
+  if (n < 2) return (set_last_error("invalid argument", "plonk_compile: fewer than 2 gates", __FILE__, __LINE__), PLONK_ERR_ARG);
+  for (int w = 0; w < 4; ++w)
+    if (!s->wires[w]) return (set_last_error("invalid argument", "plonk_compile: wires", __FILE__, __LINE__), PLONK_ERR_ARG);
+  for (int k = 0; k < QS_COUNT; ++k)
+    if (s->selectors[k]) HIP_TRY(hipMemcpyAsync(p->polys + k * np, s->selectors[k], sizeof(Fr) * m, hipMemcpyHostToDevice, c->stream));
+  // w^i, i < n (domain.elements(), permutation.rs:146): the polynomial X evaluated over the domain
+  Fr* roots = p->cos;   // per-proof buffer, free until the first proof
+  const Fr lin[2] = {Fr::zero(), Fr::one()};
+  HIP_TRY(hipMemcpyAsync(p->scratch, lin, sizeof lin, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  PTRY(ntt_device(c, p->scratch, roots, p->tmp8, L, false, false, 2));
+  // the selector interpolations run while the host walks the copy constraints
+  for (int k = 0; k < QS_COUNT; ++k)
+    if (s->selectors[k]) PTRY(ntt_device(c, p->polys + k * np, p->polys + k * np, p->tmp8, L, true, false, n));
+  {
+    std::vector<uint32_t> map(4 * n);
+    if (!sigma_mappings(s->wires, m, n, s->witnesses, map.data()))
+      return (set_last_error("invalid argument", "plonk_compile: witness index out of range", __FILE__, __LINE__), PLONK_ERR_ARG);
+    DevFree map_dev;
+    HIP_TRY(hipMalloc(&map_dev.p, sizeof(uint32_t) * 4 * n));
+    HIP_TRY(hipMemcpyAsync(map_dev.p, map.data(), sizeof(uint32_t) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    SigmaArgs sa;
+    sa.ks[0] = Fr::one(); sa.ks[1] = fr_small(7); sa.ks[2] = fr_small(13); sa.ks[3] = fr_small(17);
+    PTRY(poly_sigma_evals(c, (const uint32_t*)map_dev.p, roots, p->polys + P_S1 * np, n, np, sa));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // map (host and device copy) is released here
+  }
+  for (int k = P_S1; k < P_S1 + 4; ++k) PTRY(ntt_device(c, p->polys + k * np, p->polys + k * np, p->tmp8, L, true, false, n));
+  // Polynomial::from_coefficients_vec (polynomial.rs:79): degrees and the low coefficients the host keeps
+  DevFree lens_dev;
+  HIP_TRY(hipMalloc(&lens_dev.p, sizeof(unsigned long long) * P_COUNT));
+  unsigned long long lens[P_COUNT];
+  for (int k = 0; k < P_COUNT; ++k) PTRY(poly_trimmed_len(c, p->polys + k * np, n, (unsigned long long*)lens_dev.p + k));
+  HIP_TRY(hipMemcpyAsync(lens, lens_dev.p, sizeof lens, hipMemcpyDeviceToHost, c->stream));
+  for (int k = 0; k < P_COUNT; ++k)
+    HIP_TRY(hipMemcpyAsync(p->key_low[k], p->polys + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));   // np >= n + 8: zero past the degree
+  // the witness index of every wire stays on the device for plonk_prover_prove_witnesses
+  HIP_TRY(hipMalloc((void**)&p->wire_idx, sizeof(uint32_t) * 4 * m));
+  for (int w = 0; w < 4; ++w)
+    HIP_TRY(hipMemcpyAsync(p->wire_idx + w * m, s->wires[w], sizeof(uint32_t) * m, hipMemcpyHostToDevice, c->stream));
+  p->witnesses = s->witnesses;
+  HIP_TRY(hipMalloc((void**)&p->wit_vals, sizeof(Fr) * (s->witnesses ? s->witnesses : 1)));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < P_COUNT; ++k) p->poly_len[k] = lens[k];
+  return PLONK_OK;
+}
+
+static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* circ, Prover** out) {
   if (!d || d->constraints == 0) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   if (d->label_len && !d->label) return (plonk::set_last_error("invalid argument: label", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   for (int k = 0; k < P_COUNT; ++k)
@@ -331,19 +404,23 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
 
   // ---- ProverKey polynomials (coefficient form, trailing zeros ignored)
   PTRY(poly_fill_zero(c, p->polys, P_COUNT * np));
-  for (int k = 0; k < P_COUNT; ++k) {
-    uint64_t len = d->poly_len[k];
-    if (len > n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-    if (len) HIP_TRY(hipMemcpyAsync(p->polys + k * np, d->polys[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c->stream));
-    // Polynomial::from_coefficients_vec trim (polynomial.rs:79): highest non-zero coefficient
-    const Fr* hp = (const Fr*)d->polys[k];
-    while (len && hp[len - 1].is_zero()) --len;
-    p->poly_len[k] = len;
+  if (circ) {
+    PTRY(compile_polynomials(p, circ));
+  } else {
+    for (int k = 0; k < P_COUNT; ++k) {
+      uint64_t len = d->poly_len[k];
+      if (len > n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+      if (len) HIP_TRY(hipMemcpyAsync(p->polys + k * np, d->polys[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c->stream));
+      // Polynomial::from_coefficients_vec trim (polynomial.rs:79): highest non-zero coefficient
+      const Fr* hp = (const Fr*)d->polys[k];
+      while (len && hp[len - 1].is_zero()) --len;
+      p->poly_len[k] = len;
+    }
+    for (int k = 0; k < P_COUNT; ++k)
+      for (int i = 0; i < 7; ++i)
+        p->key_low[k][i] = (uint64_t)i < p->poly_len[k] ? ((const Fr*)d->polys[k])[i] : Fr::zero();
   }
   for (int s = 0; s < QS_COUNT; ++s) p->has[s] = p->poly_len[s] != 0;   // PolyId 0..10 == QS_*
-  for (int k = 0; k < P_COUNT; ++k)
-    for (int i = 0; i < 7; ++i)
-      p->key_low[k][i] = (uint64_t)i < p->poly_len[k] ? ((const Fr*)d->polys[k])[i] : Fr::zero();
 
   // ---- cached evaluations: 16 coset FFTs on the quotient domain (8n in compiler.rs:312-377) ...
   L1Args l1a;
@@ -429,9 +506,16 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, Prover** out) {
   {
     const char* wc = getenv("PLONK_WIRE_COMMIT");   // "coeff": commit to the coefficient form like the reference (A/B, fallback)
     if (p->world == 1 && !(wc && wc[0] == 'c') && c->srs_n >= n + 2 && n >= 2) {
+      if (d->lagrange_xy96 && d->lagrange_count != n + 2)
+        return (plonk::set_last_error("invalid argument", "lagrange_count is not size + 2", __FILE__, __LINE__), PLONK_ERR_ARG);
       G1Affine* lag_pts = nullptr;
       HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * (n + 2)));
-      int rc = lagrange_points_device(c, L, lag_pts);
+      int rc = PLONK_OK;
+      if (d->lagrange_xy96) {   // a key the caller kept from an earlier plonk_lagrange_key: skips the group FFT
+        if (hipMemcpyAsync(lag_pts, d->lagrange_xy96, sizeof(G1Affine) * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+      } else {
+        rc = lagrange_points_device(c, L, lag_pts);
+      }
       if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table);
       p->lag_n = n + 2;
       p->lag_on = true;
@@ -1271,7 +1355,34 @@ int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_pro
   HIP_TRY(hipSetDevice(ctx->c.device));
   if (!ctx->c.srs_table && desc->shard_world <= 1) return PLONK_ERR_NO_SRS;
   plonk::Prover* p = nullptr;
-  int rc = prover_build(&ctx->c, desc, &p);
+  int rc = prover_build(&ctx->c, desc, nullptr, &p);
+  if (rc) return rc;
+  *out = new plonk_prover{p, ctx};
+  return PLONK_OK;
+}
+
+int plonk_compile(plonk_ctx* ctx, const plonk_circuit_desc* circuit, plonk_prover** out) {
+  if (!ctx || !circuit || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  HIP_TRY(hipSetDevice(ctx->c.device));
+  if (!ctx->c.srs_table && circuit->shard_world <= 1) return PLONK_ERR_NO_SRS;
+  plonk_prover_desc d{};
+  d.constraints = circuit->constraints;
+  d.label = circuit->label;
+  d.label_len = circuit->label_len;
+  d.shard_rank = circuit->shard_rank;
+  d.shard_world = circuit->shard_world;
+  d.srs_total = circuit->srs_total;
+  d.allgather = circuit->allgather;
+  d.allgather_user = circuit->allgather_user;
+  d.lagrange_xy96 = circuit->lagrange_xy96;
+  d.lagrange_count = circuit->lagrange_count;
+  CircuitSrc src;
+  for (int k = 0; k < QS_COUNT; ++k) src.selectors[k] = (const Fr*)circuit->selectors[k];
+  for (int w = 0; w < 4; ++w) src.wires[w] = circuit->wires[w];
+  src.witnesses = circuit->witnesses;
+  plonk::Prover* p = nullptr;
+  int rc = prover_build(&ctx->c, &d, &src, &p);
   if (rc) return rc;
   *out = new plonk_prover{p, ctx};
   return PLONK_OK;
@@ -1318,6 +1429,21 @@ int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   return prover_prove(pr->p, (const Fr*)wires_dev, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+}
+
+int plonk_prover_prove_witnesses(plonk_prover* pr, const uint64_t* witnesses, uint64_t count, const uint64_t* pi_idx,
+                                 const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
+  if (!pr || !blinders || !proof || (count && !witnesses) || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  HIP_TRY(hipSetDevice(pr->ctx->c.device));
+  plonk::Prover* p = pr->p;
+  Ctx* c = p->c;
+  if (!p->wire_idx) return (plonk::set_last_error("prover was not built by plonk_compile: it has no wire -> witness table", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (count != p->witnesses) return (plonk::set_last_error("invalid argument", "witness count differs from the compiled circuit's", __FILE__, __LINE__), PLONK_ERR_ARG);
+  // a_scalars .. d_scalars of prove_inner (prover.rs:446-460), gathered in HBM
+  if (count) HIP_TRY(hipMemcpyAsync(p->wit_vals, witnesses, sizeof(Fr) * count, hipMemcpyHostToDevice, c->stream));
+  PTRY(poly_gather_wires(c, p->wire_idx, p->wit_vals, p->wires, p->constraints, p->n));
+  return prover_prove(p, p->wires, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
 }
 
 int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const uint64_t* pi_idx, const uint64_t* pi_val,

@@ -68,6 +68,19 @@ def compile_fast(composer, label: bytes) -> dict:
                 pi=pi, pi_idx=idx, pi_val=fr_bytes([pi[i] for i in idx]))
 
 
+def circuit_columns(composer) -> dict:
+    """A composed circuit as the columns Compiler::preprocess starts from (compiler.rs:145-175, composer.rs:119-167):
+    per-gate selector values (Montgomery bytes, all-zero selectors omitted), the witness index on every wire,
+    the witness values."""
+    sel = {}
+    for name in O.SELECTORS:
+        col = [getattr(g, name) % Q for g in composer.constraints]
+        if any(col):
+            sel[name] = fr_bytes(col)
+    wires = [[getattr(g, w) for g in composer.constraints] for w in "abcd"]
+    return dict(selectors=sel, wires=wires, witnesses=len(composer.witnesses), values=fr_bytes(composer.witnesses))
+
+
 def big_widget_circuit(ngates: int, seed: int = 1):
     """>= ngates - 8 and <= ngates gates: every widget family with honest non-trivial witnesses
     (tests/widget_circuits.py gadgets), random arithmetic gates in between, public inputs."""

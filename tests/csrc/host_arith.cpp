@@ -194,3 +194,11 @@ extern "C" void h_batch_compress(const uint8_t* pts96, int count, uint8_t* out48
   batch_xyzz_to_affine97(p, count, aff);
   for (int k = 0; k < count; ++k) g1_compress97(aff[k], out48 + 48 * k);
 }
+
+// ---- permutation.hpp: copy constraints -> sigma mappings (Permutation::compute_sigma_permutations) ----
+#include "../../plonk_amd/csrc/permutation.hpp"
+extern "C" int h_sigma_mappings(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint64_t constraints,
+                                uint64_t n, uint64_t witnesses, uint32_t* out) {
+  const uint32_t* wires[4] = {a, b, c, d};
+  return plonk::sigma_mappings(wires, constraints, n, witnesses, out) ? 0 : -1;
+}

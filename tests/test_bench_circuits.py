@@ -64,3 +64,46 @@ def test_chunk_workers_equal_the_in_process_generator():
     # the headline circuit is one chain from one stream: its digest is part of the bench line's stability
     w, c, t = BC.arithmetic_circuit(8, "dense")
     assert hashlib.blake2b(b"".join(w)).hexdigest()[:16] == hashlib.blake2b(b"".join(BC.arithmetic_circuit(8, "dense")[0])).hexdigest()[:16]
+
+
+def _sigma_columns_from_witnesses(lib, cc, log_n):
+    """Permutation::compute_sigma_polynomials' evaluation columns (permutation.rs:141-175) from the gate-column
+    form, through the product's host pass (plonk_amd/csrc/permutation.hpp, compiled for the host)."""
+    import ctypes
+    n = 1 << log_n
+    out = (ctypes.c_uint32 * (4 * n))()
+    bufs = [ctypes.create_string_buffer(w, len(w)) for w in cc["wires"]]
+    args = [ctypes.cast(b, ctypes.POINTER(ctypes.c_uint32)) for b in bufs]
+    assert lib.h_sigma_mappings(*args, ctypes.c_uint64(n), ctypes.c_uint64(n), ctypes.c_uint64(cc["witnesses"]), out) == 0
+    T = BC._omega_table(log_n)
+    ks = (1, BC.K1, BC.K2, BC.K3)
+    return [BC._bytes([ks[out[col * n + i] >> 30] * T[out[col * n + i] & 0x3FFFFFFF] % BC.Q for i in range(n)]) for col in range(4)]
+
+
+def test_gate_column_forms_describe_the_same_circuits():
+    """arithmetic_columns / widget_columns (what plonk_compile takes) against arithmetic_circuit / widget_circuit
+    (what the coefficient-form path takes): same wire columns from the witness table, same sigma columns from the
+    witness indices, same selectors."""
+    from tests.test_field_host import build_host_lib
+    lib = build_host_lib()
+    log_n = 10
+    for profile in ("dense", "bench-like"):
+        wires, cols, trivial = BC.arithmetic_circuit(log_n, profile)
+        cc = BC.arithmetic_columns(log_n, profile)
+        sig = _sigma_columns_from_witnesses(lib, cc, log_n)
+        T = BC._omega_table(log_n)
+        assert sig[0] == cols["s_sigma_1"] and sig[2] == cols["s_sigma_3"]
+        assert sig[1] == BC._bytes([BC.K1 * t % BC.Q for t in T]) and sig[3] == BC._bytes([BC.K3 * t % BC.Q for t in T])
+        assert trivial["s_sigma_2"] == [0, BC.K1] and trivial["s_sigma_4"] == [0, BC.K3]
+        for name in ("q_m", "q_l", "q_r", "q_f", "q_c"):
+            assert cc["selectors"][name] == cols[name]
+        assert C.fr_vals(cc["selectors"]["q_o"]) == [BC.Q - 1] * (1 << log_n) and trivial["q_o"] == [BC.Q - 1]
+        assert C.fr_vals(cc["selectors"]["q_arith"]) == [1] * (1 << log_n) and trivial["q_arith"] == [1]
+        assert cc["columns"] == wires
+    wires, cols, pi = BC.widget_circuit(11)
+    cc = BC.widget_columns(11)
+    sig = _sigma_columns_from_witnesses(lib, cc, 11)
+    for k in range(4):
+        assert sig[k] == cols[f"s_sigma_{k + 1}"]
+    assert cc["columns"] == wires and cc["public_inputs"] == pi
+    assert {k: v for k, v in cols.items() if k.startswith("q_")} == cc["selectors"]

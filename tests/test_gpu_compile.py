@@ -1,0 +1,147 @@
+"""GPU parity of plonk_compile (Compiler::preprocess on the device, reference src/compiler.rs:132-461) and
+plonk_prover_prove_witnesses (prove_inner's wire columns gathered from the witness values, prover.rs:446-460):
+
+  * the reference KAT through the compiled prover: MinimalCircuit laid out as gate columns -> VerifierKey
+    commitments of the oracle's Compiler::preprocess -> blake2b(proof) == the literal at prover.rs:1151-1158;
+  * circuits with every widget family at 2^12 / 2^13 gates: the 15 key polynomials coefficient by coefficient
+    against the C oracle's interpolation of the same columns (tests/circuits.py compile_fast), the 15
+    commitments against the C oracle prover's, the proof bytes against the C oracle's prove();
+  * the error surface."""
+import hashlib
+
+import pytest
+
+from oracle import bls12_381 as E
+from oracle import cbind
+from oracle.rng import StdRng
+from tests import circuits as C
+from tests.test_oracle_kat import KAT_DIGEST
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plonk_amd
+    c = plonk_amd.Context(0)
+    yield c
+    c.close()
+
+
+def compiled(ctx, comp, label, **kw):
+    import plonk_amd
+    cols = C.circuit_columns(comp)
+    return plonk_amd.Prover.compile(ctx, label, cols["selectors"], cols["wires"], cols["witnesses"], **kw), cols
+
+
+@pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
+def test_kat_circuit_compiled_on_the_device(ctx, kat_setup, monkeypatch, domain):
+    import plonk_amd
+    if domain == "quotient-8n":
+        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
+    else:
+        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    _, oprover, circuit = kat_setup
+    ctx.srs_load(oprover.ck)
+    comp = circuit()
+    gp, cols = compiled(ctx, comp, b"proof-compatibility")
+    assert gp.size == oprover.size == 8
+    assert gp.vk_commitments() == b"".join(E.g1_compress(oprover.vk[n]) for n in plonk_amd.POLY_ORDER)
+    for k, name in enumerate(plonk_amd.POLY_ORDER):
+        want = list(oprover.pk.polys[name])
+        got = gp.peek(12, k * (gp.size + 8), gp.size)
+        assert got == want + [0] * (gp.size - len(want)), name
+    rng = StdRng.seed_from_u64(0x9235E701)
+    blinders = [rng.random_scalar() for _ in range(14)]
+    proof = gp.prove_witnesses(cols["values"], {}, blinders)
+    assert hashlib.blake2b(proof).digest() == KAT_DIGEST
+    gp.close()
+
+
+@pytest.mark.parametrize("log_n", [12, 13])
+def test_compiled_key_and_proof_equal_the_c_oracle(ctx, log_n):
+    import plonk_amd
+    comp = C.big_widget_circuit(1 << log_n, seed=300 + log_n)()
+    case = C.compile_fast(comp, b"compile-parity")
+    n = case["size"]
+    srs = C.synthetic_srs(n + 7)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    gp, cols = compiled(ctx, comp, b"compile-parity")
+    assert gp.size == n
+    # key polynomials: iNTT of the same columns by the C oracle (EvaluationDomain::ifft)
+    for k, name in enumerate(plonk_amd.POLY_ORDER):
+        want = C.fr_vals(case["polys"][name]) if case["polys"][name] else [0] * n
+        assert gp.peek(12, k * (n + 8), n) == want, name
+    cp = cbind.CProver(case["constraints"], case["label"], case["polys"], srs)
+    assert gp.vk_commitments() == cp.vk()
+    bl = C.blinders(8100 + log_n)
+    expected = cp.prove(case["wires"], case["pi_idx"], case["pi_val"], bl)
+    got = gp.prove_witnesses(cols["values"], case["pi"], bl)
+    assert got == expected
+    # the gathered columns are the padded wire columns: the column entry point gives the same proof
+    assert gp.prove(case["wires"], case["pi"], C.fr_vals(bl)) == expected
+    # an unsatisfying witness table
+    bad = bytearray(cols["values"])
+    bad[32 * comp.constraints[len(comp.constraints) // 2].c] ^= 1
+    with pytest.raises(plonk_amd.CircuitUnsatisfied):
+        gp.prove_witnesses(bytes(bad), case["pi"], bl)
+    assert gp.prove_witnesses(cols["values"], case["pi"], bl) == expected
+    gp.close()
+
+
+def test_compile_error_surface(ctx):
+    import plonk_amd
+    comp = C.big_widget_circuit(200, seed=5)()
+    case = C.compile_fast(comp, b"errors")
+    srs = C.synthetic_srs(case["size"] + 7)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    cols = C.circuit_columns(comp)
+    with pytest.raises(plonk_amd.PlonkError) as e:            # witness index out of range
+        plonk_amd.Prover.compile(ctx, b"errors", cols["selectors"], cols["wires"], cols["witnesses"] - 1)
+    assert e.value.code == -1
+    gp = plonk_amd.Prover.compile(ctx, b"errors", cols["selectors"], cols["wires"], cols["witnesses"])
+    with pytest.raises(plonk_amd.PlonkError) as e:            # wrong number of witness values
+        gp.prove_witnesses(cols["values"][:-32], case["pi"], C.blinders(1))
+    assert e.value.code == -1
+    gp.close()
+    plain = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"])
+    with pytest.raises(plonk_amd.PlonkError) as e:            # not a compiled prover
+        plain.prove_witnesses(cols["values"], case["pi"], C.blinders(1))
+    assert e.value.code == -7
+    plain.close()
+    ctx.srs_load_bytes(srs[:96 * 64], 64)                     # commit key shorter than the domain
+    with pytest.raises(plonk_amd.PlonkError) as e:
+        plonk_amd.Prover.compile(ctx, b"errors", cols["selectors"], cols["wires"], cols["witnesses"])
+    assert e.value.code == -3
+
+
+def test_cached_lagrange_key_gives_the_same_prover(ctx):
+    """plonk_prover_desc.lagrange_xy96 on one GPU: a key kept from plonk_lagrange_key replaces the group FFT of the
+    build; same commitments, same proof.  A key of the wrong length is refused."""
+    import plonk_amd
+    comp = C.big_widget_circuit(1 << 10, seed=77)()
+    case = C.compile_fast(comp, b"cached-key")
+    n, log_n = case["size"], case["log_n"]
+    srs = C.synthetic_srs(n + 7)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    key = ctx.lagrange_key(log_n)
+    assert len(key) == 96 * (n + 2)
+    cols = C.circuit_columns(comp)
+    bl = C.blinders(41)
+    fresh = plonk_amd.Prover.compile(ctx, b"cached-key", cols["selectors"], cols["wires"], cols["witnesses"])
+    want = fresh.prove_witnesses(cols["values"], case["pi"], bl)
+    fresh.close()
+    for make in (lambda: plonk_amd.Prover.compile(ctx, b"cached-key", cols["selectors"], cols["wires"], cols["witnesses"], lagrange_slice=key),
+                 lambda: plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=key)):
+        gp = make()
+        assert gp.prove(case["wires"], case["pi"], C.fr_vals(bl)) == want
+        gp.close()
+    with pytest.raises(plonk_amd.PlonkError) as e:
+        plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=key[:-96])
+    assert e.value.code == -1
+    # a corrupted key is a different commit key for the wires: the proof changes (nothing validates 2^20 points per build)
+    bad = bytearray(key)
+    bad[96 * 5:96 * 6] = key[96 * 6:96 * 7]
+    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=bytes(bad))
+    assert gp.prove(case["wires"], case["pi"], C.fr_vals(bl)) != want
+    gp.close()

@@ -36,10 +36,10 @@ def single(log_gates, profile):
     return _single[key]
 
 
-def multi(ranks, log_gates, profile, env):
+def multi(ranks, log_gates, profile, env, extra=()):
     return _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}",
                  "--master-addr", "127.0.0.1", "--master-port", str(29600 + ranks), "bench.py", "--gpus", str(ranks),
-                 "--log-gates", str(log_gates), "--steps", "1", "--warmup", "1", "--profile", profile, "--no-extras"], env)
+                 "--log-gates", str(log_gates), "--steps", "1", "--warmup", "1", "--profile", profile, "--no-extras", *extra], env)
 
 
 @pytest.mark.parametrize("ranks,log_gates,profile", [(2, 13, "widgets"), (4, 13, "widgets"), (8, 13, "widgets"),
@@ -50,6 +50,22 @@ def test_sharded_quotient_prove_matches_single_gpu(ranks, log_gates, profile):
     m = multi(ranks, log_gates, profile, {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
     assert m["n_gpus"] == ranks and s["n_gpus"] == 1 and m["config"]["collective"] == "gloo"
     assert "residue class" in m["config"]["parallelism"]
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
+@pytest.mark.parametrize("ranks,log_gates,profile", [(1, 13, "widgets"), (2, 13, "widgets"), (4, 12, "dense")])
+def test_compiled_prover_matches_the_coefficient_form_prover(ranks, log_gates, profile):
+    """plonk_compile (Compiler::preprocess on the device: gate columns + witness indices in) on 1 / 2 / 4 ranks — the
+    VerifierKey commitments are sharded MSMs like every other commitment — against the single-GPU prover built
+    from coefficient forms; bench.py --from-circuit also proves from the witness table on every rank
+    (plonk_prover_prove_witnesses) and compares with the wire-column entry point."""
+    s = single(log_gates, profile)
+    if ranks == 1:
+        m = _run([sys.executable, "bench.py", "--log-gates", str(log_gates), "--steps", "1", "--warmup", "0", "--profile", profile,
+                  "--no-cpu-baseline", "--no-extras", "--from-circuit"])
+    else:
+        m = multi(ranks, log_gates, profile, {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"}, ["--from-circuit"])
+    assert "plonk_compile" in m["config"]["prover_built_by"] and "plonk_prover_create" in s["config"]["prover_built_by"]
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
