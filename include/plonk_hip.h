@@ -258,6 +258,17 @@ int plonk_comm_destroy(plonk_ctx* ctx);
  * equation of the commit-key points; the subgroup check needs the GPU (plonk_srs_validate).
  * plonk_srs_validate: CommitKey::from_raw_var_bytes' per-point is_on_curve & is_torsion_free
  * (key.rs:283-294) for x||y points as taken by plonk_srs_load. */
+/* The other direction.  plonk_prover_to_bytes writes what the reference's Prover::to_bytes() writes
+ * (prover.rs:238-263) for this prover and the commit key its context holds — the key polynomials, their 8n coset
+ * evaluations (computed on the device and streamed out: 17 x 8 x size scalars, 4.6 GB at 2^20 gates), the raw commit
+ * key and the VerifierKey — so a circuit compiled by plonk_compile can be loaded by the unmodified reference
+ * (Prover::try_from_bytes) or by plonk_prover_from_bytes later.  plonk_verifier_to_bytes writes Verifier::to_bytes()
+ * (src/compiler/verifier.rs:88-117) from the prover's label / sizes / VerifierKey, the caller's OpeningKey::to_bytes()
+ * (opaque here: G2 never enters this library) and the public-input indexes.
+ * Both: out == NULL reports the length in *len; otherwise cap >= *len bytes are written.  Single-GPU provers only. */
+int plonk_prover_to_bytes(plonk_prover* p, uint8_t* out, uint64_t cap, uint64_t* len);
+int plonk_verifier_to_bytes(plonk_prover* p, const uint8_t* opening_key, uint64_t opening_key_len,
+                            const uint64_t* pi_idx, uint64_t pi_count, uint8_t* out, uint64_t cap, uint64_t* len);
 typedef struct {
   uint64_t size, constraints;
   uint64_t label_off, label_len;

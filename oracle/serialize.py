@@ -18,6 +18,11 @@ Follows (paths relative to the dusk-network/plonk tree):
                                            97-byte raw points (x || y Montgomery limbs || infinity)
   src/proof_system/widget.rs:84-111       VerifierKey::to_bytes — u64 n + 15 compressed
                                            commitments inside a 20 x 48 + 8 = 968-byte buffer
+  src/compiler/verifier.rs:62-117         Verifier::prepare_serialize / to_bytes — six big-endian u64
+                                           (label, verifier-key, opening-key lengths, number of public
+                                           inputs, size, constraints), label, VerifierKey, OpeningKey
+                                           (key.rs:597-607: g, h, beta_h compressed = 240 bytes),
+                                           big-endian u64 public-input indexes
 """
 from __future__ import annotations
 
@@ -91,3 +96,10 @@ def prover_to_bytes(prover) -> bytes:
     head = b"".join(v.to_bytes(8, "big") for v in (len(prover.label), len(pk), len(ck), len(vk),
                                                    prover.size, prover.constraints))
     return head + prover.label + pk + ck + vk
+
+
+def verifier_to_bytes(label: bytes, vk: dict, opening_key: bytes, public_input_indexes, size: int, constraints: int) -> bytes:
+    vkb = verifier_key_to_bytes(vk)
+    idx = list(public_input_indexes)
+    head = b"".join(v.to_bytes(8, "big") for v in (len(label), len(vkb), len(opening_key), len(idx), size, constraints))
+    return head + label + vkb + opening_key + b"".join(i.to_bytes(8, "big") for i in idx)

@@ -48,7 +48,7 @@ EXPORTS = [
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
-    "plonk_compile", "plonk_prover_prove_witnesses",
+    "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -167,6 +167,8 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_lagrange_key.argtypes = [vp, u32, vp]
     lib.plonk_compile.argtypes = [vp, ctypes.POINTER(_CircuitDesc), ctypes.POINTER(vp)]
     lib.plonk_prover_prove_witnesses.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp]
+    lib.plonk_prover_to_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(u64)]
+    lib.plonk_verifier_to_bytes.argtypes = [vp, vp, u64, vp, u64, vp, u64, ctypes.POINTER(u64)]
     lib.plonk_host_alloc.argtypes = [u64, ctypes.POINTER(vp)]
     lib.plonk_host_free.argtypes = [vp]
     lib.plonk_comm_unique_id.argtypes = [vp]
@@ -562,6 +564,24 @@ class Prover:
         proof = ctypes.create_string_buffer(1008)
         self.ctx._check(self.ctx.lib.plonk_prover_prove_witnesses(self.handle, values_ptr, count, idx, val, cnt, blinders_mont, proof))
         return proof.raw
+
+    def to_bytes(self) -> bytes:
+        """Prover::to_bytes() (reference prover.rs:238-263) of this prover and its context's commit key."""
+        n = ctypes.c_uint64()
+        self.ctx._check(self.ctx.lib.plonk_prover_to_bytes(self.handle, None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        self.ctx._check(self.ctx.lib.plonk_prover_to_bytes(self.handle, buf, n.value, ctypes.byref(n)))
+        return buf.raw
+
+    def verifier_to_bytes(self, opening_key: bytes, public_input_indexes) -> bytes:
+        """Verifier::to_bytes() (reference verifier.rs:88-117); opening_key = OpeningKey::to_bytes() of the caller's parameters."""
+        idx = list(public_input_indexes)
+        arr = (ctypes.c_uint64 * max(len(idx), 1))(*idx)
+        n = ctypes.c_uint64()
+        self.ctx._check(self.ctx.lib.plonk_verifier_to_bytes(self.handle, opening_key, len(opening_key), arr, len(idx), None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        self.ctx._check(self.ctx.lib.plonk_verifier_to_bytes(self.handle, opening_key, len(opening_key), arr, len(idx), buf, n.value, ctypes.byref(n)))
+        return buf.raw
 
     def vk_commitments(self) -> bytes:
         out = ctypes.create_string_buffer(15 * 48)

@@ -611,6 +611,24 @@ int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
   return PLONK_OK;
 }
 
+// the commit key back in the ABI's form (x || y, 12 x 32-bit Montgomery limbs each, canonical) from row 0 of the
+// window tables: what CommitKey::to_raw_var_bytes serialises (key.rs:215-229) — plonk_prover_to_bytes
+__global__ void srs_export_kernel(const G1AffineR* __restrict__ row0, uint64_t n, G1Affine* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine a;
+  a.x = ld_f28(&row0[i].x).to_fp();
+  a.y = ld_f28(&row0[i].y).to_fp();
+  st_aff(out + i, a);
+}
+int srs_export_device(Ctx* c, G1Affine* out_dev) {
+  if (!c->srs_n) return PLONK_OK;
+  hipLaunchKernelGGL(srs_export_kernel, dim3((uint32_t)((c->srs_n + 63) / 64)), dim3(64), 0, c->stream,
+                     (const G1AffineR*)c->srs_table, c->srs_n, out_dev);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
 int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev) {
   HIP_TRY(hipMemsetAsync(flag_dev, 0, sizeof(int), c->stream));
   if (n) hipLaunchKernelGGL(srs_validate_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, n, flag_dev);

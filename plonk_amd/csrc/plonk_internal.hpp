@@ -152,6 +152,7 @@ int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
 int srs_table_begin(Ctx* c, uint64_t n);
 int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first, uint64_t count, hipStream_t st);
 int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev);
+int srs_export_device(Ctx* c, G1Affine* out_dev);   // the context's commit key (srs_n points) as x || y Montgomery limbs
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 // bit_sums = false: out[k] = the commitment (one XYZZ point).  true: out[k][0..16) = partial sums the
 // host combines with a short doubling chain (msm.hip msm_bits_kernel, prover.hip finish_bit_sums).

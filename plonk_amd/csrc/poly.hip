@@ -698,6 +698,12 @@ __global__ void scale_array_kernel(Fr* __restrict__ v, uint64_t n, Fr s) {
   if (i < n) stf(v + i, ldf(v + i) * s);
 }
 
+// Montgomery limbs -> canonical little-endian scalars (BlsScalar::to_bytes), for the serialisers
+__global__ void from_mont_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stf(dst + i, ldf(src + i).from_mont());
+}
+
 // L1 numerators on the coset: out[i] = v_h[i & 7] * n_inv  (to be multiplied by 1/(linear[i]-1))
 __global__ void l1_prepare_kernel(const Fr* __restrict__ linear, Fr* __restrict__ out, uint64_t n8) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1026,6 +1032,12 @@ int poly_quotient(Ctx* c, const QuotientArgs& q) {
     hipLaunchKernelGGL(quotient_kernel<false>, grid1(q.n8, 128), dim3(128), 0, c->stream, q, wc);
   }
   prof_end(c, 3);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int poly_from_mont(Ctx* c, const Fr* src, Fr* dst, uint64_t n) {
+  if (!n) return PLONK_OK;
+  hipLaunchKernelGGL(from_mont_kernel, grid1(n, 256), dim3(256), 0, c->stream, src, dst, n);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

@@ -127,6 +127,7 @@ int poly_quotient(Ctx* c, const QuotientArgs& q);
 int poly_dealias(Ctx* c, Fr* t, uint64_t nq, const Fr low[7], const Fr& g_inv);
 int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a);
 int poly_scale_array(Ctx* c, Fr* v, uint64_t n, const Fr& s);
+int poly_from_mont(Ctx* c, const Fr* src, Fr* dst, uint64_t n);   // canonical limbs (BlsScalar::to_bytes); dst may equal src
 void quotient_const(const Fr& c, int shift, uint32_t out[9]);
 void quotient_data(const Fr& c, uint32_t out[9]);
 int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev);

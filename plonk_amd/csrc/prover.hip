@@ -1431,6 +1431,153 @@ int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64
   return prover_prove(pr->p, (const Fr*)wires_dev, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
 }
 
+// ---- Prover::to_bytes / Verifier::to_bytes ------------------------------------------------------------------------
+namespace {
+inline void put_le64(uint8_t* p, uint64_t v) { for (int i = 0; i < 8; ++i) p[i] = (uint8_t)(v >> (8 * i)); }
+inline void put_be64(uint8_t* p, uint64_t v) { for (int i = 0; i < 8; ++i) p[i] = (uint8_t)(v >> (8 * (7 - i))); }
+inline void put_scalar(uint8_t* p, const Fr& x) {   // BlsScalar::to_bytes: canonical, little-endian
+  const Fr c = x.from_mont();
+  memcpy(p, c.l, 32);
+}
+// ProverKey::to_var_bytes / VerifierKey::to_bytes order (widget.rs:347-447, :84-111) against PolyId order:
+// q_range and q_logic trade places (the permutation is its own inverse)
+constexpr int SER_ORDER[15] = {P_QM, P_QL, P_QR, P_QO, P_QF, P_QC, P_QARITH, P_QLOGIC, P_QRANGE, P_QFIXED, P_QVAR, P_S1, P_S2, P_S3, P_S4};
+constexpr uint64_t SER_DOMAIN = 8 + 4 + 5 * 32, SER_VK = 20 * 48 + 8, SER_RAW_POINT = 97;
+// EvaluationDomain::to_bytes (domain.rs:59-79) of the domain of size 2^log
+void put_domain(uint8_t* p, uint32_t log) {
+  const uint64_t size = 1ull << log;
+  const Fr gen = omega_of(log), size_fe = Fr::from_u64(size);
+  put_le64(p, size);
+  for (int i = 0; i < 4; ++i) p[8 + i] = (uint8_t)(log >> (8 * i));
+  const Fr vals[5] = {size_fe, size_fe.inv(), gen, gen.inv(), fr_generator().inv()};
+  for (int k = 0; k < 5; ++k) put_scalar(p + 12 + 32 * k, vals[k]);
+}
+void put_vk(uint8_t* p, const Prover* pv) {   // VerifierKey::to_bytes: u64 n, 15 commitments, zero padding to 968 bytes
+  memset(p, 0, SER_VK);
+  put_le64(p, pv->constraints);
+  for (int j = 0; j < 15; ++j) memcpy(p + 8 + 48 * j, pv->vk[SER_ORDER[j]], 48);
+}
+}  // namespace
+
+int plonk_prover_to_bytes(plonk_prover* pr, uint8_t* out, uint64_t cap, uint64_t* len) {
+  if (!pr || !len) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  HIP_TRY(hipSetDevice(pr->ctx->c.device));
+  plonk::Prover* p = pr->p;
+  Ctx* c = p->c;
+  if (p->world > 1) return (plonk::set_last_error("a sharded prover holds one slice of the commit key; serialise where the whole key is", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (p->srs_gen != c->srs_gen) return (plonk::set_last_error("prover is bound to an SRS that was replaced on its context", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
+  const uint64_t n = p->n, n8 = 8 * n, np = p->np;
+  const uint32_t L = p->logn;
+  const uint64_t eval_size = SER_DOMAIN + 32 * n8;
+  uint64_t pk_len = 16 + 17 * eval_size;
+  for (int k = 0; k < P_COUNT; ++k) pk_len += 8 + 32 * p->poly_len[k];
+  const uint64_t ck_len = 8 + SER_RAW_POINT * c->srs_n;
+  const uint64_t total = 48 + p->label.size() + pk_len + ck_len + SER_VK;
+  *len = total;
+  if (!out) return PLONK_OK;                      // size query
+  if (cap < total) return (plonk::set_last_error("invalid argument", "output buffer too small", __FILE__, __LINE__), PLONK_ERR_ARG);
+  uint8_t* w = out;
+  // six big-endian u64 (prover.rs:247-252), then the four sections
+  const uint64_t head[6] = {p->label.size(), pk_len, ck_len, SER_VK, n, p->constraints};
+  for (int k = 0; k < 6; ++k) { put_be64(w, head[k]); w += 8; }
+  memcpy(w, p->label.data(), p->label.size());
+  w += p->label.size();
+  // ---- ProverKey::to_var_bytes: n, evaluation size, 15 x (length, coefficients, 8n coset evaluations), linear, v_h
+  put_le64(w, n); put_le64(w + 8, eval_size);
+  w += 16;
+  DevFree ev, tmp;
+  HIP_TRY(hipMalloc(&ev.p, sizeof(Fr) * n8));
+  HIP_TRY(hipMalloc(&tmp.p, sizeof(Fr) * n8));
+  uint8_t dom[SER_DOMAIN];
+  put_domain(dom, L + 3);
+  auto put_evals = [&](const Fr* poly, uint64_t plen) -> int {   // Evaluations::to_var_bytes of coset_fft(poly) on 8n
+    memcpy(w, dom, SER_DOMAIN);
+    w += SER_DOMAIN;
+    if (plen) {
+      PTRY(ntt_device(c, poly, (Fr*)ev.p, (Fr*)tmp.p, L + 3, false, true, plen));
+      PTRY(poly_from_mont(c, (const Fr*)ev.p, (Fr*)ev.p, n8));
+      HIP_TRY(hipMemcpyAsync(w, ev.p, 32 * n8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+      memset(w, 0, 32 * n8);
+    }
+    w += 32 * n8;
+    return PLONK_OK;
+  };
+  for (int j = 0; j < P_COUNT; ++j) {
+    const int k = SER_ORDER[j];
+    const uint64_t plen = p->poly_len[k];
+    put_le64(w, plen);
+    w += 8;
+    if (plen) {   // Polynomial::to_var_bytes: the degree + 1 coefficients
+      PTRY(poly_from_mont(c, p->polys + k * np, (Fr*)tmp.p, plen));
+      HIP_TRY(hipMemcpyAsync(w, tmp.p, 32 * plen, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      w += 32 * plen;
+    }
+    PTRY(put_evals(p->polys + k * np, plen));
+  }
+  {   // permutation.linear_evaluations: X over the coset (compiler.rs:379-382)
+    const Fr lin[2] = {Fr::zero(), Fr::one()};
+    HIP_TRY(hipMemcpyAsync(p->scratch, lin, sizeof lin, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    PTRY(put_evals(p->scratch, 2));
+  }
+  {   // v_h_coset_8n: X^n - 1 over the coset takes 8 values (domain.rs:338-351)
+    memcpy(w, dom, SER_DOMAIN);
+    w += SER_DOMAIN;
+    uint8_t vh[8][32];
+    Fr point = fr_generator().pow_u64(n);
+    const Fr step = omega_of(L + 3).pow_u64(n);
+    for (int i = 0; i < 8; ++i) { put_scalar(vh[i], point - Fr::one()); point = point * step; }
+    for (uint64_t i = 0; i < n8; ++i) memcpy(w + 32 * i, vh[i & 7], 32);
+    w += 32 * n8;
+  }
+  // ---- CommitKey::to_raw_var_bytes (key.rs:215-229): count, then x || y || infinity flag per point
+  {
+    DevFree pts;
+    HIP_TRY(hipMalloc(&pts.p, sizeof(G1Affine) * (c->srs_n ? c->srs_n : 1)));
+    PTRY(srs_export_device(c, (G1Affine*)pts.p));
+    std::vector<uint8_t> xy(96 * (size_t)c->srs_n);
+    HIP_TRY(hipMemcpyAsync(xy.data(), pts.p, xy.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    put_le64(w, c->srs_n);
+    w += 8;
+    for (uint64_t i = 0; i < c->srs_n; ++i) {
+      memcpy(w, &xy[96 * i], 96);
+      w[96] = 0;
+      w += SER_RAW_POINT;
+    }
+  }
+  put_vk(w, p);
+  w += SER_VK;
+  if ((uint64_t)(w - out) != total) return (plonk::set_last_error("plonk_prover_to_bytes", "length accounting", __FILE__, __LINE__), PLONK_ERR_STATE);
+  return PLONK_OK;
+}
+
+int plonk_verifier_to_bytes(plonk_prover* pr, const uint8_t* opening_key, uint64_t opening_key_len, const uint64_t* pi_idx,
+                            uint64_t pi_count, uint8_t* out, uint64_t cap, uint64_t* len) {
+  if (!pr || !len || (opening_key_len && !opening_key) || (pi_count && !pi_idx)) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  plonk::Prover* p = pr->p;
+  const uint64_t total = 48 + p->label.size() + SER_VK + opening_key_len + 8 * pi_count;
+  *len = total;
+  if (!out) return PLONK_OK;
+  if (cap < total) return (plonk::set_last_error("invalid argument", "output buffer too small", __FILE__, __LINE__), PLONK_ERR_ARG);
+  uint8_t* w = out;
+  // Verifier::to_bytes (verifier.rs:88-117): six big-endian u64, label, VerifierKey, OpeningKey, big-endian indexes
+  const uint64_t head[6] = {p->label.size(), SER_VK, opening_key_len, pi_count, p->n, p->constraints};
+  for (int k = 0; k < 6; ++k) { put_be64(w, head[k]); w += 8; }
+  memcpy(w, p->label.data(), p->label.size());
+  w += p->label.size();
+  put_vk(w, p);
+  w += SER_VK;
+  if (opening_key_len) memcpy(w, opening_key, opening_key_len);
+  w += opening_key_len;
+  for (uint64_t i = 0; i < pi_count; ++i) { put_be64(w, pi_idx[i]); w += 8; }
+  return PLONK_OK;
+}
+
 int plonk_prover_prove_witnesses(plonk_prover* pr, const uint64_t* witnesses, uint64_t count, const uint64_t* pi_idx,
                                  const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
   if (!pr || !blinders || !proof || (count && !witnesses) || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);

@@ -145,3 +145,57 @@ def test_cached_lagrange_key_gives_the_same_prover(ctx):
     gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=bytes(bad))
     assert gp.prove(case["wires"], case["pi"], C.fr_vals(bl)) != want
     gp.close()
+
+
+def test_compiled_prover_serialises_like_the_reference(ctx, kat_setup):
+    """plonk_prover_to_bytes on the KAT circuit compiled by the device: byte for byte the blob the oracle's restatement
+    of Prover::to_bytes (oracle/serialize.py) writes for the oracle's Compiler::preprocess — its digest is the
+    literal of tests/test_prover_blob.py that tools/dump_kat_blob.rs pins to the reference — and
+    plonk_prover_from_bytes takes it back (the KAT proof digest again)."""
+    import plonk_amd
+    from oracle.serialize import prover_to_bytes
+    _, oprover, circuit = kat_setup
+    ctx.srs_load(oprover.ck)
+    gp, cols = compiled(ctx, circuit(), b"proof-compatibility")
+    blob = gp.to_bytes()
+    gp.close()
+    want = prover_to_bytes(oprover)
+    assert len(blob) == len(want) == 43966
+    assert blob == want
+    assert hashlib.blake2b(blob).hexdigest().startswith("959ac0e3ee3d8f14695fccf849c92c9e")
+    back = plonk_amd.Prover.from_bytes(ctx, blob)
+    rng = StdRng.seed_from_u64(0x9235E701)
+    blinders = [rng.random_scalar() for _ in range(14)]
+    wires = C.wires_of(circuit(), 8)
+    assert hashlib.blake2b(back.prove(wires, {}, blinders)).digest() == KAT_DIGEST
+    back.close()
+
+
+def test_serialised_prover_and_verifier_of_a_widget_circuit(ctx):
+    """A 200-gate circuit with every widget family: plonk_prover_to_bytes against the oracle serialiser fed with the
+    oracle's own compile (big-int interpolation, 8n coset evaluations, commitments); plonk_verifier_to_bytes against
+    the restated Verifier::to_bytes; both blobs survive a round trip."""
+    import plonk_amd
+    from oracle import plonk as O
+    from oracle.serialize import prover_to_bytes, verifier_to_bytes
+    comp = C.big_widget_circuit(200, seed=11)()
+    pp = O.srs_setup(300, StdRng.seed_from_u64(5), keep=256 + 7)
+    oprover = O.compile_circuit(pp, b"serialise", C.big_widget_circuit(200, seed=11)(), msm=E.msm_pippenger)
+    ctx.srs_load(oprover.ck)
+    gp, cols = compiled(ctx, comp, b"serialise")
+    blob = gp.to_bytes()
+    assert blob == prover_to_bytes(oprover)
+    info = plonk_amd.prover_blob_check(blob)
+    assert info["size"] == 256 and info["constraints"] == len(comp.constraints)
+    opening_key = bytes(range(240))                       # opaque to the library (G1 + 2 x G2 compressed)
+    pi_idx = sorted(comp.public_inputs)
+    vblob = gp.verifier_to_bytes(opening_key, pi_idx)
+    assert vblob == verifier_to_bytes(b"serialise", oprover.vk, opening_key, pi_idx, 256, len(comp.constraints))
+    bl = C.blinders(3)
+    want = gp.prove_witnesses(cols["values"], dict(comp.public_inputs), bl)
+    gp.close()
+    back = plonk_amd.Prover.from_bytes(ctx, blob)
+    case = C.compile_fast(comp, b"serialise")
+    assert back.prove(case["wires"], case["pi"], C.fr_vals(bl)) == want
+    assert back.to_bytes() == blob                        # and the loaded prover serialises to the same bytes
+    back.close()
