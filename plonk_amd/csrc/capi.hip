@@ -159,7 +159,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
     delete t;
   }
   (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_buf2); (void)hipFree(c.ntt_tmp);
-  if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream); (void)hipFree(c.srs_table);
+  if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream); (void)hipFree(c.srs_table); (void)hipFree(c.table_scratch);
   MsmWork& w = c.msm;
   (void)hipFree(w.tmp_words); (void)hipFree(w.entries); (void)hipFree(w.coarse_cnt); (void)hipFree(w.coarse_off); (void)hipFree(w.coarse_cur); (void)hipFree(w.big_off); (void)hipFree(w.big_cnt); (void)hipFree(w.nheavy); (void)hipFree(w.heavy_list); (void)hipFree(w.seg_sum);
   (void)hipFree(w.offsets); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
@@ -359,6 +359,7 @@ int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
   }
   if (e == hipSuccess && rc == PLONK_OK) e = hipStreamSynchronize(c.stream);
   cleanup();
+  srs_table_scratch_free(&c);
   if (e != hipSuccess) { set_last_error("plonk_srs_load", hipGetErrorString(e), __FILE__, __LINE__); rc = PLONK_ERR_HIP; }
   if (rc == PLONK_OK) c.srs_n = npoints;
   return rc;

@@ -109,26 +109,44 @@ __device__ __forceinline__ void st_g1r(G1RSlot* p, const G1R& v) {
 // ---------------------------------------------------------------------------
 // SRS tables
 // ---------------------------------------------------------------------------
-// T[w * n + i] = 2^(16 w) * P_i, affine, in the reduced-radix form (x, y < 2p).  One lane per
-// point; 16 doublings and one Fp inversion per window (one-off per Prover, outside every
-// timed region).
+// T[w * n + i] = 2^(16 w) * P_i, affine, in the reduced-radix form (x, y < 2p).  One lane per point: 15 x 16
+// doublings in XYZZ coordinates, and ONE Fp inversion for the 15 normalisations (Montgomery's trick along the lane's
+// own windows: the unnormalised X, Y wait in their table slots, ZZ, ZZZ and the running product of the ZZ * ZZZ in a
+// scratch array of 3 x 64 B per window and point; a Fermat inversion is ~570 products, as much as 60 doublings, and
+// one per window made the inversions 4/5 of this kernel).  One-off per commit key, outside every timed region.
 // `pts` holds points [first, first + count) of the key (a chunk of the stream in plonk_srs_load); the table
-// row of window w starts at w * n.
+// row of window w starts at w * n.  scratch: [(MSM_W - 1) * 3][count] slots.
+static constexpr uint64_t SRS_TABLE_CHUNK = 1ull << 18;   // points per launch: bounds the scratch at 720 MiB
 __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __restrict__ table, uint64_t n,
-                                 uint64_t first, uint64_t count) {
+                                 uint64_t first, uint64_t count, Fp28Slot* __restrict__ scratch) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   const uint64_t i = first + j;
   const G1Affine a = ld_aff(pts + j);
-  Fp28 x = Fp28::from_fp(a.x), y = Fp28::from_fp(a.y);
-  st_f28(&table[i].x, x);
-  st_f28(&table[i].y, y);
+  G1R p = G1R::from_affine(Fp28::from_fp(a.x), Fp28::from_fp(a.y));
+  st_f28(&table[i].x, p.X);
+  st_f28(&table[i].y, p.Y);
+  Fp28 run = Fp28::one();
   for (int w = 1; w < MSM_W; ++w) {
-    G1R p = G1R::dbl_affine(x, y);
-    for (int k = 1; k < MSM_C; ++k) p = p.dbl();
-    g1r_to_affine(p, &x, &y);   // P_i has prime order: never the identity
-    st_f28(&table[(uint64_t)w * n + i].x, x);
-    st_f28(&table[(uint64_t)w * n + i].y, y);
+    for (int k = 0; k < MSM_C; ++k) p = p.dbl();          // P_i has prime order: never the identity
+    Fp28Slot* sc = scratch + (uint64_t)(w - 1) * 3 * count + j;
+    st_f28(&table[(uint64_t)w * n + i].x, p.X.normalized());
+    st_f28(&table[(uint64_t)w * n + i].y, p.Y.normalized());
+    st_f28(sc, p.ZZ);
+    st_f28(sc + count, p.ZZZ);
+    run = Fp28::mul(run, Fp28::mul(p.ZZ, p.ZZZ));
+    st_f28(sc + 2 * count, run);
+  }
+  Fp28 inv = fp28_inv(run);                                // 1 / prod_w ZZ_w ZZZ_w
+  for (int w = MSM_W - 1; w >= 1; --w) {
+    const Fp28Slot* sc = scratch + (uint64_t)(w - 1) * 3 * count + j;
+    const Fp28 zz = ld_f28(sc), zzz = ld_f28(sc + count);
+    const Fp28 before = w > 1 ? ld_f28(sc - 3 * count + 2 * count) : Fp28::one();   // running product up to w - 1
+    const Fp28 iw = Fp28::mul(inv, before);                // 1 / (ZZ_w ZZZ_w)
+    inv = Fp28::mul(inv, Fp28::mul(zz, zzz));
+    G1AffineR* e = &table[(uint64_t)w * n + i];
+    st_f28(&e->x, Fp28::mul(ld_f28(&e->x), Fp28::mul(iw, zzz)));   // X / ZZ
+    st_f28(&e->y, Fp28::mul(ld_f28(&e->y), Fp28::mul(iw, zz)));    // Y / ZZZ
   }
 }
 
@@ -497,12 +515,35 @@ int srs_table_begin(Ctx* c, uint64_t n) {
   HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)MSM_W * n));
   return PLONK_OK;
 }
-// table entries of points [first, first + count), read from pts_dev[0 .. count), on `st`
+// scratch of srs_table_kernel, kept on the context between the chunks of one load
+static int srs_table_scratch(Ctx* c, uint64_t count) {
+  if (c->table_scratch_pts >= count) return PLONK_OK;
+  if (c->table_scratch) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->table_scratch)); c->table_scratch = nullptr; c->table_scratch_pts = 0; }
+  HIP_TRY(hipMalloc(&c->table_scratch, sizeof(Fp28Slot) * 3 * (MSM_W - 1) * count));
+  c->table_scratch_pts = count;
+  return PLONK_OK;
+}
+void srs_table_scratch_free(Ctx* c) {   // after the stream that ran the table kernels was synchronised
+  if (c->table_scratch) (void)hipFree(c->table_scratch);
+  c->table_scratch = nullptr;
+  c->table_scratch_pts = 0;
+}
+// table entries of points [first, first + count), read from pts_dev[0 .. count), on `st` (always the context's main
+// stream: the launches share one scratch array and rely on stream order)
+static int srs_table_launch(Ctx* c, const G1Affine* pts_dev, G1AffineR* table, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
+  for (uint64_t off = 0; off < count; off += SRS_TABLE_CHUNK) {
+    const uint64_t cnt = count - off < SRS_TABLE_CHUNK ? count - off : SRS_TABLE_CHUNK;
+    const int rc = srs_table_scratch(c, cnt);
+    if (rc) return rc;
+    hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, st, pts_dev + off, table, n, first + off, cnt,
+                       (Fp28Slot*)c->table_scratch);
+    HIP_TRY(hipGetLastError());
+  }
+  return PLONK_OK;
+}
 int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
   if (!count) return PLONK_OK;
-  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, st, pts_dev, (G1AffineR*)c->srs_table, n, first, count);
-  HIP_TRY(hipGetLastError());
-  return PLONK_OK;
+  return srs_table_launch(c, pts_dev, (G1AffineR*)c->srs_table, n, first, count, st);
 }
 int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out) {
   *table_out = nullptr;
@@ -510,8 +551,10 @@ int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_ou
   if ((uint64_t)MSM_W * n > (1ull << 27)) return (plonk::set_last_error("invalid argument", "window tables: MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
   G1AffineR* t = nullptr;
   HIP_TRY(hipMalloc((void**)&t, sizeof(G1AffineR) * (size_t)MSM_W * n));
-  hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, c->stream, pts_dev, t, n, (uint64_t)0, n);
-  if (hipGetLastError() != hipSuccess) { (void)hipFree(t); return PLONK_ERR_HIP; }
+  int rc = srs_table_launch(c, pts_dev, t, n, 0, n, c->stream);
+  if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  srs_table_scratch_free(c);
+  if (rc) { (void)hipFree(t); return rc; }
   *table_out = t;
   return PLONK_OK;
 }
@@ -605,8 +648,9 @@ int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n) {
   int rc = srs_table_begin(c, n);
   if (rc || n == 0) return rc;
   rc = srs_table_chunk(c, pts_dev, n, 0, n, c->stream);
+  if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+  srs_table_scratch_free(c);
   if (rc) return rc;
-  HIP_TRY(hipStreamSynchronize(c->stream));
   c->srs_n = n;
   return PLONK_OK;
 }

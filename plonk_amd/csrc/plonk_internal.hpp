@@ -104,6 +104,8 @@ struct Ctx {
   uint64_t ntt_cap = 0;
   // SRS
   void* srs_table = nullptr;       // [MSM_W][npoints] 128-B affine entries (Fp28), 2^(16 w) * P_i
+  void* table_scratch = nullptr;   // srs_table_kernel's per-window ZZ / ZZZ / running products, alive during a key load
+  uint64_t table_scratch_pts = 0;
   uint64_t srs_n = 0;
   uint64_t srs_gen = 0;            // bumped by every (re)load: provers remember the generation they were built on
   MsmWork msm;
@@ -151,6 +153,7 @@ int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* rec
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);
 int srs_table_begin(Ctx* c, uint64_t n);
 int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first, uint64_t count, hipStream_t st);
+void srs_table_scratch_free(Ctx* c);   // once the stream that built the tables was synchronised
 int srs_validate_device(Ctx* c, const G1Affine* pts_dev, uint64_t n, int* flag_dev);
 int srs_export_device(Ctx* c, G1Affine* out_dev);   // the context's commit key (srs_n points) as x || y Montgomery limbs
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
