@@ -489,6 +489,127 @@ __global__ void __launch_bounds__(128) msm_bits_kernel(MsmBatch bt, const G1RSlo
   if (t == 0) st_g1(out, acc.to_g1());
 }
 
+// ---- quad-cooperative tail (round 3) -----------------------------------------------------------
+// The row/column and bit-sum kernels are chains of DEPENDENT full additions (12 products + 2 squarings,
+// ~7.6 k instructions each) on a chip that is mostly idle while they run.  The 14 products of an
+// addition form four levels of mutually independent products:
+//     U1 U2 S1 S2 | P^2 R^2 ZZ1*ZZ2 ZZZ1*ZZZ2 | P*PP U1*PP ZZ12*PP ZZZ12*P | R*(Q-X3) PPP*(-S1) T*PP
+// so the four lanes of a quad hold the SAME two points, each lane computes ONE product per level, and the
+// results are exchanged with DPP quad broadcasts (one v_mov_dpp per limb): 4 products + ~0.6 k
+// instructions of selects / exchanges instead of 14 products per addition — the latency of an addition drops
+// ~2.8x, at 1.6x the issue slots, which these kernels have to spare.  A "logical lane" is a quad; control flow is
+// uniform inside a quad by construction (replicated operands), which the DPP reads rely on.
+template <int K>
+__device__ __forceinline__ Fp28 quad_get(const Fp28& v) {   // lane K of the quad -> all four lanes
+  Fp28 r;
+#pragma unroll
+  for (int i = 0; i < Fp28::N; ++i)
+    r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], K * 0x55, 0xf, 0xf, true);
+  return r;
+}
+__device__ __forceinline__ Fp28 quad_sel(uint32_t q, const Fp28& a0, const Fp28& a1, const Fp28& a2, const Fp28& a3) {
+  // bit masks, not ?: — the compiler turns a four-way conditional over arrays into a pointer select with the
+  // operands parked in scratch memory, which is the last thing a latency-bound chain needs
+  const uint32_t k0 = 0u - (uint32_t)(q == 0), k1 = 0u - (uint32_t)(q == 1), k2 = 0u - (uint32_t)(q == 2), k3 = 0u - (uint32_t)(q == 3);
+  Fp28 r;
+#pragma unroll
+  for (int i = 0; i < Fp28::N; ++i) r.l[i] = (a0.l[i] & k0) | (a1.l[i] & k1) | (a2.l[i] & k2) | (a3.l[i] & k3);
+  return r;
+}
+// a + b, both replicated over the quad; q = lane & 3.  Same bounds as G1R::add (Y3 < 4p here: two reductions
+// instead of the fused one, inside the Y < 8p contract).
+__device__ __forceinline__ G1R g1r_add_quad(const G1R& a, const G1R& b, uint32_t q) {
+  if (a.is_identity()) return b;
+  if (b.is_identity()) return a;
+  const Fp28 m1 = Fp28::mul(quad_sel(q, a.X, b.X, a.Y, b.Y), quad_sel(q, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ));
+  const Fp28 U1 = quad_get<0>(m1), U2 = quad_get<1>(m1), S1 = quad_get<2>(m1), S2 = quad_get<3>(m1);   // < 2p
+  const Fp28 P_ = Fp28::sub_lazy<4>(U2, U1);                // < 6p, lazy limbs
+  const Fp28 R_ = Fp28::sub<4>(S2, S1);                     // < 6p, normalised
+  if (G1R::maybe_zero(P_) && P_.normalized().is_zero_mod()) {
+    // equal or opposite points (never for independent bucket sums; small or repeated bases reach it): every lane of the
+    // quad doubles on its own.  Inlined — an out-of-line call would pin both points in scratch memory on the hot path.
+    return R_.is_zero_mod() ? a.dbl() : G1R::identity();
+  }
+  const Fp28 m2 = Fp28::mul(quad_sel(q, P_, R_, a.ZZ, a.ZZZ), quad_sel(q, P_, R_, b.ZZ, b.ZZZ));   // 6*6, 2*2 -> < 2p
+  const Fp28 PP = quad_get<0>(m2), RR = quad_get<1>(m2), ZZ12 = quad_get<2>(m2), ZZZ12 = quad_get<3>(m2);
+  const Fp28 m3 = Fp28::mul(quad_sel(q, P_, U1, ZZ12, ZZZ12), quad_sel(q, PP, PP, PP, P_));           // 6*2, 2*2 -> < 2p
+  const Fp28 PPP = quad_get<0>(m3), Q_ = quad_get<1>(m3), T_ = quad_get<3>(m3);
+  G1R r;
+  r.ZZ = quad_get<2>(m3);
+  r.X = Fp28::sub<8>(Fp28::sub_lazy<4>(RR, PPP), Fp28::add_lazy(Q_, Q_));                             // < 14p
+  const Fp28 m4 = Fp28::mul(quad_sel(q, R_, PPP, T_, T_),                                              // 6*34, 2*4, 2*2 -> < 2p
+                            quad_sel(q, Fp28::sub_lazy<32>(Q_, r.X), Fp28::neg_lazy<4>(S1), PP, PP));
+  r.Y = Fp28::add(quad_get<0>(m4), quad_get<1>(m4));                                                   // < 4p
+  r.ZZZ = quad_get<2>(m4);
+  return r;
+}
+
+// Row sums R_h (256) and HALF-column sums C'_{half,l} (2 x 128; C_l = C'_{0,l} + C'_{1,l}): 512 sums of 128 buckets each,
+// so that every sum has the same depth.  WV waves per sum = 16 WV logical lanes: a logical lane adds 128 / (16 WV)
+// buckets serially, then a log2(16 WV)-step LDS tree.  WV is chosen so that one launch fits the chip's wave slots.
+static constexpr uint32_t RCQ_SUMS = RC_ROWS + 2 * RC_COLS;
+template <int WV>
+__global__ void __launch_bounds__(64 * WV) msm_rowcol_quad_kernel(const G1RSlot* __restrict__ buckets_all,
+                                                                  G1RSlot* __restrict__ rc_all) {
+  constexpr uint32_t LL = 16 * WV;
+  __shared__ G1R sh[LL];
+  const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
+  G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * RCQ_SUMS;
+  const uint32_t t = threadIdx.x, q = t & 3, L = t >> 2;
+  const uint32_t sum = blockIdx.x;
+  const G1RSlot* base;
+  uint64_t stride;
+  if (sum < RC_ROWS) {               // R_h: the 128 buckets of row h
+    base = buckets + (uint64_t)sum * RC_COLS;
+    stride = 1;
+  } else {                           // C'_{half,l}: rows 128 half .. 128 half + 127 of column l
+    const uint32_t cidx = sum - RC_ROWS, half = cidx / RC_COLS, l = cidx % RC_COLS;
+    base = buckets + (uint64_t)half * (RC_ROWS / 2) * RC_COLS + l;
+    stride = RC_COLS;
+  }
+  G1R acc = ld_g1r(base + (uint64_t)L * stride);
+  for (uint32_t k = L + LL; k < 128; k += LL) acc = g1r_add_quad(acc, ld_g1r(base + (uint64_t)k * stride), q);
+  for (uint32_t d = LL / 2; d >= 1; d >>= 1) {
+    if (q == 0) sh[L] = acc;
+    __syncthreads();
+    if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
+    __syncthreads();
+  }
+  if (t == 0) st_g1r(rc + sum, acc);
+}
+
+// The 16 bit sums of msm_bits_kernel from the 512 sums above: every bit sum is a plain sum of <= 128 points
+// (rows with bit j set; both halves of the 64 columns whose weight has bit j set; the two halves of column 128).
+// 64 logical lanes, two points each, a 6-step tree: depth 7.
+__global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G1RSlot* __restrict__ rc_all) {
+  __shared__ G1R sh[64];
+  const G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * RCQ_SUMS;
+  G1* __restrict__ out = bt.out[blockIdx.y] + blockIdx.x;
+  const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
+  G1R acc = G1R::identity();
+  for (uint32_t i = L; i < 128; i += 64) {
+    G1R p = G1R::identity();
+    if (u < 8) {                       // 128 of the 256 rows
+      const uint32_t h = ((i >> u) << (u + 1)) | (1u << u) | (i & ((1u << u) - 1u));
+      p = ld_g1r(rc + h);
+    } else if (u < 15) {               // 64 of the column weights 1..127, both halves
+      const uint32_t j = u - 8, half = i >> 6, tt = i & 63;
+      const uint32_t l = ((tt >> j) << (j + 1)) | (1u << j) | (tt & ((1u << j) - 1u));
+      p = ld_g1r(rc + RC_ROWS + half * RC_COLS + (l - 1));
+    } else if (i < 2) {                // weight 128
+      p = ld_g1r(rc + RC_ROWS + i * RC_COLS + (RC_COLS - 1));
+    }
+    acc = g1r_add_quad(acc, p, q);
+  }
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
+    if (q == 0) sh[L] = acc;
+    __syncthreads();
+    if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
+    __syncthreads();
+  }
+  if (t == 0) st_g1(out, acc.to_g1());
+}
+
 __global__ void xyzz_to_affine97_kernel(const G1* __restrict__ in, uint8_t* __restrict__ out97) {
   if (threadIdx.x != 0) return;
   G1Affine a;
@@ -691,7 +812,7 @@ int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G
 // MSM still spreads over ~2^19 lanes instead of leaving most SIMDs idle behind 32 serial additions.
 static uint32_t msm_ksl(uint64_t m) {
   static const int forced = [] { const char* e = getenv("PLONK_MSM_KSL"); return e ? atoi(e) : 0; }();   // tuning experiments only
-  if (forced == 4 || forced == 8 || forced == 16 || forced == 32) return (uint32_t)forced;
+  if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64 || forced == 128) return (uint32_t)forced;
   uint32_t r = 4;
   while (r < MSM_KSL && (uint64_t)r * MSM_NB < m) r *= 2;   // smallest power of two >= m / 2^15, clamped to [4, 32]
   return r;
@@ -805,6 +926,18 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
                      w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
   hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
                      (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
+  // PLONK_MSM_TAIL=serial: one lane per addition in the row/column and bit-sum kernels (A/B, fallback)
+  static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
+  if (bit_sums && tail_quad) {
+    // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
+    if (count >= 3) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    else if (count == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    else hipLaunchKernelGGL(msm_rowcol_quad_kernel<4>, dim3(RCQ_SUMS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(MSM_BIT_SUMS, count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk);
+    prof_end(c, 2);
+    HIP_TRY(hipGetLastError());
+    return PLONK_OK;
+  }
   hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);
   if (bit_sums) {
