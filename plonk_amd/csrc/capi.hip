@@ -448,13 +448,15 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
   rc = ensure_scalar_staging(&c, m ? m : 1);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c.msm.scalars_stage, scalars, sizeof(Fr) * m, hipMemcpyHostToDevice, c.stream));
-  rc = msm_device(&c, c.msm.scalars_stage, m, (G1*)c.msm.result);
+  // same tail as plonk_msm_batch: the 16 bit sums come back and the host finishes (15-term Horner chain + one Fp
+  // inversion) — ~25 dependent additions and a Fermat inversion that a single GPU lane would otherwise serialise
+  const Fr* sc = c.msm.scalars_stage;
+  G1* res = (G1*)c.msm.result;
+  rc = msm_batch_device(&c, &sc, &m, 1, &res, true);
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, sizeof(G1), hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, sizeof(G1) * MSM_BIT_SUMS, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
-  G1 r;
-  memcpy(&r, c.msm.result_host, sizeof(G1));
-  xyzz_to_affine97_host(r, out_xy_inf);   // one Fp inversion on the host instead of a serial GPU lane
+  xyzz_to_affine97_host(finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host)), out_xy_inf);
   return PLONK_OK;
 }
 

@@ -610,6 +610,72 @@ __global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G
   if (t == 0) st_g1(out, acc.to_g1());
 }
 
+// Heavy buckets (skewed digits) with quad additions: a 256-slice segment per WORKGROUP of 64 logical lanes (four
+// slices each, then a 6-step tree), and the segment sums of one bucket per workgroup.  The list of heavy buckets is
+// short and these kernels are chains of dependent additions like the two above.
+__global__ void __launch_bounds__(256) msm_heavy_seg_quad_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
+                                                                 const uint32_t* __restrict__ slice_off_all,
+                                                                 const uint32_t* __restrict__ nheavy_all,
+                                                                 const HeavyItem* __restrict__ heavy_list_all,
+                                                                 G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap) {
+  const int kb = blockIdx.y;
+  const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
+  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
+  const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
+  G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
+  __shared__ G1R sh[64];
+  __shared__ uint32_t found[2];
+  const uint32_t t = threadIdx.x, q = t & 3, L = t >> 2;
+  const uint32_t nitems = nheavy_all[2 * kb], nsegs = nheavy_all[2 * kb + 1];
+  for (uint32_t sg = blockIdx.x; sg < nsegs; sg += gridDim.x) {
+    for (uint32_t i = t; i < nitems; i += 256) {   // which item owns segment sg
+      const HeavyItem it = list[i];
+      if (sg >= it.seg_base && sg < it.seg_base + it.nseg) { found[0] = it.bucket; found[1] = sg - it.seg_base; }
+    }
+    __syncthreads();
+    const uint32_t b = found[0], j = found[1];
+    const uint32_t beg = slice_off[b] + j * HEAVY_SEG, bend = slice_off[b + 1];
+    G1R acc = G1R::identity();
+    for (uint32_t r = 0; r < HEAVY_SEG / 64; ++r) {
+      const uint32_t k = beg + L + 64 * r;
+      if (k < bend) acc = g1r_add_quad(acc, ld_g1r(partial + k), q);
+    }
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+      if (q == 0) sh[L] = acc;
+      __syncthreads();
+      if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
+      __syncthreads();
+    }
+    if (t == 0) st_g1r(seg_sum + sg, acc);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) msm_heavy_bucket_quad_kernel(const uint32_t* __restrict__ nheavy_all,
+                                                                    const HeavyItem* __restrict__ heavy_list_all,
+                                                                    const G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap,
+                                                                    G1RSlot* __restrict__ buckets_all) {
+  const int kb = blockIdx.y;
+  const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
+  const G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
+  G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
+  __shared__ G1R sh[64];
+  const uint32_t t = threadIdx.x, q = t & 3, L = t >> 2;
+  const uint32_t nitems = nheavy_all[2 * kb];
+  for (uint32_t i = blockIdx.x; i < nitems; i += gridDim.x) {
+    const HeavyItem it = list[i];
+    G1R acc = G1R::identity();
+    for (uint32_t k = L; k < it.nseg; k += 64) acc = g1r_add_quad(acc, ld_g1r(seg_sum + it.seg_base + k), q);
+    for (uint32_t d = 32; d >= 1; d >>= 1) {
+      if (q == 0) sh[L] = acc;
+      __syncthreads();
+      if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
+      __syncthreads();
+    }
+    if (t == 0) st_g1r(buckets + it.bucket, acc);
+    __syncthreads();
+  }
+}
+
 __global__ void xyzz_to_affine97_kernel(const G1* __restrict__ in, uint8_t* __restrict__ out97) {
   if (threadIdx.x != 0) return;
   G1Affine a;
@@ -922,12 +988,19 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     else BSUM(8);
 #undef BSUM
   }
-  hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(4 * HEAVY_WGS, count), dim3(64), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
-                     w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
-  hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
-                     (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
-  // PLONK_MSM_TAIL=serial: one lane per addition in the row/column and bit-sum kernels (A/B, fallback)
+  // PLONK_MSM_TAIL=serial: one lane per addition in the heavy-bucket, row/column and bit-sum kernels (A/B, fallback)
   static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
+  if (tail_quad) {
+    hipLaunchKernelGGL(msm_heavy_seg_quad_kernel, dim3(HEAVY_WGS, count), dim3(256), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
+                       w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
+    hipLaunchKernelGGL(msm_heavy_bucket_quad_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
+                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
+  } else {
+    hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(4 * HEAVY_WGS, count), dim3(64), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
+                       w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
+    hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
+                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
+  }
   if (bit_sums && tail_quad) {
     // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
     if (count >= 3) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
