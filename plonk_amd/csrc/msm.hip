@@ -264,6 +264,118 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   st_g1r(partial + s, acc);
 }
 
+// Occupancy experiment (PLONK_MSM_ACC=lds), kept as the measured answer to "would a third wave per SIMD help?":
+// same slices, same additions, THREE waves per SIMD instead of two — and the same time per proof as the kernel above
+// (same-box A/B at 2^20: 26.59 / 26.84 ms against 26.84 / 26.93 ms), i.e. msm_accumulate is bound by the number of
+// VALU instructions issued, not by latency hiding.  The register-prefetch kernel above needs 216 VGPRs (accumulator 56, current + prefetched table entry 56, P, R, PP,
+// PPP, Q 70, a 28-register column accumulator), i.e. two waves per SIMD, where a wave-instruction issues every 4.9
+// cycles; at three waves the interval is ~4.6 and at four 4.4 (profiles/r01/valu_issue_rates_gfx950.txt).  Forcing
+// 168 registers on that kernel spills 49 of them.  Here (i) the table entry of step k+1 is fetched straight into LDS
+// (global_load_lds_dwordx4: no VGPR is held while the gather is in flight; one wave-private 8 KiB slot, chunk j of
+// lane L at 1024 j + 16 L, refilled as soon as step k has read it), (ii) the entry words run two steps ahead so that
+// the refill never waits for its address, and (iii) the addition is written in the order that keeps the live set
+// small (ZZ3 as soon as PP exists, P dead after PPP, X after Q): 167 VGPRs, no scratch, 18 KiB of LDS per workgroup.
+typedef __attribute__((address_space(1))) const void* acc_gptr_t;
+typedef __attribute__((address_space(3))) void* acc_lptr_t;
+__device__ __forceinline__ void acc_prefetch_entry(const G1AffineR* e, uint8_t* wave_slot) {
+  const uint8_t* g = reinterpret_cast<const uint8_t*>(e);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    __builtin_amdgcn_global_load_lds((acc_gptr_t)(g + 16 * j), (acc_lptr_t)(wave_slot + 1024 * j), 16, 0, 0);
+}
+__device__ __forceinline__ Fp28 acc_read_coord(const uint8_t* wave_slot, uint32_t lane, int coord /*0: x, 1: y*/) {
+  const uint4* q = reinterpret_cast<const uint4*>(wave_slot + 16 * lane) + 256 * coord;
+  const uint4 a = q[0], b = q[64], c = q[128], d = q[192];
+  Fp28 r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+  r.l[12] = d.x; r.l[13] = d.y;
+  return r;
+}
+__device__ __forceinline__ Fp28 acc_signed_y(const Fp28& y, bool neg) {   // -y as 4p - y, lazy limbs
+  Fp28 r;
+#pragma unroll
+  for (int i = 0; i < Fp28::N; ++i) r.l[i] = neg ? Fp28::pad<4>(i) - y.l[i] : y.l[i];
+  return r;
+}
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3)))
+msm_accumulate_lds_kernel(const G1AffineR* __restrict__ table, MsmBatch bt, const uint32_t* __restrict__ entries_all,
+                          const uint32_t* __restrict__ offsets_all, const uint32_t* __restrict__ slice_off_all,
+                          G1RSlot* __restrict__ partial_all) {
+  const int kb = blockIdx.y;
+  const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
+  G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nslices = slice_off[MSM_NB];
+  __shared__ uint32_t coarse[MSM_NB / 64];                          // every 64th slice offset (bucket search, see above)
+  __shared__ __attribute__((aligned(16))) uint8_t slot[2][8192];    // one table-entry slot per wave
+  for (uint32_t j = threadIdx.x; j < MSM_NB / 64; j += blockDim.x) coarse[j] = slice_off[j * 64];
+  __syncthreads();
+  if (s >= nslices) return;
+  uint8_t* wave_slot = slot[threadIdx.x >> 6];
+  const uint32_t lane = threadIdx.x & 63;
+  uint32_t lo = 0, hi = MSM_NB / 64 - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (coarse[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  lo *= 64;
+  hi = lo + 63;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (slice_off[mid] <= s) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t b = lo;
+  const uint32_t beg = offsets[b] + (s - slice_off[b]) * bt.ksl;
+  uint32_t end = beg + bt.ksl;
+  const uint32_t bend = offsets[b + 1];
+  if (end > bend) end = bend;
+  G1R acc = G1R::identity();
+  uint32_t e_cur = beg < end ? entries[beg] : 0;
+  uint32_t e_nxt = beg + 1 < end ? entries[beg + 1] : 0;
+  if (beg < end) acc_prefetch_entry(&table[e_cur & 0x7fffffffu], wave_slot);
+  for (uint32_t k = beg; k < end; ++k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the slot holds entry k (and e_nxt has arrived)
+    const uint32_t ent_c = e_cur;
+    const bool neg = ent_c & 0x80000000u;
+    if (acc.is_identity()) {   // first entry of the slice (or the step after a cancellation)
+      const Fp28 x2 = acc_read_coord(wave_slot, lane, 0);
+      const Fp28 y2 = acc_signed_y(acc_read_coord(wave_slot, lane, 1), neg);
+      acc = G1R::from_affine(x2, y2.normalized());
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot has been read before it is refilled
+      if (k + 1 < end) acc_prefetch_entry(&table[e_nxt & 0x7fffffffu], wave_slot);
+      e_cur = e_nxt;
+      if (k + 2 < end) e_nxt = entries[k + 2];
+      continue;
+    }
+    // G1R::add_affine (curve28.cuh) with the operands taken from the slot where they are needed; bounds as there
+    const Fp28 P_ = Fp28::sub_lazy<32>(Fp28::mul(acc_read_coord(wave_slot, lane, 0), acc.ZZ), acc.X);   // U2 - X  < 34p, lazy
+    const Fp28 R_ = Fp28::sub<16>(Fp28::mul(acc_signed_y(acc_read_coord(wave_slot, lane, 1), neg), acc.ZZZ), acc.Y);   // S2 - Y < 18p
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (k + 1 < end) acc_prefetch_entry(&table[e_nxt & 0x7fffffffu], wave_slot);
+    e_cur = e_nxt;
+    if (k + 2 < end) e_nxt = entries[k + 2];
+    if (G1R::maybe_zero(P_) && P_.normalized().is_zero_mod()) {   // same x as the accumulator: double or cancel (rare)
+      const G1AffineR* e = &table[ent_c & 0x7fffffffu];             // the slot is being refilled: gather the entry again
+      acc = R_.is_zero_mod() ? G1R::dbl_affine(ld_f28(&e->x), acc_signed_y(ld_f28(&e->y), neg).normalized()) : G1R::identity();
+      continue;
+    }
+    const Fp28 PP = P_.sqr();                                 // 34*34 = 1156      -> < 2p
+    acc.ZZ = Fp28::mul(acc.ZZ, PP);                           // < 2p
+    const Fp28 PPP = Fp28::mul(P_, PP);                       // 34*2              -> < 2p
+    const Fp28 Q_ = Fp28::mul(acc.X, PP);                     // 16*2              -> < 2p
+    acc.ZZZ = Fp28::mul(acc.ZZZ, PPP);                        // < 2p
+    acc.X = Fp28::sub<8>(Fp28::sub_lazy<4>(R_.sqr(), PPP),    // 18*18=324; 2p + 4p
+                         Fp28::add_lazy(Q_, Q_));             // - (<4p) + 8p      -> < 14p
+    acc.Y = Fp28::mul2(R_, Fp28::sub_lazy<32>(Q_, acc.X),     // 18 * (2+32=34) = 612
+                       PPP, Fp28::neg_lazy<16>(acc.Y));       // + 2 * 16 = 644    -> < 2p
+  }
+  st_g1r(partial + s, acc);
+}
+
 // bucket[b] = sum of its slice partials.  Uniform scalars give ~16 slices per bucket: two lanes
 // per bucket (strided partial sums + one LDS step) keep the SIMDs busy without idling lanes in a
 // deep tree.  Lanes per bucket follow the expected slice count: 1 (sparse), 2 (m ~ 2^20: 16 slices), 4, 8 (m >= 2^22).
@@ -971,8 +1083,15 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   // upper bound on slices known on the host: no device->host sync on the path
   const uint64_t max_slices = (MSM_W * mmax) / bt.ksl + MSM_NB + 1;
   prof_begin(c, 1);
-  hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
-                     (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
+  // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
+  // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
+  static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
+  if (acc_lds)
+    hipLaunchKernelGGL(msm_accumulate_lds_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
+                       (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
+  else
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
+                       (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
   prof_begin(c, 2);
   {
