@@ -1093,6 +1093,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
                        (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   prof_end(c, 1);
+  if (c->acc_done) HIP_TRY(hipEventRecord(c->acc_done, st));
   prof_begin(c, 2);
   {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits

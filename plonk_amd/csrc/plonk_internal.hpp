@@ -92,6 +92,7 @@ struct Ctx {
   hipStream_t stream = nullptr;    // every launch goes to this stream (prover.hip swaps it for side work)
   hipStream_t main_stream = nullptr;
   hipStream_t side_stream = nullptr;   // low priority: challenge-independent NTTs overlapped with MSM phases
+  hipEvent_t acc_done = nullptr;       // when set: recorded by msm_batch_device right after its msm_accumulate launch (prover.hip gates side work on it)
   std::mutex mu;         // serialises entry points (reference calls concurrently from rayon)
   std::mutex table_mu;
   std::map<uint32_t, NttTables*> ntt_tables;

@@ -57,6 +57,7 @@ struct Prover {
   Fr* tmp8 = nullptr;              // [n8] NTT scratch (main stream)
   Fr* tmp8b = nullptr;             // [n8] NTT scratch (side stream)
   hipEvent_t ev_ready = nullptr, ev_side = nullptr;
+  hipEvent_t ev_acc = nullptr;   // end of a commitment group's msm_accumulate (deferred side work starts there)
   hipEvent_t ev_wire[4] = {nullptr, nullptr, nullptr, nullptr};   // host-wire uploads in flight on the copy stream (plonk_prover_prove)
   bool wires_pending = false;
   Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
@@ -142,6 +143,22 @@ struct SideScope {
   }
   ~SideScope() { c->stream = c->main_stream; }
 };
+// Side work that must not start before an event ALREADY recorded on the main stream (the end of a group's
+// msm_accumulate): the transforms then fill the latency-bound tail of the group and the host synchronisation instead
+// of competing with the bandwidth-bound sort and the VALU-bound accumulation.
+struct SideScopeAfter {
+  Ctx* c;
+  SideScopeAfter(Ctx* ctx, hipEvent_t recorded) : c(ctx) {
+    (void)hipStreamWaitEvent(c->side_stream, recorded, 0);
+    c->stream = c->side_stream;
+  }
+  ~SideScopeAfter() { c->stream = c->main_stream; }
+};
+struct AccMark {   // msm_batch_device records `ev` after its accumulate launch while this is alive
+  Ctx* c;
+  AccMark(Ctx* ctx, hipEvent_t ev) : c(ctx) { c->acc_done = ev; }
+  ~AccMark() { c->acc_done = nullptr; }
+};
 struct SideJoin {   // never leave side work in flight when prove() returns (buffers are reused)
   Ctx* c;
   ~SideJoin() { (void)hipStreamSynchronize(c->side_stream); }
@@ -213,6 +230,7 @@ static void prover_free(Prover* p) {
   for (int k = 0; k < 8; ++k) { ntt_coset_free(&p->cs_fwd[k]); ntt_coset_free(&p->cs_inv[k]); }
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
+  if (p->ev_acc) (void)hipEventDestroy(p->ev_acc);
   if (p->ev_pi) (void)hipEventDestroy(p->ev_pi);
   for (int k = 0; k < 4; ++k) if (p->ev_wire[k]) (void)hipEventDestroy(p->ev_wire[k]);
   if (p->low_host) (void)hipHostFree(p->low_host);
@@ -394,6 +412,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
 #undef ALLOC
   HIP_TRY(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_acc, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_pi, hipEventDisableTiming));
   for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&p->ev_wire[k], hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&p->low_host, 42 * sizeof(Fr), hipHostMallocDefault));
@@ -691,11 +710,16 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   }
   SideJoin side_join{c};
   uint64_t pi_len = 0;
-  {
+  // Side transforms either start with the group (they then compete with its bandwidth-bound sort) or wait for the end of
+  // its accumulation and fill the latency-bound tail.  Same-box A/B (r02e): waiting wins up to 2^18 gates (2^16: 5.19 vs
+  // 5.33 ms) and on the widget workload (38.1 vs 38.5 ms) but loses on the dense 2^20 headline (37.2-37.4 vs 36.6-36.8 ms:
+  // z's transform no longer fits between its commitment and the quotient), so it follows the size.  PLONK_SIDE_DEFER=0/1 forces it.
+  static const int side_defer_env = [] { const char* e = getenv("PLONK_SIDE_DEFER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool side_defer = side_defer_env >= 0 ? side_defer_env == 1 : L <= 18;
+  auto side_round1 = [&]() -> int {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
-    // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments below; with the
+    // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments; with the
     // Lagrange key the wire polynomials themselves are only needed from round 3 on and move there too
-    SideScope side(c, p->ev_ready);
     if (polys_on_side) PTRY(wire_polynomials(p->tmp8b));
     for (int k = 0; k < 4; ++k)
       PTRY(ntt_device(c, p->wpoly + k * np, p->cos + (1 + k) * n8, p->tmp8b, L + p->lq, false, true, n + 2));
@@ -707,8 +731,14 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     HIP_TRY(hipMemcpyAsync(p->low_host + 35, p->pipoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(p->ev_pi, c->stream));
     if (pi_len) PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + p->lq, false, true, pi_len));   // no public inputs: PI(X) = 0, nothing to transform or read
+    return PLONK_OK;
+  };
+  if (!side_defer) {
+    SideScope side(c, p->ev_ready);
+    PTRY(side_round1());
   }
   {
+    AccMark mark(c, side_defer ? p->ev_acc : nullptr);
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
     if (lag) {
       const Fr* sc[4] = {wires_dev, wires_dev + n, wires_dev + 2 * n, wires_dev + 3 * n};
@@ -719,6 +749,10 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
       PTRY(msm_group(p, sc, ms, 4, 0));   // commit_polynomials (prover.rs:187-210) as one group launch
     }
+  }
+  if (side_defer) {
+    SideScopeAfter side(c, p->ev_acc);
+    PTRY(side_round1());
   }
   PTRY(fetch_commitments(p, 0, 4, comm));
   tr.append_commitment("a_comm", comm[0]);
@@ -754,12 +788,20 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     prof_end(c, 4);
   }
   HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-  {
+  if (!side_defer) {
     SideScope side(c, p->ev_ready);   // z's coset FFT only needs z(X): overlap with its commitment
     PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
     HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
   }
-  PTRY(msm_to(p, p->zpoly, n + 3, 4));
+  {
+    AccMark mark(c, side_defer ? p->ev_acc : nullptr);
+    PTRY(msm_to(p, p->zpoly, n + 3, 4));
+  }
+  if (side_defer) {
+    SideScopeAfter side(c, p->ev_acc);
+    PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
+    HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+  }
   PTRY(fetch_commitments(p, 4, 1, comm + 4));
   tr.append_commitment("z_comm", comm[4]);
 
