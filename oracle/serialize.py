@@ -84,6 +84,13 @@ def commit_key_to_raw_var_bytes(ck) -> bytes:
     return b"".join(out)
 
 
+def public_parameters_to_raw_var_bytes(opening_key: bytes, ck) -> bytes:
+    """PublicParameters::to_raw_var_bytes (src/commitment_scheme/kzg10/srs.rs:114-121): OpeningKey::to_bytes()
+    (240 bytes: g, h, x_h compressed, key.rs:436-452) followed by CommitKey::to_raw_var_bytes()."""
+    assert len(opening_key) == 240
+    return opening_key + commit_key_to_raw_var_bytes(ck)
+
+
 def verifier_key_to_bytes(vk: dict) -> bytes:
     out = vk["n"].to_bytes(8, "little") + b"".join(E.g1_compress(vk[name]) for name in VK_ORDER)
     return out + bytes(VERIFIER_KEY_SIZE - len(out))

@@ -49,6 +49,7 @@ EXPORTS = [
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
     "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
+    "plonk_public_parameters_check", "plonk_srs_load_public_parameters",
 ]
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
@@ -75,6 +76,11 @@ class _BlobInfo(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint64), ("constraints", ctypes.c_uint64), ("label_off", ctypes.c_uint64),
                 ("label_len", ctypes.c_uint64), ("poly_off", ctypes.c_uint64 * 15), ("poly_len", ctypes.c_uint64 * 15),
                 ("srs_off", ctypes.c_uint64), ("srs_points", ctypes.c_uint64), ("vk_off", ctypes.c_uint64)]
+
+
+class _PublicParametersInfo(ctypes.Structure):
+    _fields_ = [("opening_key_off", ctypes.c_uint64), ("points_off", ctypes.c_uint64),
+                ("points_total", ctypes.c_uint64), ("points_kept", ctypes.c_uint64)]
 
 
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
@@ -164,6 +170,8 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_prover_blob_check.argtypes = [vp, u64, ctypes.POINTER(_BlobInfo)]
     lib.plonk_prover_from_bytes.argtypes = [vp, vp, u64, ctypes.POINTER(vp)]
     lib.plonk_srs_validate.argtypes = [vp, vp, u64]
+    lib.plonk_public_parameters_check.argtypes = [vp, u64, u64, ci, ctypes.POINTER(_PublicParametersInfo)]
+    lib.plonk_srs_load_public_parameters.argtypes = [vp, vp, u64, u64, ci, vp, ctypes.POINTER(u64)]
     lib.plonk_lagrange_key.argtypes = [vp, u32, vp]
     lib.plonk_compile.argtypes = [vp, ctypes.POINTER(_CircuitDesc), ctypes.POINTER(vp)]
     lib.plonk_prover_prove_witnesses.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp]
@@ -193,6 +201,21 @@ def prover_blob_check(blob: bytes) -> dict:
             "label": blob[info.label_off:info.label_off + info.label_len],
             "polys": {name: (info.poly_off[k], info.poly_len[k]) for k, name in enumerate(POLY_ORDER)},
             "srs": (info.srs_off, info.srs_points), "vk_off": info.vk_off}
+
+
+def public_parameters_check(data: bytes, truncated_degree: int = 0, validate: bool = True) -> dict:
+    """Host-only decode of PublicParameters::to_raw_var_bytes() (reference srs.rs:114-146, key.rs:215-300; no GPU needed):
+    the opening-key bytes and the layout of the (trimmed) commit key, or NotEnoughBytes / InvalidData / PointMalformed /
+    PolynomialDegreeTooLarge-style PlonkError(-3) for a trim beyond the key (Error::TruncatedDegreeTooLarge)."""
+    lib = load_library()
+    info = _PublicParametersInfo()
+    rc = lib.plonk_public_parameters_check(data, len(data), truncated_degree, 1 if validate else 0, ctypes.byref(info))
+    if rc in _DECODE_ERRORS:
+        raise _DECODE_ERRORS[rc](rc, (lib.plonk_last_error() or b"").decode())
+    if rc != PLONK_OK:
+        raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
+    return {"opening_key": data[info.opening_key_off:info.opening_key_off + 240], "points_off": info.points_off,
+            "points_total": info.points_total, "points_kept": info.points_kept}
 
 
 # ---- marshalling -----------------------------------------------------------------
@@ -356,6 +379,16 @@ class Context:
     def srs_load_bytes(self, raw: bytes, npoints: int) -> None:
         self._check(self.lib.plonk_srs_load(self.handle, raw, npoints))
         self.srs_points = npoints
+
+    def srs_load_public_parameters(self, data: bytes, truncated_degree: int = 0, validate: bool = True) -> bytes:
+        """PublicParameters::from_slice_unchecked / CommitKey::from_raw_var_bytes + trim(truncated_degree) straight into
+        the context's window tables (plonk_srs_load_public_parameters); returns the 240 opening-key bytes."""
+        ok = ctypes.create_string_buffer(240)
+        n = ctypes.c_uint64(0)
+        self._check(self.lib.plonk_srs_load_public_parameters(self.handle, data, len(data), truncated_degree,
+                                                              1 if validate else 0, ok, ctypes.byref(n)))
+        self.srs_points = n.value
+        return ok.raw
 
     def srs_load_host_ptr(self, ptr: int, npoints: int) -> None:
         """plonk_srs_load from a raw host address (e.g. inside a PinnedBuffer): streamed in chunks."""

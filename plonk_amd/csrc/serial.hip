@@ -233,6 +233,59 @@ int blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob_info* info) 
   return PLONK_OK;
 }
 
+// PublicParameters::to_raw_var_bytes (srs.rs:114-121): decode + structural validation, see include/plonk_hip.h
+constexpr uint64_t OPENING_KEY_BYTES = 48 + 96 + 96, ADDED_BLINDING_DEGREE = 6;   // key.rs:436-452, srs.rs:54
+
+int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int validate,
+                            plonk_public_parameters_info* info) {
+  memset(info, 0, sizeof *info);
+  if (len <= OPENING_KEY_BYTES) FAIL(PLONK_ERR_BYTES, "public parameters shorter than an opening key");   // srs.rs:165-167
+  // OpeningKey::from_slice (key.rs:455-490): three compressed points; g is checked like every G1 encoding
+  if (!g1_compressed_valid(bytes)) FAIL(PLONK_ERR_DATA, "opening key: g is not a valid compressed G1 point");
+  for (uint64_t off : {(uint64_t)48, (uint64_t)144})
+    if (!(bytes[off] & 0x80)) FAIL(PLONK_ERR_DATA, "opening key: G2 point without the compression flag");
+  info->opening_key_off = 0;
+  const uint8_t* ck = bytes + OPENING_KEY_BYTES;
+  const uint64_t ck_len = len - OPENING_KEY_BYTES;
+  if (ck_len < 8) FAIL(PLONK_ERR_BYTES, "commit key header");
+  const uint64_t count = le64(ck);
+  uint64_t npts;
+  if (validate) {   // CommitKey::from_raw_var_bytes (key.rs:263-300)
+    if (count == 0) FAIL(PLONK_ERR_DATA, "empty commit key");
+    if (count > (1ull << 40) || ck_len != 8 + count * RAW_POINT) FAIL(PLONK_ERR_BYTES, "commit key length");
+    npts = count;
+  } else {          // CommitKey::from_slice_unchecked (key.rs:243-258): chunks_exact(97).zip(0..count)
+    const uint64_t chunks = (ck_len - 8) / RAW_POINT;
+    npts = count < chunks ? count : chunks;
+    if (npts == 0) FAIL(PLONK_ERR_BYTES, "commit key holds no point");
+  }
+  info->points_off = OPENING_KEY_BYTES + 8;
+  info->points_total = npts;
+  uint64_t keep = npts;
+  if (truncated_degree) {   // PublicParameters::trim -> CommitKey::truncate (srs.rs:188-196, key.rs:336-355)
+    uint64_t d = truncated_degree + ADDED_BLINDING_DEGREE;
+    if (d > npts - 1) FAIL(PLONK_ERR_DEGREE, "TruncatedDegreeTooLarge");
+    if (d == 1) d = 2;      // (unreachable with the +6, kept for the literal rule)
+    keep = d + 1;
+  }
+  info->points_kept = keep;
+  for (uint64_t i = 0; i < keep; ++i) {
+    const uint8_t* r = bytes + info->points_off + RAW_POINT * i;
+    if (r[96] != 0) FAIL(PLONK_ERR_POINT, "identity in the commit key");
+    if (validate) {   // reduced limbs, so that the curve test on the GPU means what it says
+      for (int c = 0; c < 2; ++c) {
+        bool lt = false;
+        for (int k = 11; k >= 0; --k) {
+          const uint32_t w = le32(r + 48 * c + 4 * k);
+          if (w != FpP::MOD[k]) { lt = w < FpP::MOD[k]; break; }
+        }
+        if (!lt) FAIL(PLONK_ERR_POINT, "coordinate not reduced");
+      }
+    }
+  }
+  return PLONK_OK;
+}
+
 }  // namespace
 }  // namespace plonk
 
@@ -243,6 +296,32 @@ extern "C" {
 int plonk_prover_blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob_info* info) {
   if (!blob || !info) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   return blob_check(blob, len, info);
+}
+
+int plonk_public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int validate,
+                                  plonk_public_parameters_info* info) {
+  if (!bytes || !info) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  return public_parameters_check(bytes, len, truncated_degree, validate, info);
+}
+
+int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint64_t len, uint64_t truncated_degree,
+                                     int validate, uint8_t opening_key_out[240], uint64_t* points_loaded) {
+  if (!ctx || !bytes) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  plonk_public_parameters_info info;
+  int rc = public_parameters_check(bytes, len, truncated_degree, validate, &info);
+  if (rc) return rc;
+  // 97-byte raw points -> x || y; the trimmed prefix only (the rest of the file is never touched)
+  std::vector<uint8_t> xy((size_t)info.points_kept * 96);
+  for (uint64_t i = 0; i < info.points_kept; ++i) memcpy(&xy[96 * i], bytes + info.points_off + RAW_POINT * i, 96);
+  if (validate) {   // is_on_curve & is_torsion_free for every point, on the GPU (key.rs:287-293)
+    rc = plonk_srs_validate(ctx, xy.data(), info.points_kept);
+    if (rc) return rc;
+  }
+  rc = plonk_srs_load(ctx, xy.data(), info.points_kept);
+  if (rc) return rc;
+  if (opening_key_out) memcpy(opening_key_out, bytes + info.opening_key_off, OPENING_KEY_BYTES);
+  if (points_loaded) *points_loaded = info.points_kept;
+  return PLONK_OK;
 }
 
 int plonk_prover_from_bytes(plonk_ctx* ctx, const uint8_t* blob, uint64_t len, plonk_prover** out) {

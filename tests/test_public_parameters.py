@@ -1,0 +1,120 @@
+"""PublicParameters::to_raw_var_bytes (reference src/commitment_scheme/kzg10/srs.rs:114-146) -> plonk_public_parameters_check /
+plonk_srs_load_public_parameters: the file a dusk-plonk user keeps next to the circuit.
+
+The bytes come from the oracle's restatement of the serialiser (oracle/serialize.py) over the reference KAT's commit key
+(SRS seed 0x9235_e700, prover.rs:1134-1139); the host-side decoder must find every piece and refuse what
+PublicParameters::from_slice / from_slice_unchecked, OpeningKey::from_slice, CommitKey::from_raw_var_bytes and
+CommitKey::truncate refuse, with the same error kinds.  The G2 half of the opening key is opaque to a prover backend."""
+import pytest
+
+import plonk_amd
+from oracle import bls12_381 as E
+from oracle.serialize import public_parameters_to_raw_var_bytes
+
+
+def opening_key_bytes():
+    # g = the G1 generator (compressed); h, x_h: 96-byte compressed G2 encodings — only their flag bit is looked at
+    g2 = bytes([0x80 | 0x13]) + bytes(range(1, 96))
+    return E.g1_compress(E.G1_GEN) + g2 + g2
+
+
+@pytest.fixture(scope="module")
+def pp(kat_setup):
+    _, oprover, _ = kat_setup
+    return public_parameters_to_raw_var_bytes(opening_key_bytes(), oprover.ck), oprover.ck
+
+
+def test_layout_and_trim(pp):
+    data, ck = pp
+    assert len(data) == 240 + 8 + 97 * len(ck)                                   # srs.rs:114-121, key.rs:215-229
+    info = plonk_amd.public_parameters_check(data)
+    assert info["opening_key"] == data[:240] and info["points_off"] == 248
+    assert info["points_total"] == info["points_kept"] == len(ck) == 23
+    off = info["points_off"]
+    assert E.g1_from_raw96(data[off:off + 96]) == ck[0]
+    assert E.g1_from_raw96(data[off + 97 * 22:off + 97 * 22 + 96]) == ck[22]
+    # PublicParameters::trim(d) = CommitKey::truncate(d + 6): powers_of_g[..= d + 6]  (srs.rs:188-196, key.rs:336-355)
+    assert plonk_amd.public_parameters_check(data, truncated_degree=8)["points_kept"] == 15
+    assert plonk_amd.public_parameters_check(data, truncated_degree=16)["points_kept"] == 23   # max_degree = 22 = 16 + 6
+    with pytest.raises(plonk_amd.PlonkError) as e:                               # Error::TruncatedDegreeTooLarge
+        plonk_amd.public_parameters_check(data, truncated_degree=17)
+    assert e.value.code == -3                                              # PLONK_ERR_DEGREE
+
+
+def test_not_enough_bytes(pp):
+    data, _ = pp
+    for cut in (0, 100, 240):                                                    # srs.rs:165-167: len <= OpeningKey::SIZE
+        with pytest.raises(plonk_amd.NotEnoughBytes):
+            plonk_amd.public_parameters_check(data[:cut])
+    with pytest.raises(plonk_amd.NotEnoughBytes):                                # commit key header
+        plonk_amd.public_parameters_check(data[:244])
+    with pytest.raises(plonk_amd.NotEnoughBytes):                                # from_raw_var_bytes: exact length
+        plonk_amd.public_parameters_check(data[:-1])
+    with pytest.raises(plonk_amd.NotEnoughBytes):
+        plonk_amd.public_parameters_check(data + b"\x00")
+
+
+def test_unchecked_decoding_takes_the_whole_chunks_present(pp):
+    data, ck = pp
+    # CommitKey::from_slice_unchecked (key.rs:243-258): chunks_exact(97).zip(0..count)
+    info = plonk_amd.public_parameters_check(data[:-1], validate=False)
+    assert info["points_total"] == len(ck) - 1
+    info = plonk_amd.public_parameters_check(data + b"\x00" * 50, validate=False)
+    assert info["points_total"] == len(ck)
+    with pytest.raises(plonk_amd.NotEnoughBytes):
+        plonk_amd.public_parameters_check(data[:248 + 96], validate=False)
+
+
+def test_invalid_data(pp):
+    data, _ = pp
+    empty = data[:240] + (0).to_bytes(8, "little")
+    with pytest.raises(plonk_amd.InvalidData):                                   # key.rs:272-274: len == 0
+        plonk_amd.public_parameters_check(empty)
+    bad_g = bytes([data[0] & 0x7F]) + data[1:]                                   # g without the compression flag
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.public_parameters_check(bad_g)
+    off_curve = E.g1_compress(E.G1_GEN)
+    off_curve = off_curve[:47] + bytes([off_curve[47] ^ 1])                      # x + 1: x^3 + 4 is not a square here, or the point leaves the subgroup
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.public_parameters_check(off_curve + data[48:])
+    bad_h = data[:48] + bytes([data[48] & 0x7F]) + data[49:]
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.public_parameters_check(bad_h)
+
+
+def test_point_malformed(pp):
+    data, _ = pp
+    inf = bytearray(data)
+    inf[248 + 97 * 3 + 96] = 1                                                   # infinity flag of point 3
+    with pytest.raises(plonk_amd.PointMalformed):
+        plonk_amd.public_parameters_check(bytes(inf))
+    big = bytearray(data)
+    big[248 + 97 * 5 + 47] = 0xFF                                                # x limb 11 >= p's: not reduced
+    with pytest.raises(plonk_amd.PointMalformed):
+        plonk_amd.public_parameters_check(bytes(big))
+    # a point beyond the trim is never looked at
+    far = bytearray(data)
+    far[248 + 97 * 20 + 96] = 1
+    assert plonk_amd.public_parameters_check(bytes(far), truncated_degree=8)["points_kept"] == 15
+
+
+@pytest.mark.gpu
+def test_loaded_key_commits_like_the_points_loaded_directly(pp):
+    data, ck = pp
+    ctx = plonk_amd.Context(0)
+    ok = ctx.srs_load_public_parameters(data, truncated_degree=8)                # validate: on-curve + torsion-free on the GPU
+    assert ok == data[:240] and ctx.srs_points == 15
+    sc = [(0x9E3779B97F4A7C15 * (i + 1)) % E.Q for i in range(15)]
+    assert ctx.msm(sc) == E.msm_pippenger(ck[:15], sc)
+    with pytest.raises(plonk_amd.PolynomialDegreeTooLarge):                      # the trimmed key holds 15 points
+        ctx.commit(list(range(1, 17)))
+    ctx.srs_load_public_parameters(data, validate=False)                         # from_slice_unchecked: all 23 points
+    assert ctx.srs_points == 23
+    sc = [(0xD1B54A32D192ED03 * (i + 3)) % E.Q for i in range(23)]
+    assert ctx.msm(sc) == E.msm_pippenger(ck, sc)
+    # a point off the curve is caught by the GPU check of the validated path only
+    bad = bytearray(data)
+    bad[248 + 97 * 2 + 48] ^= 1                                                  # y of point 2
+    with pytest.raises(plonk_amd.PointMalformed):
+        ctx.srs_load_public_parameters(bytes(bad))
+    ctx.close()
