@@ -714,8 +714,9 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // its accumulation and fill the latency-bound tail.  Same-box A/B (r02e): waiting wins up to 2^18 gates (2^16: 5.19 vs
   // 5.33 ms) and on the widget workload (38.1 vs 38.5 ms) but loses on the dense 2^20 headline (37.2-37.4 vs 36.6-36.8 ms:
   // z's transform no longer fits between its commitment and the quotient), so it follows the size.  PLONK_SIDE_DEFER=0/1 forces it.
-  static const int side_defer_env = [] { const char* e = getenv("PLONK_SIDE_DEFER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-  const bool side_defer = side_defer_env >= 0 ? side_defer_env == 1 : L <= 18;
+  static const int side_defer_env = [] { const char* e = getenv("PLONK_SIDE_DEFER"); return e ? (e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0) : -1; }();
+  const bool side_defer = side_defer_env >= 0 ? side_defer_env >= 1 : L <= 18;          // round 1: a, b, c, d (+ PI)
+  const bool side_defer_z = side_defer_env >= 0 ? side_defer_env == 1 : L <= 18;         // round 2: z ("2" = round 1 only)
   auto side_round1 = [&]() -> int {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
     // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments; with the
@@ -788,16 +789,16 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     prof_end(c, 4);
   }
   HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-  if (!side_defer) {
+  if (!side_defer_z) {
     SideScope side(c, p->ev_ready);   // z's coset FFT only needs z(X): overlap with its commitment
     PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
     HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
   }
   {
-    AccMark mark(c, side_defer ? p->ev_acc : nullptr);
+    AccMark mark(c, side_defer_z ? p->ev_acc : nullptr);
     PTRY(msm_to(p, p->zpoly, n + 3, 4));
   }
-  if (side_defer) {
+  if (side_defer_z) {
     SideScopeAfter side(c, p->ev_acc);
     PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
     HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
