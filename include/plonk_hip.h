@@ -281,32 +281,40 @@ int plonk_prover_from_bytes(plonk_ctx* ctx, const uint8_t* blob, uint64_t len, p
 int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
 
 /* ---- PublicParameters on disk -> commit key on the device ------------------------------------
- * The file a dusk-plonk user keeps: PublicParameters::to_raw_var_bytes() (src/commitment_scheme/kzg10/srs.rs:114-121)
- *   = OpeningKey::to_bytes() (240 B: g 48 B, h 96 B, x_h 96 B, compressed; key.rs:436-452)
- *   || CommitKey::to_raw_var_bytes() (u64 LE count, then count x 97 B raw points x || y || infinity flag; key.rs:215-229).
- * plonk_public_parameters_check decodes it on the host (no GPU):
- *   validate = 0  PublicParameters::from_slice_unchecked (srs.rs:131-146): the commit-key points are trusted; like
- *                 CommitKey::from_slice_unchecked (key.rs:243-258) it takes min(count, whole 97-byte chunks present) points;
- *   validate = 1  CommitKey::from_raw_var_bytes (key.rs:263-300): count != 0 (PLONK_ERR_DATA), exact length
- *                 (PLONK_ERR_BYTES); the per-point is_on_curve & is_torsion_free test runs on the GPU in
- *                 plonk_srs_load_public_parameters (PLONK_ERR_POINT).
- *   The opening key's g must be a valid compressed G1 point (PLONK_ERR_DATA, OpeningKey::from_slice); h and x_h are G2
- *   points — the prover never touches them, they are checked for the compression flag only and handed back as bytes.
+ * The files a dusk-plonk user keeps (src/commitment_scheme/kzg10/srs.rs:103-178).  Both start with
+ * OpeningKey::to_bytes() (240 B: g 48 B, h 96 B, x_h 96 B, compressed; key.rs:436-452); then
+ *   RAW        PublicParameters::to_raw_var_bytes(): CommitKey::to_raw_var_bytes() = u64 LE count, count x 97 B raw points
+ *              x || y || infinity flag (key.rs:215-229);
+ *   COMPRESSED PublicParameters::to_var_bytes(): CommitKey::to_var_bytes() = 48-byte compressed points, no count (key.rs:303-308).
+ * mode:
+ *   PLONK_PP_RAW_UNCHECKED  PublicParameters::from_slice_unchecked (srs.rs:131-146): the commit-key points are trusted; like
+ *                           CommitKey::from_slice_unchecked (key.rs:243-258) it takes min(count, whole 97-byte chunks present) points;
+ *   PLONK_PP_RAW            CommitKey::from_raw_var_bytes (key.rs:263-300): count != 0 (PLONK_ERR_DATA), exact length
+ *                           (PLONK_ERR_BYTES), every kept point is_on_curve & is_torsion_free (PLONK_ERR_POINT; on the GPU);
+ *   PLONK_PP_COMPRESSED     PublicParameters::from_slice (srs.rs:164-178) = one G1Affine::from_slice per 48-byte chunk
+ *                           (key.rs:319-326): compression flag, x < p, x^3 + 4 a square, torsion-free — any failure, a short
+ *                           last chunk included, is a dusk_bytes error (PLONK_ERR_DATA).  Decompression (one square root per
+ *                           point, g1codec.cuh) and the subgroup test run on the GPU.
+ *   All modes: the opening key's g must be a valid compressed G1 point (PLONK_ERR_DATA, OpeningKey::from_slice); h and x_h are
+ *   G2 points — the prover never touches them, they are checked for the compression flag only and handed back as bytes.
  *   truncated_degree > 0: PublicParameters::trim (srs.rs:188-196) = CommitKey::truncate(truncated_degree + 6)
- *   (key.rs:336-355): PLONK_ERR_DEGREE when the key is shorter (Error::TruncatedDegreeTooLarge); 0 keeps every point.
- *   A point with the infinity flag set is refused (PLONK_ERR_POINT): a commit key never holds the identity and the
- *   window tables cannot represent it.  Fewer than 241 bytes: PLONK_ERR_BYTES (Error::NotEnoughBytes, srs.rs:165-167).
- * plonk_srs_load_public_parameters = check, (validate: plonk_srs_validate), plonk_srs_load of the kept points. */
+ *   (key.rs:336-355): PLONK_ERR_DEGREE when the key is shorter (Error::TruncatedDegreeTooLarge); 0 keeps every point; points
+ *   beyond the trim are never decoded.  An identity among the kept points is refused (PLONK_ERR_POINT): a commit key never
+ *   holds one and the window tables cannot represent it.  At most 240 bytes: PLONK_ERR_BYTES (Error::NotEnoughBytes, srs.rs:165-167).
+ * plonk_public_parameters_check is the host-side part (no GPU): structure, opening key, trim, flags and coordinate ranges.
+ * plonk_srs_load_public_parameters = check + the per-point work on the GPU + window tables of the kept points. */
+enum { PLONK_PP_RAW_UNCHECKED = 0, PLONK_PP_RAW = 1, PLONK_PP_COMPRESSED = 2 };
 typedef struct plonk_public_parameters_info {
   uint64_t opening_key_off;   /* 240 bytes */
-  uint64_t points_off;        /* first 97-byte raw point */
+  uint64_t points_off;        /* first point */
+  uint64_t point_stride;      /* 97 (raw) or 48 (compressed) */
   uint64_t points_total;      /* points the file holds */
   uint64_t points_kept;       /* after the trim */
 } plonk_public_parameters_info;
-int plonk_public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int validate,
+int plonk_public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int mode,
                                   plonk_public_parameters_info* info);
 int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint64_t len, uint64_t truncated_degree,
-                                     int validate, uint8_t opening_key_out[240] /* may be NULL */,
+                                     int mode, uint8_t opening_key_out[240] /* may be NULL */,
                                      uint64_t* points_loaded /* may be NULL */);
 
 /* ---- measurement --------------------------------------------------------------

@@ -91,6 +91,13 @@ def public_parameters_to_raw_var_bytes(opening_key: bytes, ck) -> bytes:
     return opening_key + commit_key_to_raw_var_bytes(ck)
 
 
+def public_parameters_to_var_bytes(opening_key: bytes, ck) -> bytes:
+    """PublicParameters::to_var_bytes (srs.rs:149-153): the opening key, then CommitKey::to_var_bytes() — the 48-byte
+    compressed encoding of every point, no count (key.rs:303-308)."""
+    assert len(opening_key) == 240
+    return opening_key + b"".join(E.g1_compress(pt) for pt in ck)
+
+
 def verifier_key_to_bytes(vk: dict) -> bytes:
     out = vk["n"].to_bytes(8, "little") + b"".join(E.g1_compress(vk[name]) for name in VK_ORDER)
     return out + bytes(VERIFIER_KEY_SIZE - len(out))

@@ -79,8 +79,11 @@ class _BlobInfo(ctypes.Structure):
 
 
 class _PublicParametersInfo(ctypes.Structure):
-    _fields_ = [("opening_key_off", ctypes.c_uint64), ("points_off", ctypes.c_uint64),
+    _fields_ = [("opening_key_off", ctypes.c_uint64), ("points_off", ctypes.c_uint64), ("point_stride", ctypes.c_uint64),
                 ("points_total", ctypes.c_uint64), ("points_kept", ctypes.c_uint64)]
+
+
+PP_RAW_UNCHECKED, PP_RAW, PP_COMPRESSED = 0, 1, 2   # plonk_hip.h PLONK_PP_*
 
 
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
@@ -203,19 +206,24 @@ def prover_blob_check(blob: bytes) -> dict:
             "srs": (info.srs_off, info.srs_points), "vk_off": info.vk_off}
 
 
-def public_parameters_check(data: bytes, truncated_degree: int = 0, validate: bool = True) -> dict:
-    """Host-only decode of PublicParameters::to_raw_var_bytes() (reference srs.rs:114-146, key.rs:215-300; no GPU needed):
-    the opening-key bytes and the layout of the (trimmed) commit key, or NotEnoughBytes / InvalidData / PointMalformed /
-    PolynomialDegreeTooLarge-style PlonkError(-3) for a trim beyond the key (Error::TruncatedDegreeTooLarge)."""
+def _pp_mode(validate: bool, compressed: bool) -> int:
+    return PP_COMPRESSED if compressed else (PP_RAW if validate else PP_RAW_UNCHECKED)
+
+
+def public_parameters_check(data: bytes, truncated_degree: int = 0, validate: bool = True, compressed: bool = False) -> dict:
+    """Host-only decode of a PublicParameters file (reference srs.rs:103-178, key.rs:215-326; no GPU needed) — the raw form
+    (`to_raw_var_bytes`, checked or unchecked) or the compressed form (`to_var_bytes`): the opening-key bytes and the layout of
+    the (trimmed) commit key, or NotEnoughBytes / InvalidData / PointMalformed / PlonkError(-3) for a trim beyond the key
+    (Error::TruncatedDegreeTooLarge)."""
     lib = load_library()
     info = _PublicParametersInfo()
-    rc = lib.plonk_public_parameters_check(data, len(data), truncated_degree, 1 if validate else 0, ctypes.byref(info))
+    rc = lib.plonk_public_parameters_check(data, len(data), truncated_degree, _pp_mode(validate, compressed), ctypes.byref(info))
     if rc in _DECODE_ERRORS:
         raise _DECODE_ERRORS[rc](rc, (lib.plonk_last_error() or b"").decode())
     if rc != PLONK_OK:
         raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
     return {"opening_key": data[info.opening_key_off:info.opening_key_off + 240], "points_off": info.points_off,
-            "points_total": info.points_total, "points_kept": info.points_kept}
+            "point_stride": info.point_stride, "points_total": info.points_total, "points_kept": info.points_kept}
 
 
 # ---- marshalling -----------------------------------------------------------------
@@ -380,13 +388,15 @@ class Context:
         self._check(self.lib.plonk_srs_load(self.handle, raw, npoints))
         self.srs_points = npoints
 
-    def srs_load_public_parameters(self, data: bytes, truncated_degree: int = 0, validate: bool = True) -> bytes:
-        """PublicParameters::from_slice_unchecked / CommitKey::from_raw_var_bytes + trim(truncated_degree) straight into
-        the context's window tables (plonk_srs_load_public_parameters); returns the 240 opening-key bytes."""
+    def srs_load_public_parameters(self, data: bytes, truncated_degree: int = 0, validate: bool = True,
+                                   compressed: bool = False) -> bytes:
+        """PublicParameters::from_slice_unchecked / CommitKey::from_raw_var_bytes / PublicParameters::from_slice (compressed)
+        + trim(truncated_degree) straight into the context's window tables (plonk_srs_load_public_parameters); returns the
+        240 opening-key bytes."""
         ok = ctypes.create_string_buffer(240)
         n = ctypes.c_uint64(0)
         self._check(self.lib.plonk_srs_load_public_parameters(self.handle, data, len(data), truncated_degree,
-                                                              1 if validate else 0, ok, ctypes.byref(n)))
+                                                              _pp_mode(validate, compressed), ok, ctypes.byref(n)))
         self.srs_points = n.value
         return ok.raw
 

@@ -27,6 +27,7 @@
 #include "../../include/plonk_hip.h"
 #include "plonk_internal.hpp"
 #include "hostg1.hpp"
+#include "g1codec.cuh"
 
 namespace plonk {
 namespace {
@@ -233,12 +234,13 @@ int blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob_info* info) 
   return PLONK_OK;
 }
 
-// PublicParameters::to_raw_var_bytes (srs.rs:114-121): decode + structural validation, see include/plonk_hip.h
-constexpr uint64_t OPENING_KEY_BYTES = 48 + 96 + 96, ADDED_BLINDING_DEGREE = 6;   // key.rs:436-452, srs.rs:54
+// PublicParameters files (srs.rs:103-178): decode + structural validation, see include/plonk_hip.h
+constexpr uint64_t OPENING_KEY_BYTES = 48 + 96 + 96, ADDED_BLINDING_DEGREE = 6, COMPRESSED_POINT = 48;   // key.rs:436-452, srs.rs:54
 
-int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int validate,
+int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int mode,
                             plonk_public_parameters_info* info) {
   memset(info, 0, sizeof *info);
+  if (mode != PLONK_PP_RAW_UNCHECKED && mode != PLONK_PP_RAW && mode != PLONK_PP_COMPRESSED) FAIL(PLONK_ERR_ARG, "unknown public-parameters mode");
   if (len <= OPENING_KEY_BYTES) FAIL(PLONK_ERR_BYTES, "public parameters shorter than an opening key");   // srs.rs:165-167
   // OpeningKey::from_slice (key.rs:455-490): three compressed points; g is checked like every G1 encoding
   if (!g1_compressed_valid(bytes)) FAIL(PLONK_ERR_DATA, "opening key: g is not a valid compressed G1 point");
@@ -247,19 +249,27 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
   info->opening_key_off = 0;
   const uint8_t* ck = bytes + OPENING_KEY_BYTES;
   const uint64_t ck_len = len - OPENING_KEY_BYTES;
-  if (ck_len < 8) FAIL(PLONK_ERR_BYTES, "commit key header");
-  const uint64_t count = le64(ck);
   uint64_t npts;
-  if (validate) {   // CommitKey::from_raw_var_bytes (key.rs:263-300)
-    if (count == 0) FAIL(PLONK_ERR_DATA, "empty commit key");
-    if (count > (1ull << 40) || ck_len != 8 + count * RAW_POINT) FAIL(PLONK_ERR_BYTES, "commit key length");
-    npts = count;
-  } else {          // CommitKey::from_slice_unchecked (key.rs:243-258): chunks_exact(97).zip(0..count)
-    const uint64_t chunks = (ck_len - 8) / RAW_POINT;
-    npts = count < chunks ? count : chunks;
-    if (npts == 0) FAIL(PLONK_ERR_BYTES, "commit key holds no point");
+  if (mode == PLONK_PP_COMPRESSED) {   // CommitKey::from_slice (key.rs:319-326): chunks(48).map(G1Affine::from_slice)
+    if (ck_len % COMPRESSED_POINT) FAIL(PLONK_ERR_DATA, "commit key: short last chunk (dusk_bytes BadLength)");
+    npts = ck_len / COMPRESSED_POINT;
+    info->points_off = OPENING_KEY_BYTES;
+    info->point_stride = COMPRESSED_POINT;
+  } else {
+    if (ck_len < 8) FAIL(PLONK_ERR_BYTES, "commit key header");
+    const uint64_t count = le64(ck);
+    if (mode == PLONK_PP_RAW) {   // CommitKey::from_raw_var_bytes (key.rs:263-300)
+      if (count == 0) FAIL(PLONK_ERR_DATA, "empty commit key");
+      if (count > (1ull << 40) || ck_len != 8 + count * RAW_POINT) FAIL(PLONK_ERR_BYTES, "commit key length");
+      npts = count;
+    } else {                      // CommitKey::from_slice_unchecked (key.rs:243-258): chunks_exact(97).zip(0..count)
+      const uint64_t chunks = (ck_len - 8) / RAW_POINT;
+      npts = count < chunks ? count : chunks;
+      if (npts == 0) FAIL(PLONK_ERR_BYTES, "commit key holds no point");
+    }
+    info->points_off = OPENING_KEY_BYTES + 8;
+    info->point_stride = RAW_POINT;
   }
-  info->points_off = OPENING_KEY_BYTES + 8;
   info->points_total = npts;
   uint64_t keep = npts;
   if (truncated_degree) {   // PublicParameters::trim -> CommitKey::truncate (srs.rs:188-196, key.rs:336-355)
@@ -270,9 +280,19 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
   }
   info->points_kept = keep;
   for (uint64_t i = 0; i < keep; ++i) {
-    const uint8_t* r = bytes + info->points_off + RAW_POINT * i;
+    const uint8_t* r = bytes + info->points_off + info->point_stride * i;
+    if (mode == PLONK_PP_COMPRESSED) {   // the flag and range half of G1Affine::from_bytes; the square root is the GPU's
+      if (!(r[0] & 0x80)) FAIL(PLONK_ERR_DATA, "commit key point without the compression flag");
+      if (r[0] & 0x40) {
+        bool zero = !(r[0] & 0x3f);
+        for (int k = 1; k < 48; ++k) zero = zero && r[k] == 0;
+        if (!zero) FAIL(PLONK_ERR_DATA, "malformed identity encoding");
+        FAIL(PLONK_ERR_POINT, "identity in the commit key");
+      }
+      continue;
+    }
     if (r[96] != 0) FAIL(PLONK_ERR_POINT, "identity in the commit key");
-    if (validate) {   // reduced limbs, so that the curve test on the GPU means what it says
+    if (mode == PLONK_PP_RAW) {   // reduced limbs, so that the curve test on the GPU means what it says
       for (int c = 0; c < 2; ++c) {
         bool lt = false;
         for (int k = 11; k >= 0; --k) {
@@ -284,6 +304,17 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
     }
   }
   return PLONK_OK;
+}
+
+// one lane per 48-byte chunk: G1Affine::from_bytes minus the subgroup test (srs_validate_kernel's job); flag |= 1 invalid, 2 identity
+__global__ void __launch_bounds__(64) g1_decompress_kernel(const uint8_t* __restrict__ in, uint64_t n, G1Affine* __restrict__ out,
+                                                           int* __restrict__ flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine a;
+  const int rc = g1_decompress48(in + COMPRESSED_POINT * i, &a);
+  if (rc != G1DEC_OK) { atomicOr(flag, rc == G1DEC_IDENTITY ? 2 : 1); return; }
+  out[i] = a;
 }
 
 }  // namespace
@@ -298,27 +329,70 @@ int plonk_prover_blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob
   return blob_check(blob, len, info);
 }
 
-int plonk_public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int validate,
+int plonk_public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int mode,
                                   plonk_public_parameters_info* info) {
   if (!bytes || !info) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-  return public_parameters_check(bytes, len, truncated_degree, validate, info);
+  return public_parameters_check(bytes, len, truncated_degree, mode, info);
 }
 
 int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint64_t len, uint64_t truncated_degree,
-                                     int validate, uint8_t opening_key_out[240], uint64_t* points_loaded) {
+                                     int mode, uint8_t opening_key_out[240], uint64_t* points_loaded) {
   if (!ctx || !bytes) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk_public_parameters_info info;
-  int rc = public_parameters_check(bytes, len, truncated_degree, validate, &info);
+  int rc = public_parameters_check(bytes, len, truncated_degree, mode, &info);
   if (rc) return rc;
-  // 97-byte raw points -> x || y; the trimmed prefix only (the rest of the file is never touched)
-  std::vector<uint8_t> xy((size_t)info.points_kept * 96);
-  for (uint64_t i = 0; i < info.points_kept; ++i) memcpy(&xy[96 * i], bytes + info.points_off + RAW_POINT * i, 96);
-  if (validate) {   // is_on_curve & is_torsion_free for every point, on the GPU (key.rs:287-293)
-    rc = plonk_srs_validate(ctx, xy.data(), info.points_kept);
+  if (mode == PLONK_PP_COMPRESSED) {
+    // 48-byte chunks -> raw affine points on the device (a square root each), subgroup test, window tables: the decoded
+    // key never visits the host
+    Ctx& c = ctx->c;
+    std::lock_guard<std::mutex> lk(c.mu);
+    HIP_TRY(hipSetDevice(c.device));
+    uint8_t* in = nullptr;
+    G1Affine* pts = nullptr;
+    int* flag = nullptr;
+    const uint64_t n = info.points_kept;
+    hipError_t e = hipMalloc((void**)&in, COMPRESSED_POINT * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&pts, sizeof(G1Affine) * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&flag, 2 * sizeof(int));
+    int bad[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, 2 * sizeof(int), c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(in, bytes + info.points_off, COMPRESSED_POINT * n, hipMemcpyHostToDevice, c.stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(g1_decompress_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c.stream, in, n, pts, flag);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad[0], flag, sizeof(int), hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+    rc = e == hipSuccess ? PLONK_OK : PLONK_ERR_HIP;
+    if (rc == PLONK_OK && bad[0]) {   // (an identity was already refused by the host pass)
+      set_last_error("InvalidData", "commit key chunk is not a valid compressed G1 point", __FILE__, __LINE__);
+      rc = PLONK_ERR_DATA;
+    }
+    if (rc == PLONK_OK) rc = srs_validate_device(&c, pts, n, flag + 1);   // is_torsion_free
+    if (rc == PLONK_OK && hipMemcpyAsync(&bad[1], flag + 1, sizeof(int), hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+    if (rc == PLONK_OK && hipStreamSynchronize(c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
+    if (rc == PLONK_OK && bad[1]) {
+      set_last_error("InvalidData", "commit key point outside the prime-order subgroup", __FILE__, __LINE__);
+      rc = PLONK_ERR_DATA;
+    }
+    if (rc == PLONK_OK) rc = srs_load_device(&c, pts, n);
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipFree(in);
+    (void)hipFree(pts);
+    (void)hipFree(flag);
+    if (e != hipSuccess) set_last_error("plonk_srs_load_public_parameters", hipGetErrorString(e), __FILE__, __LINE__);
+    if (rc) return rc;
+  } else {
+    // 97-byte raw points -> x || y; the trimmed prefix only (the rest of the file is never touched)
+    std::vector<uint8_t> xy((size_t)info.points_kept * 96);
+    for (uint64_t i = 0; i < info.points_kept; ++i) memcpy(&xy[96 * i], bytes + info.points_off + RAW_POINT * i, 96);
+    if (mode == PLONK_PP_RAW) {   // is_on_curve & is_torsion_free for every point, on the GPU (key.rs:287-293)
+      rc = plonk_srs_validate(ctx, xy.data(), info.points_kept);
+      if (rc) return rc;
+    }
+    rc = plonk_srs_load(ctx, xy.data(), info.points_kept);
     if (rc) return rc;
   }
-  rc = plonk_srs_load(ctx, xy.data(), info.points_kept);
-  if (rc) return rc;
   if (opening_key_out) memcpy(opening_key_out, bytes + info.opening_key_off, OPENING_KEY_BYTES);
   if (points_loaded) *points_loaded = info.points_kept;
   return PLONK_OK;

@@ -202,3 +202,13 @@ extern "C" int h_sigma_mappings(const uint32_t* a, const uint32_t* b, const uint
   const uint32_t* wires[4] = {a, b, c, d};
   return plonk::sigma_mappings(wires, constraints, n, witnesses, out) ? 0 : -1;
 }
+
+#include "../../plonk_amd/csrc/g1codec.cuh"
+// G1Affine::from_bytes on a 48-byte compressed encoding (g1codec.cuh): returns the decoder's code, out = x || y (96 B, Montgomery)
+extern "C" int h_g1_decompress48(const uint8_t* in, uint8_t* out96) {
+  G1Affine a;
+  memset(&a, 0, sizeof a);
+  const int rc = g1_decompress48(in, &a);
+  memcpy(out96, &a, 96);
+  return rc;
+}

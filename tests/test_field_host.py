@@ -19,7 +19,7 @@ def build_host_lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
     hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
-            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp")]
+            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp", "g1codec.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -297,3 +297,35 @@ def test_host_msm_finish_and_group_normalisation(lib):
     out = (ctypes.c_uint8 * (48 * 15))()
     lib.h_batch_compress(raw, 15, out)
     assert bytes(out) == b"".join(E.g1_compress(p) for p in pts)
+
+
+def test_g1_decompress48_matches_the_oracle(lib):
+    """g1codec.cuh (the lane function of the compressed commit-key loader) against oracle g1_compress / g1_decompress:
+    G1Affine::from_bytes semantics of the 48-byte encoding — both roots, the flag rules, x >= p, x^3 + 4 not a square."""
+    rnd = random.Random(11)
+    out = ctypes.create_string_buffer(96)
+    pts = [E.G1_GEN] + [E.g1_mul(E.G1_GEN, rnd.randrange(1, Q)) for _ in range(24)]
+    pts += [(x, (P - y) % P) for x, y in pts[:8]]                      # the other root / sign flag
+    for pt in pts:
+        enc = E.g1_compress(pt)
+        assert lib.h_g1_decompress48(enc, out) == 0
+        assert out.raw == E.g1_to_raw96(pt)
+        assert E.g1_decompress(enc) == pt
+    g = E.g1_compress(E.G1_GEN)
+    assert lib.h_g1_decompress48(bytes([g[0] & 0x7F]) + g[1:], out) == 1          # compression flag missing
+    assert lib.h_g1_decompress48(bytes([0xC0]) + bytes(47), out) == 2              # the identity
+    assert lib.h_g1_decompress48(bytes([0xE0]) + bytes(47), out) == 1              # identity with the sort flag
+    assert lib.h_g1_decompress48(bytes([0xC0]) + bytes(46) + b"\x01", out) == 1    # identity with x != 0
+    assert lib.h_g1_decompress48(bytes([0x80 | (P >> 376)]) + (P & ((1 << 376) - 1)).to_bytes(47, "big"), out) == 1   # x = p
+    bad = 0
+    for x in range(1, 40):                                                          # x^3 + 4 a non-residue for about half of them
+        enc = bytes([0x80]) + x.to_bytes(47, "big")
+        rc = lib.h_g1_decompress48(enc, out)
+        on_curve = pow((x ** 3 + 4) % P, (P - 1) // 2, P) == 1
+        assert rc == (0 if on_curve else 1)
+        bad += not on_curve
+        if on_curve:                                                                # smaller root requested (flag clear)
+            y = pow((x ** 3 + 4) % P, (P + 1) // 4, P)
+            y = min(y, P - y)
+            assert out.raw == E.g1_to_raw96((x, y))
+    assert bad > 5

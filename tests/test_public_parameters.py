@@ -9,7 +9,7 @@ import pytest
 
 import plonk_amd
 from oracle import bls12_381 as E
-from oracle.serialize import public_parameters_to_raw_var_bytes
+from oracle.serialize import public_parameters_to_raw_var_bytes, public_parameters_to_var_bytes
 
 
 def opening_key_bytes():
@@ -96,6 +96,61 @@ def test_point_malformed(pp):
     far = bytearray(data)
     far[248 + 97 * 20 + 96] = 1
     assert plonk_amd.public_parameters_check(bytes(far), truncated_degree=8)["points_kept"] == 15
+
+
+def test_compressed_form_layout_and_host_side_refusals(pp):
+    _, ck = pp
+    data = public_parameters_to_var_bytes(opening_key_bytes(), ck)                # srs.rs:149-153, key.rs:303-308
+    assert len(data) == 240 + 48 * len(ck)
+    info = plonk_amd.public_parameters_check(data, compressed=True)
+    assert info["points_off"] == 240 and info["point_stride"] == 48 and info["points_total"] == info["points_kept"] == 23
+    assert E.g1_decompress(data[240:288]) == ck[0]
+    assert plonk_amd.public_parameters_check(data, truncated_degree=8, compressed=True)["points_kept"] == 15
+    with pytest.raises(plonk_amd.PlonkError) as e:
+        plonk_amd.public_parameters_check(data, truncated_degree=17, compressed=True)
+    assert e.value.code == -3
+    with pytest.raises(plonk_amd.NotEnoughBytes):                                # srs.rs:165-167
+        plonk_amd.public_parameters_check(data[:240], compressed=True)
+    with pytest.raises(plonk_amd.InvalidData):                                   # a short last chunk: G1Affine::from_slice fails
+        plonk_amd.public_parameters_check(data[:-1], compressed=True)
+    noflag = bytearray(data)
+    noflag[240 + 48 * 2] &= 0x7F
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.public_parameters_check(bytes(noflag), compressed=True)
+    ident = data[:240 + 48 * 4] + bytes([0xC0]) + bytes(47) + data[240 + 48 * 5:]
+    with pytest.raises(plonk_amd.PointMalformed):                                # valid encoding, but no commit key holds the identity
+        plonk_amd.public_parameters_check(ident, compressed=True)
+    badident = data[:240 + 48 * 4] + bytes([0xC0]) + bytes(46) + b"\x01" + data[240 + 48 * 5:]
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.public_parameters_check(badident, compressed=True)
+
+
+@pytest.mark.gpu
+def test_compressed_key_is_decompressed_on_the_device(pp):
+    _, ck = pp
+    data = public_parameters_to_var_bytes(opening_key_bytes(), ck)
+    ctx = plonk_amd.Context(0)
+    ok = ctx.srs_load_public_parameters(data, compressed=True)                   # square roots + subgroup test on the GPU
+    assert ok == data[:240] and ctx.srs_points == 23
+    sc = [(0xA24BAED4963EE407 * (i + 5)) % E.Q for i in range(23)]
+    assert ctx.msm(sc) == E.msm_pippenger(ck, sc)
+    ctx.srs_load_public_parameters(data, truncated_degree=8, compressed=True)
+    assert ctx.srs_points == 15
+    assert ctx.msm(sc[:15]) == E.msm_pippenger(ck[:15], sc[:15])
+    # both roots decode to the point that was encoded
+    flipped = [(x, (E.P - y) % E.P) for x, y in ck]
+    ctx.srs_load_public_parameters(public_parameters_to_var_bytes(opening_key_bytes(), flipped), compressed=True)
+    assert ctx.msm(sc) == E.msm_pippenger(flipped, sc)
+    # x^3 + 4 not a square -> InvalidData from the device pass; a point of the curve outside the subgroup likewise
+    x = next(v for v in range(2, 50) if pow((v ** 3 + 4) % E.P, (E.P - 1) // 2, E.P) != 1)
+    bad = data[:240 + 48 * 3] + bytes([0x80]) + x.to_bytes(47, "big") + data[240 + 48 * 4:]
+    with pytest.raises(plonk_amd.InvalidData):
+        ctx.srs_load_public_parameters(bad, compressed=True)
+    x = next(v for v in range(2, 50) if pow((v ** 3 + 4) % E.P, (E.P - 1) // 2, E.P) == 1)   # on the curve, cofactor part present
+    bad = data[:240 + 48 * 3] + bytes([0x80]) + x.to_bytes(47, "big") + data[240 + 48 * 4:]
+    with pytest.raises(plonk_amd.InvalidData):
+        ctx.srs_load_public_parameters(bad, compressed=True)
+    ctx.close()
 
 
 @pytest.mark.gpu
