@@ -18,8 +18,11 @@
 //                    XYZZ accumulator.  Field arithmetic is the reduced-radix, lazily
 //                    reduced Fp28 of fp28.cuh / curve28.cuh: a mixed addition is ten
 //                    Montgomery products of 2*14*14 v_mad_u64_u32 each and no carry chains.
-//   * msm_bucket_sum, msm_chunk_reduce, msm_final: slice partials -> buckets ->
-//                    sum_b b * B_b -> affine.
+//   * msm_bucket_sum: slice partials -> buckets (one full addition per slice: throughput-bound);
+//     msm_heavy_seg / msm_heavy_bucket: buckets with far more slices than expected (skewed digits);
+//     msm_rowcol -> msm_bits (or msm_final): sum_b b * B_b as row / column sums and 16 bit sums that the host
+//     finishes.  These are chains of DEPENDENT additions; the default kernels (*_quad) run every addition on the four
+//     lanes of a quad, one product per lane and level (g1r_add_quad), ~2.8x lower latency per addition.
 //
 // Algorithmic HBM bytes per MSM of m terms: 128 * m (32 B scalar + 96 B base).
 #include <cstdlib>
