@@ -1,0 +1,117 @@
+"""Executable model of the NEXT bucket layout of the MSM: wider windows with size-ordered buckets.
+
+Not product code and not used by it — an index-arithmetic model in the style of tests/ntt_model.py, written before the
+kernels so that every convention they must agree on is pinned against the oracle on the CPU:
+
+  * signed window digits for ANY window width c (13 windows of 20 bits cover 260 >= 256 bits; today: 16 x 16), the carry
+    rule and the range of the top window;
+  * the entry word (table row = window, column = base index, sign) and the bucket an entry belongs to;
+  * buckets handed to lanes in order of their entry count (a wave's lanes then run the same number of additions) —
+    any order gives the same sums, the model checks that the permutation is one;
+  * the weighted reduction sum_b b * B_b with b = COLS * h + l, l in [1, COLS]: row sums R_h, column sums C_l, the bit sums
+    T_j / T'_j / C_COLS the device leaves to the host, and the host's Horner chain over them.
+
+The generalisation of msm.hip's constants: c = 16: ROWS x COLS = 256 x 128 (msm_rowcol / msm_bits, 8 + 7 + 1 sums);
+c = 20: 512 x 1024 (9 + 10 + 1 sums)."""
+from oracle import bls12_381 as E
+
+
+def windows_for(c: int) -> int:
+    return -(-256 // c)          # ceil(256 / c): scalars are < 2^255, one spare bit absorbs the last carry
+
+
+def signed_digits(s: int, c: int):
+    """d_w in [-2^(c-1), 2^(c-1)] with sum d_w 2^(c w) = s; the same recoding rule as msm_hist / msm_partition for c = 16
+    (a window value above 2^(c-1) borrows 2^c from the next window)."""
+    W = windows_for(c)
+    half, full = 1 << (c - 1), 1 << c
+    out, carry = [], 0
+    for w in range(W):
+        v = ((s >> (c * w)) & (full - 1)) + carry
+        carry = 0
+        if v > half:
+            v -= full
+            carry = 1
+        out.append(v)
+    assert carry == 0, "the top window cannot overflow for s < 2^255"
+    assert sum(d << (c * w) for w, d in enumerate(out)) == s
+    return out
+
+
+def entries(scalars, c: int):
+    """(bucket index b - 1, negative?, table row, base index) for every non-zero digit; zero digits never leave the sort."""
+    out = []
+    for i, s in enumerate(scalars):
+        for w, d in enumerate(signed_digits(s % E.Q, c)):
+            if d:
+                out.append((abs(d) - 1, d < 0, w, i))
+    return out
+
+
+def bucket_sums(points, ents, c: int, order_by_size: bool = True):
+    """One lane per bucket; lanes in order of decreasing entry count.  Returns {bucket index: Jacobian sum}."""
+    groups = {}
+    for b, neg, w, i in ents:
+        groups.setdefault(b, []).append((neg, w, i))
+    lanes = sorted(groups, key=lambda b: (-len(groups[b]), b)) if order_by_size else sorted(groups)
+    assert sorted(lanes) == sorted(groups)                      # a permutation of the non-empty buckets
+    table = {}                                                  # T[w][i] = 2^(c w) P_i, built on demand
+    sums = {}
+    for b in lanes:
+        acc = E.JAC_ID
+        for neg, w, i in groups[b]:
+            if (w, i) not in table:
+                table[(w, i)] = E.to_jac(E.g1_mul(points[i], 1 << (c * w)))
+            p = table[(w, i)]
+            acc = E.jac_add(acc, E.jac_neg(p) if neg else p)
+        sums[b] = acc
+    return sums
+
+
+def row_col_split(c: int):
+    """ROWS x COLS = 2^(c-1) buckets; the split msm.hip uses for c = 16 and the one planned for c = 20."""
+    col_bits = {16: 7, 20: 10}.get(c, (c - 1 + 1) // 2)
+    return 1 << (c - 1 - col_bits), 1 << col_bits
+
+
+def bit_sums(sums, c: int):
+    """What the device hands to the host: T_j (rows with bit j of h), T'_j (columns with bit j of their weight l < COLS), C_COLS."""
+    ROWS, COLS = row_col_split(c)
+    R = [E.JAC_ID] * ROWS
+    C = [E.JAC_ID] * COLS                                       # C[l - 1]
+    for b, v in sums.items():
+        h, l0 = divmod(b, COLS)                                 # bucket weight b + 1 = COLS * h + (l0 + 1)
+        R[h] = E.jac_add(R[h], v)
+        C[l0] = E.jac_add(C[l0], v)
+    rb, cb = ROWS.bit_length() - 1, COLS.bit_length() - 1
+    T = []
+    for j in range(rb):
+        acc = E.JAC_ID
+        for h in range(ROWS):
+            if (h >> j) & 1:
+                acc = E.jac_add(acc, R[h])
+        T.append(acc)
+    Tp = []
+    for j in range(cb):
+        acc = E.JAC_ID
+        for l in range(1, COLS):
+            if (l >> j) & 1:
+                acc = E.jac_add(acc, C[l - 1])
+        Tp.append(acc)
+    return T, Tp, C[COLS - 1]
+
+
+def host_finish(T, Tp, C_top):
+    """W = sum_j 2^j T'_j + COLS * C_COLS + COLS * sum_j 2^j T_j as ONE Horner chain (hostg1.hpp finish_bit_sums for c = 16)."""
+    cb = len(Tp)
+    U = list(Tp) + [E.jac_add(C_top, T[0])] + list(T[1:])       # weights 2^0 .. 2^(cb - 1), 2^cb, 2^(cb + 1) ...
+    acc = U[-1]
+    for u in reversed(U[:-1]):
+        acc = E.jac_add(E.jac_double(acc), u)
+    assert len(U) == cb + len(T)
+    return E.to_affine(acc)
+
+
+def msm_model(points, scalars, c: int, order_by_size: bool = True):
+    ents = entries(scalars, c)
+    return host_finish(*bit_sums(bucket_sums(points, ents, c, order_by_size), c))
