@@ -115,3 +115,40 @@ def host_finish(T, Tp, C_top):
 def msm_model(points, scalars, c: int, order_by_size: bool = True):
     ents = entries(scalars, c)
     return host_finish(*bit_sums(bucket_sums(points, ents, c, order_by_size), c))
+
+
+# ---- lanes in order of slice length -------------------------------------------------------
+def slice_order(counts, ksl: int):
+    """The lane -> slice map msm_accumulate would use when slices are handed out by LENGTH instead of in bucket order.
+
+    counts[b] = entries of bucket b.  Bucket b has ceil(counts[b] / ksl) slices; its partial sums keep their slots
+    slice_off[b] + q (bucket order), so msm_bucket_sum and the heavy path do not change.  Lanes: first every FULL slice
+    (ksl entries) — lane s < F belongs to the bucket found by a search in full_off, the exclusive scan of
+    floor(counts / ksl) — then the one partial slice of every bucket whose count is not a multiple of ksl, in order of
+    decreasing length (a counting sort over the ksl - 1 possible lengths, ties by bucket index).
+    Returns (lanes, slice_off) with lanes[s] = (bucket, q, first entry offset inside the bucket, length)."""
+    full = [c // ksl for c in counts]
+    rem = [c % ksl for c in counts]
+    slice_off, run = [], 0
+    for b in range(len(counts)):
+        slice_off.append(run)
+        run += full[b] + (1 if rem[b] else 0)
+    slice_off.append(run)
+    lanes = []
+    for b in range(len(counts)):                                   # lane s < F: bucket = upper_bound(full_off, s) - 1
+        for q in range(full[b]):
+            lanes.append((b, q, q * ksl, ksl))
+    by_len = [[] for _ in range(ksl)]                              # counting sort of the partial slices by length
+    for b in range(len(counts)):
+        if rem[b]:
+            by_len[rem[b]].append(b)
+    for length in range(ksl - 1, 0, -1):
+        for b in by_len[length]:
+            lanes.append((b, full[b], full[b] * ksl, length))
+    return lanes, slice_off
+
+
+def idle_fraction(lengths, wave: int = 64):
+    """Lane-steps a wave-synchronous machine issues beyond the useful ones: every wave runs as long as its longest lane."""
+    issued = sum(max(lengths[k:k + wave]) * wave for k in range(0, len(lengths), wave))
+    return issued / max(sum(lengths), 1) - 1

@@ -36,3 +36,26 @@ def test_model_equals_the_oracle_msm(c):
     # zero digits never become entries; every other digit does, once
     sc = cases[2]
     assert len(entries(sc, c)) == sum(1 for s in sc if s)
+
+
+@pytest.mark.parametrize("ksl,mean", [(32, 512), (64, 512), (32, 32), (8, 20)])
+def test_length_ordered_lanes_are_a_permutation_of_the_slices_and_waste_nothing(ksl, mean):
+    from msm_wide_model import idle_fraction, slice_order
+    r = random.Random(ksl * 1000 + mean)
+    counts = [max(0, int(r.gauss(mean, mean ** 0.5))) for _ in range(4096)] + [0, 1, ksl, ksl + 1, 5 * ksl - 1]
+    lanes, slice_off = slice_order(counts, ksl)
+    # every slice exactly once, its partial-sum slot unchanged, its entries inside its bucket
+    slots = sorted(slice_off[b] + q for b, q, _, _ in lanes)
+    assert slots == list(range(slice_off[-1]))
+    covered = [0] * len(counts)
+    for b, q, first, length in lanes:
+        assert first == q * ksl and 0 < length <= ksl and first + length <= counts[b]
+        covered[b] += length
+    assert covered == counts
+    # full slices first, then partial ones by decreasing length
+    lengths = [l for _, _, _, l in lanes]
+    assert lengths == sorted(lengths, reverse=True)
+    # a wave of equal lanes idles (almost) never; bucket order idles by the partial slice of every bucket
+    in_bucket_order = [l for _, l in sorted(((slice_off[b] + q), l) for b, q, _, l in lanes)]
+    assert idle_fraction(lengths) < 0.01
+    assert idle_fraction(in_bucket_order) > 2.5 * idle_fraction(lengths)
