@@ -162,7 +162,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream); (void)hipFree(c.srs_table); (void)hipFree(c.table_scratch);
   MsmWork& w = c.msm;
   (void)hipFree(w.tmp_words); (void)hipFree(w.entries); (void)hipFree(w.coarse_cnt); (void)hipFree(w.coarse_off); (void)hipFree(w.coarse_cur); (void)hipFree(w.big_off); (void)hipFree(w.big_cnt); (void)hipFree(w.nheavy); (void)hipFree(w.heavy_list); (void)hipFree(w.seg_sum);
-  (void)hipFree(w.offsets); (void)hipFree(w.slice_off); (void)hipFree(w.partial); (void)hipFree(w.buckets);
+  (void)hipFree(w.offsets); (void)hipFree(w.slice_off); (void)hipFree(w.full_off); (void)hipFree(w.part_list); (void)hipFree(w.partial); (void)hipFree(w.buckets);
   (void)hipFree(w.chunk); (void)hipFree(w.result); (void)hipFree(w.scalars_stage);
   if (w.result_host) (void)hipHostFree(w.result_host);
   (void)hipStreamDestroy(c.main_stream);

@@ -267,6 +267,73 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   st_g1r(partial + s, acc);
 }
 
+// msm_accumulate_kernel with the lanes in order of slice length (PLONK_MSM_ORDER=1; msm_sort.hip msm_order_kernel): lane
+// s < F owns full slice s - full_off[b] of the bucket b found by the same two-level search, the lanes after them own the
+// partial slice of bucket part_list[s - F].  The additions are the ones above; the partial sum goes to the slice's usual
+// slot slice_off[b] + q.
+__global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1AffineR* __restrict__ table, MsmBatch bt,
+                                                                     const uint32_t* __restrict__ entries_all,
+                                                                     const uint32_t* __restrict__ offsets_all,
+                                                                     const uint32_t* __restrict__ slice_off_all,
+                                                                     const uint32_t* __restrict__ full_off_all,
+                                                                     const uint32_t* __restrict__ part_list_all,
+                                                                     G1RSlot* __restrict__ partial_all) {
+  const int kb = blockIdx.y;
+  const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ full_off = full_off_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ part_list = part_list_all + (uint64_t)kb * (MSM_NB + 1);
+  G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t coarse[MSM_NB / 64];
+  for (uint32_t j = threadIdx.x; j < MSM_NB / 64; j += blockDim.x) coarse[j] = full_off[j * 64];
+  __syncthreads();
+  const uint32_t nfull = full_off[MSM_NB], npart = part_list[MSM_NB];
+  if (s >= nfull + npart) return;
+  uint32_t b, q, end;
+  if (s < nfull) {
+    uint32_t lo = 0, hi = MSM_NB / 64 - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (coarse[mid] <= s) lo = mid; else hi = mid - 1;
+    }
+    lo *= 64;
+    hi = lo + 63;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (full_off[mid] <= s) lo = mid; else hi = mid - 1;
+    }
+    b = lo;
+    q = s - full_off[b];
+    end = offsets[b] + (q + 1) * bt.ksl;
+  } else {
+    b = part_list[s - nfull];
+    q = (offsets[b + 1] - offsets[b]) / bt.ksl;
+    end = offsets[b + 1];
+  }
+  const uint32_t beg = offsets[b] + q * bt.ksl;
+  G1R acc = G1R::identity();
+  uint32_t ent = entries[beg];
+  Fp28 x = ld_f28(&table[ent & 0x7fffffffu].x);
+  Fp28 y = ld_f28(&table[ent & 0x7fffffffu].y);
+  for (uint32_t k = beg; k < end; ++k) {
+    const uint32_t ent_c = ent;
+    const Fp28 xc = x, yc = y;
+    if (k + 1 < end) {
+      ent = entries[k + 1];
+      x = ld_f28(&table[ent & 0x7fffffffu].x);
+      y = ld_f28(&table[ent & 0x7fffffffu].y);
+    }
+    Fp28 y2;
+    const bool neg = ent_c & 0x80000000u;
+#pragma unroll
+    for (int i = 0; i < Fp28::N; ++i) y2.l[i] = neg ? Fp28::pad<4>(i) - yc.l[i] : yc.l[i];
+    acc = acc.add_affine(xc, y2);
+  }
+  st_g1r(partial + slice_off[b] + q, acc);
+}
+
 // Occupancy experiment (PLONK_MSM_ACC=lds), kept as the measured answer to "would a third wave per SIMD help?":
 // same slices, same additions, THREE waves per SIMD instead of two — and the same time per proof as the kernel above
 // (same-box A/B at 2^20: 26.59 / 26.84 ms against 26.84 / 26.93 ms), i.e. msm_accumulate is bound by the number of
@@ -1089,7 +1156,14 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
   // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
   static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
-  if (acc_lds)
+  // PLONK_MSM_ORDER=1: lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel)
+  static const bool acc_ordered = [] { const char* e = getenv("PLONK_MSM_ORDER"); return e && e[0] == '1'; }();
+  if (acc_ordered) {
+    rc = msm_order_slices(c, bt);
+    if (rc) return rc;
+    hipLaunchKernelGGL(msm_accumulate_ordered_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
+                       (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, w.full_off, w.part_list, (G1RSlot*)w.partial);
+  } else if (acc_lds)
     hipLaunchKernelGGL(msm_accumulate_lds_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
                        (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
   else

@@ -413,6 +413,60 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
   if (t == SORT_T - 1) slice_off[MSM_NB] = total;
 }
 
+// ---- optional: lanes in order of slice LENGTH (PLONK_MSM_ORDER=1) ---------------------------
+// In bucket order every wave of msm_accumulate holds a few partial slices (the last slice of each bucket) next to full
+// ones and waits for the full ones: 3 % idle lane-steps at 32-entry slices, 6 % at 64, 45 % at m = 2^16 with 32
+// (tools/slice_order_sim.py).  Here the full slices come first — full_off = exclusive scan of floor(count / ksl) — and then
+// the partial slice of every bucket in order of decreasing length (a counting sort over the ksl - 1 lengths into
+// part_list; part_list[NB] = their number).  The partial sums keep their slots slice_off[b] + q, so nothing after the
+// accumulation changes.  tests/msm_wide_model.py::slice_order is the executable statement of this map.
+__global__ void __launch_bounds__(SORT_T) msm_order_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ full_off_all,
+                                                           uint32_t* __restrict__ part_list_all, uint32_t ksl) {
+  __shared__ uint32_t sh[SORT_T];
+  __shared__ uint32_t hist[129];   // ksl <= 128
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  uint32_t* __restrict__ full_off = full_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  uint32_t* __restrict__ part_list = part_list_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  constexpr uint32_t PER = MSM_NB / SORT_T;
+  const uint32_t t = threadIdx.x;
+  if (t < 129) hist[t] = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
+    mine += c / ksl;
+    const uint32_t r = c % ksl;
+    if (r) atomicAdd(&hist[r], 1u);
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan(mine, sh, &total);   // (its barriers also complete the histogram)
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
+    full_off[t * PER + k] = run;
+    run += c / ksl;
+  }
+  if (t == SORT_T - 1) full_off[MSM_NB] = total;
+  if (t == 0) {   // start of every length class, longest first; hist[0] = number of partial slices
+    uint32_t acc = 0;
+    for (uint32_t r = ksl - 1; r >= 1; --r) { const uint32_t h = hist[r]; hist[r] = acc; acc += h; }
+    hist[0] = acc;
+  }
+  __syncthreads();
+  for (uint32_t k = 0; k < PER; ++k) {
+    const uint32_t b = t * PER + k;
+    const uint32_t r = (offsets[b + 1] - offsets[b]) % ksl;
+    if (r) part_list[atomicAdd(&hist[r], 1u)] = b;
+  }
+  if (t == 0) part_list[MSM_NB] = hist[0];
+}
+int msm_order_slices(Ctx* c, const MsmBatch& bt) {
+  MsmWork& w = c->msm;
+  if (bt.ksl > 128) return (set_last_error("msm_order_slices", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
+  hipLaunchKernelGGL(msm_order_kernel, dim3(bt.count), dim3(SORT_T), 0, c->stream, w.offsets, w.full_off, w.part_list, bt.ksl);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
 // Host side: everything between the scalars and msm_accumulate for one commitment group.
 int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   MsmWork& w = c->msm;
@@ -451,6 +505,8 @@ int msm_sort_reserve_fixed(Ctx* c) {
   HIP_TRY(hipMalloc((void**)&w.coarse_cur, sizeof(uint32_t) * COARSE * KB));
   HIP_TRY(hipMalloc((void**)&w.big_off, sizeof(uint32_t) * (COARSE + 1) * KB));
   HIP_TRY(hipMalloc((void**)&w.big_cnt, sizeof(uint32_t) * 2 * MSM_NB * KB));   // bin-wide bucket counts, then the run cursors
+  HIP_TRY(hipMalloc((void**)&w.full_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.part_list, sizeof(uint32_t) * (MSM_NB + 1) * KB));
   return PLONK_OK;
 }
 

@@ -73,6 +73,8 @@ struct MsmWork {   // per-context scratch, grown on demand
   uint32_t* big_cnt = nullptr;     // 2 x NB: bucket counts / run cursors of the oversized bins
   uint32_t* offsets = nullptr;     // NB + 1
   uint32_t* slice_off = nullptr;   // NB + 1
+  uint32_t* full_off = nullptr;    // NB + 1: scan of the FULL slices per bucket (PLONK_MSM_ORDER=1: lanes in order of slice length)
+  uint32_t* part_list = nullptr;   // NB + 1: buckets with a partial slice, longest first; [NB] = their number
   uint64_t cap_slices = 0;
   void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
   void* buckets = nullptr;         // NB
@@ -162,6 +164,7 @@ int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 // host combines with a short doubling chain (msm.hip msm_bits_kernel, prover.hip finish_bit_sums).
 static constexpr int MSM_BIT_SUMS = 16;
 // table == nullptr: the context's commit key; otherwise window tables built by srs_table_build (same layout)
+int msm_order_slices(Ctx* c, const MsmBatch& bt);   // msm_sort.hip: full_off / part_list from the bucket offsets
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
                      bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0,
                      const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr);
