@@ -254,6 +254,59 @@ def cpu_baseline(log_n: int, vk48: bytes):
                        "; not the Rust binary (no cargo in this image)")}, proof
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU, rank r on device r) with
+    the environment torch.distributed.run would give them, forward rank 0's stdout (the JSON line), and supervise:
+    when one rank fails the others — which may be waiting for it inside a collective — are terminated."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench launcher] rank {r} exited with {code}: stopping the other ranks", file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def dry_launch() -> int:
+    """every rank: join the control-plane group, check that all N ranks are there; rank 0 prints one JSON line"""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if os.environ.get("PLONK_BENCH_DRY_FAIL_RANK") == str(rank):   # test hook: this rank dies before it joins
+        return 3
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    ok = int(t.item()) == world * (world + 1) // 2
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": world if ok else -1,
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "-1"))}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,7 +319,18 @@ def main():
     ap.add_argument("--from-circuit", action="store_true",
                     help="build the prover with plonk_compile from gate columns (Compiler::preprocess on the device) instead of "
                          "from coefficient forms, and check plonk_prover_prove_witnesses against the column entry point")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher self-test: every rank joins the gloo group, all-reduces its rank and exits (no GPU needed)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))       # `python bench.py --gpus N`: this process only launches and supervises the N ranks
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:                 # torchrun --nproc-per-node N ... bench.py --gpus M: refuse to print a mislabelled line
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch N ranks for --gpus N "
+                 "(python bench.py --gpus N starts them itself)")
+    if args.dry_launch:
+        sys.exit(dry_launch())
 
     # stdout carries exactly ONE line (the JSON): everything else this process or its libraries print — RCCL's version
     # banner sits in the C stdio buffer until exit and would land AFTER the JSON line — goes to stderr
@@ -284,10 +348,13 @@ def main():
     dist = None
     allgather = None
     collective = None
+    n_ranks_rccl = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world,     # control plane only
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("PLONK_BENCH_JOIN_TIMEOUT_S", "600"))))
         want_rccl = os.environ.get("PLONK_BENCH_BACKEND", "nccl") == "nccl"
         ok = 0
         if want_rccl:
@@ -315,6 +382,7 @@ def main():
                 except Exception:   # noqa: BLE001
                     pass
         collective = "rccl" if ok else "gloo"
+        n_ranks_rccl = ctx.comm_info()[1] if ok else 0
         if not ok:
             def allgather(send: bytes) -> bytes:   # host-callback transport (tests / fallback)
                 t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
@@ -413,7 +481,7 @@ def main():
                                        if world in (2, 4, 8) else "x%d: MSM by SRS point range" % world),
                        "srs": "rank's point range streamed from pinned host memory in 2^18-point chunks (upload of chunk k+1 under "
                               "the window-table build of chunk k): %d points in %.2f s" % (min(per, srs_total), build_prover.srs_stream_s),
-                       "collective": collective, "setup_s": round(t_setup, 1),
+                       "collective": collective, "n_ranks_rccl": n_ranks_rccl, "setup_s": round(t_setup, 1),
                        "prover_built_by": "plonk_compile (gate columns)" if args.from_circuit else "plonk_prover_create (coefficient forms)"},
             # whole-job MSM rate: all 11 x (n + 6) terms of a proof over the time rank 0 spends in its (sharded) MSM kernels
             "msm_mscalar_per_s": round(11 * (n + 6) / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),

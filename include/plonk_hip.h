@@ -238,9 +238,23 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  * ncclAllToAll on its own stream — no host callback is involved and desc.allgather may be NULL.
  * RCCL is loaded with dlopen at the first of these calls, so the library itself does not depend on it.
  * plonk_comm_selftest runs both collectives once with a rank-dependent pattern and checks the result.
- * What is exchanged and why EC partial sums are all-gathered rather than all-reduced: DESIGN.md §5. */
+ * What is exchanged and why EC partial sums are all-gathered rather than all-reduced: DESIGN.md §5.
+ * plonk_comm_info reports the rank / size the communicator itself holds (ncclCommUserRank / ncclCommCount).
+ *
+ * Environment: this platform's driver only supports dmabuf IPC, so RCCL between processes needs
+ * HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment before the HSA runtime starts (the first HIP call of the process).
+ * The library sets it when it is LOADED unless the host program already chose a value; a host that initialises HIP
+ * before loading libplonk_hip.so must export it itself.
+ *
+ * Failure of a peer: a sharded proof is a sequence of collectives, and a rank that fails (or never arrives) would
+ * leave the others waiting inside one.  Every wait that follows a collective polls the stream instead of blocking; after
+ * PLONK_COMM_TIMEOUT_MS (default 120000) the communicator is aborted (ncclCommAbort) and the call returns
+ * PLONK_ERR_STATE on every surviving rank — the context then has no communicator and must be given a new one
+ * (plonk_comm_init) before the next sharded proof.  The host program should still tear the job down when one rank
+ * reports an error (bench.py does: the launcher kills the remaining ranks). */
 int plonk_comm_unique_id(uint8_t out[128]);
 int plonk_comm_init(plonk_ctx* ctx, const uint8_t unique_id[128], int rank, int world);
+int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world);
 int plonk_comm_selftest(plonk_ctx* ctx);
 int plonk_comm_destroy(plonk_ctx* ctx);
 

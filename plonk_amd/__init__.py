@@ -46,7 +46,7 @@ EXPORTS = [
     "plonk_prover_create", "plonk_prover_destroy", "plonk_prover_vk", "plonk_prover_size",
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
-    "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_selftest", "plonk_comm_destroy",
+    "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_info", "plonk_comm_selftest", "plonk_comm_destroy",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
     "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
     "plonk_public_parameters_check", "plonk_srs_load_public_parameters",
@@ -185,6 +185,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_comm_unique_id.argtypes = [vp]
     lib.plonk_comm_init.argtypes = [vp, vp, ci, ci]
     lib.plonk_comm_selftest.argtypes = [vp]
+    lib.plonk_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.plonk_comm_destroy.argtypes = [vp]
     _lib = lib
     return lib
@@ -469,6 +470,12 @@ class Context:
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         assert len(unique_id) == 128
         self._check(self.lib.plonk_comm_init(self.handle, unique_id, rank, world))
+
+    def comm_info(self) -> tuple[int, int]:
+        """(rank, size) as the RCCL communicator reports them"""
+        r, w = ctypes.c_int(-1), ctypes.c_int(-1)
+        self._check(self.lib.plonk_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
 
     def comm_selftest(self):
         self._check(self.lib.plonk_comm_selftest(self.handle))

@@ -13,7 +13,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "plonk_internal.hpp"
@@ -25,6 +28,9 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                 // optional: the abort path of comm_sync
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // optional: plonk_comm_info
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllToAll)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -46,6 +52,9 @@ static RcclApi* rccl_api() {
   api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
   api.AllToAll = (decltype(api.AllToAll))dlsym(h, "ncclAllToAll");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+  api.CommAbort = (decltype(api.CommAbort))dlsym(h, "ncclCommAbort");
+  api.CommCount = (decltype(api.CommCount))dlsym(h, "ncclCommCount");
+  api.CommUserRank = (decltype(api.CommUserRank))dlsym(h, "ncclCommUserRank");
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllToAll) {
     set_last_error("dlsym(librccl)", "missing RCCL entry point", __FILE__, __LINE__);
     dlclose(h);
@@ -66,6 +75,40 @@ static RcclApi* rccl_api() {
 
 static constexpr size_t COMM_STAGE = 16384;   // bytes per rank of a small (host-value) all-gather
 
+// The host driver of this platform only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment
+// BEFORE the HSA runtime starts, RCCL's device-memory exchange between processes fails (hipIpcGetMemHandle: invalid
+// argument).  The variable is read when the runtime initialises — normally the first HIP call of the process — so it is
+// set when this library is loaded; a value the host program has already chosen is left alone.  A host that initialises
+// HIP before loading libplonk_hip.so has to export it itself (include/plonk_hip.h, "Multi-GPU").
+__attribute__((constructor)) static void comm_default_ipc_mode() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
+
+// Wait for the main stream after a collective was queued on it.  A rank that failed (or never arrived) leaves its peers
+// inside the collective for ever, and a plain hipStreamSynchronize would hang with them: with a communicator the stream
+// is POLLED, and after PLONK_COMM_TIMEOUT_MS (default 120 s) the communicator is aborted (ncclCommAbort) and the call
+// returns PLONK_ERR_STATE, so that every surviving rank gets an error instead of a hang.
+static long comm_timeout_ms() {
+  static const long v = [] { const char* e = getenv("PLONK_COMM_TIMEOUT_MS"); const long t = e ? atol(e) : 0; return t > 0 ? t : 120000L; }();
+  return v;
+}
+int comm_sync(Ctx* c, hipStream_t st) {
+  if (!c->nccl_comm) { HIP_TRY(hipStreamSynchronize(st)); return PLONK_OK; }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; ++spin) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return PLONK_OK;
+    if (e != hipErrorNotReady) { set_last_error("hipStreamQuery", hipGetErrorString(e), __FILE__, __LINE__); return PLONK_ERR_HIP; }
+    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));   // first ~ms: busy poll (collectives take tens of us)
+    if ((spin & 1023) == 1023 &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_ms()) {
+      RcclApi* api = rccl_api();
+      if (api && api->CommAbort) (void)api->CommAbort((ncclComm_t)c->nccl_comm);
+      c->nccl_comm = nullptr;   // aborted: the context falls back to "no communicator" and every later sharded call fails loudly
+      set_last_error("comm_sync", "collective timed out (a peer rank failed or never joined): communicator aborted", __FILE__, __LINE__);
+      return PLONK_ERR_STATE;
+    }
+  }
+}
+
 // All-gather of `bytes` host bytes per rank; recv is rank-major.  RCCL when the context has a
 // communicator (staged through device buffers on the main stream), else the host callback.
 int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes) {
@@ -76,8 +119,7 @@ int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv,
     HIP_TRY(hipMemcpyAsync(c->comm_send, send, bytes, hipMemcpyHostToDevice, c->main_stream));
     RCCL_TRY(api, api->AllGather(c->comm_send, c->comm_recv, bytes, ncclUint8, (ncclComm_t)c->nccl_comm, c->main_stream));
     HIP_TRY(hipMemcpyAsync(recv, c->comm_recv, bytes * (size_t)l.world, hipMemcpyDeviceToHost, c->main_stream));
-    HIP_TRY(hipStreamSynchronize(c->main_stream));
-    return PLONK_OK;
+    return comm_sync(c, c->main_stream);
   }
   if (!l.fn) return (set_last_error("comm_allgather_host", "no communicator and no all-gather callback", __FILE__, __LINE__), PLONK_ERR_STATE);
   if (l.fn(l.user, send, recv, bytes) != 0) return (set_last_error("all-gather callback", "returned non-zero", __FILE__, __LINE__), PLONK_ERR_STATE);
@@ -173,6 +215,23 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   return PLONK_OK;
 }
 
+// What the communicator itself reports (ncclCommUserRank / ncclCommCount): bench.py prints it as n_ranks_rccl.
+int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world) {
+  if (!ctx) return PLONK_ERR_ARG;
+  Ctx& c = ctx->c;
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.nccl_comm) return (set_last_error("plonk_comm_info", "no communicator", __FILE__, __LINE__), PLONK_ERR_STATE);
+  RcclApi* api = rccl_api();
+  int r = c.comm_rank, w = c.comm_world;
+  if (api && api->CommCount && api->CommUserRank) {
+    RCCL_TRY(api, api->CommCount((ncclComm_t)c.nccl_comm, &w));
+    RCCL_TRY(api, api->CommUserRank((ncclComm_t)c.nccl_comm, &r));
+  }
+  if (rank) *rank = r;
+  if (world) *world = w;
+  return PLONK_OK;
+}
+
 // Both collectives once, with a rank-dependent pattern, checked on every rank.
 int plonk_comm_selftest(plonk_ctx* ctx) {
   if (!ctx) return PLONK_ERR_ARG;
@@ -203,7 +262,7 @@ int plonk_comm_selftest(plonk_ctx* ctx) {
   if (hipMemcpyAsync(ds, hs.data(), per * W, hipMemcpyHostToDevice, c.main_stream) != hipSuccess) rc = PLONK_ERR_HIP;
   if (!rc) rc = comm_alltoall_dev(&c, l, ds, dr, per);
   if (!rc && hipMemcpyAsync(hr.data(), dr, per * W, hipMemcpyDeviceToHost, c.main_stream) != hipSuccess) rc = PLONK_ERR_HIP;
-  if (hipStreamSynchronize(c.main_stream) != hipSuccess) rc = rc ? rc : PLONK_ERR_HIP;
+  { const int rs = comm_sync(&c, c.main_stream); if (rs) rc = rc ? rc : rs; }
   (void)hipFree(ds);
   (void)hipFree(dr);
   if (rc) return rc;

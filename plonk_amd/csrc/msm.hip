@@ -1156,9 +1156,13 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
   // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
   static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
-  // PLONK_MSM_ORDER=1: lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel)
-  static const bool acc_ordered = [] { const char* e = getenv("PLONK_MSM_ORDER"); return e && e[0] == '1'; }();
-  if (acc_ordered) {
+  // lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default where slices are 32
+  // entries long (m > 2^19; r03a same-box A/B at 2^20: accumulate 26.5 -> 25.7 ms per proof, the waves no longer wait
+  // for their longest lane); shorter slices (smaller m) leave the accumulation latency-bound and the ordering loses
+  // (r02e: +1.1 ms at 2^16).  PLONK_MSM_ORDER=1 / 0 forces either.
+  static const int order_env = [] { const char* e = getenv("PLONK_MSM_ORDER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+  const bool acc_ordered = order_env >= 0 ? order_env == 1 : bt.ksl >= 32;
+  if (acc_ordered && !acc_lds) {
     rc = msm_order_slices(c, bt);
     if (rc) return rc;
     hipLaunchKernelGGL(msm_accumulate_ordered_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,

@@ -150,6 +150,7 @@ struct CommLink {
   void* user = nullptr;
 };
 int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes);
+int comm_sync(Ctx* c, hipStream_t st);   // stream wait that cannot hang on a dead peer (polls, aborts the communicator on time-out)
 int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
 
 // msm.hip

@@ -1264,7 +1264,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     }
     PTRY(poly_eval(c, ea, 15, max_len, p->evout));
     HIP_TRY(hipMemcpyAsync(p->ev_host, p->evout, 15 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    PTRY(comm_sync(c, c->stream));   // the all-to-all of the quotient precedes this on the stream: never hang on a dead peer
     std::vector<Fr> all(15 * (size_t)W);
     PTRY(comm_allgather_host(c, p->link, p->ev_host, all.data(), 15 * sizeof(Fr)));
     Fr h[15];
@@ -1360,7 +1360,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   // the suffix sums of the ranges above this one: all-gather of (total_z, total_zw) per rank
   HIP_TRY(hipMemcpyAsync(p->ev_host, p->scratch, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(p->ev_host + 1, p->scratch2, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  PTRY(comm_sync(c, c->stream));
   std::vector<Fr> tot(2 * (size_t)W);
   PTRY(comm_allgather_host(c, p->link, p->ev_host, tot.data(), 2 * sizeof(Fr)));
   Fr carry_z = Fr::zero(), carry_zw = Fr::zero(), num_at_z = Fr::zero();
