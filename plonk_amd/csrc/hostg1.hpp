@@ -177,11 +177,13 @@ static H1 h1_add(const H1& a, const H1& b) {
   r.ZZZ = fp64_mul(fp64_mul(a.ZZZ, b.ZZZ), PPP);
   return r;
 }
-// W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j  from the 16 bit sums of msm_bits_kernel
-// (rows T_0..T_7, columns T'_0..T'_6, C_128): Horner over U_0..U_14.
-static G1 finish_bit_sums(const G1* bits) {
-  H1 u[16];
-  for (int k = 0; k < 16; ++k) {
+// W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j  from the first 16 bit sums of msm_bits_kernel
+// (rows T_0..T_7, columns T'_0..T'_6, C_128): Horner over U_0..U_14.  W weighs bucket b with b + 1 — the commitment
+// for window-table entries.  Bit-position entries (width-17 NAF, msm_recode.cuh) weigh 2 b + 1: their commitment is
+// 2 W - S with S = bits[16], the sum of all buckets.
+static G1 finish_bit_sums(const G1* bits, bool bitpos) {
+  H1 u[17];
+  for (int k = 0; k < 17; ++k) {
     memcpy(u[k].X.l, bits[k].X.l, 48); memcpy(u[k].Y.l, bits[k].Y.l, 48);
     memcpy(u[k].ZZ.l, bits[k].ZZ.l, 48); memcpy(u[k].ZZZ.l, bits[k].ZZZ.l, 48);
   }
@@ -191,6 +193,13 @@ static G1 finish_bit_sums(const G1* bits) {
   for (int j = 1; j < 8; ++j) U[7 + j] = u[j];
   H1 acc = U[14];
   for (int j = 13; j >= 0; --j) acc = h1_add(h1_dbl(acc), U[j]);
+  if (bitpos) {
+    H1 negS = u[16];
+    Fp64 zero;
+    memset(&zero, 0, sizeof zero);
+    if (!negS.inf()) negS.Y = fp64_sub(zero, negS.Y);   // p - Y
+    acc = h1_add(h1_dbl(acc), negS);
+  }
   G1 r;
   if (acc.inf()) return G1::identity();
   memcpy(r.X.l, acc.X.l, 48); memcpy(r.Y.l, acc.Y.l, 48); memcpy(r.ZZ.l, acc.ZZ.l, 48); memcpy(r.ZZZ.l, acc.ZZZ.l, 48);

@@ -5,11 +5,12 @@
 // The result is a unique group element, so the schedule is free; this one is
 // sized for 288 GB of HBM rather than copied from the CPU Pippenger:
 //
-//   * plonk_srs_load precomputes T[w][i] = 2^(16 w) * P_i for the 16 windows
-//     (16 x 96 B per SRS point; 1.5 GiB at 2^20 points).  All windows then share
-//     ONE set of 2^15 signed-digit buckets, so there is no per-window bucket
-//     reduction and no Horner doubling chain at the end.
-//   * bucket grouping (msm_sort.hip): scalars -> 16 signed 16-bit digits -> table entries
+//   * plonk_srs_load precomputes one table row per BIT POSITION, T[r][i] = 2^r * P_i, r < 256 (128 B per entry:
+//     32 GiB at 2^20 points), when that fits comfortably in the free HBM, else the 16 window rows
+//     T[w][i] = 2^(16 w) * P_i (2 GiB).  All rows share ONE set of 2^15 signed-digit buckets, so there is no
+//     per-window bucket reduction and no Horner doubling chain at the end; with a row per bit the digits are a
+//     width-17 NAF — 14.7 instead of 16 additions per scalar (msm_recode.cuh).
+//   * bucket grouping (msm_sort.hip): scalars -> at most 16 signed digits -> table entries
 //                    (index | sign) grouped by bucket with a hand-written two-level counting
 //                    sort; bucket offsets and slice offsets (a slice = at most MSM_KSL entries
 //                    of one bucket) fall out of it.
@@ -112,16 +113,20 @@ __device__ __forceinline__ void st_g1r(G1RSlot* p, const G1R& v) {
 // ---------------------------------------------------------------------------
 // SRS tables
 // ---------------------------------------------------------------------------
-// T[w * n + i] = 2^(16 w) * P_i, affine, in the reduced-radix form (x, y < 2p).  One lane per point: 15 x 16
-// doublings in XYZZ coordinates, and ONE Fp inversion for the 15 normalisations (Montgomery's trick along the lane's
-// own windows: the unnormalised X, Y wait in their table slots, ZZ, ZZZ and the running product of the ZZ * ZZZ in a
-// scratch array of 3 x 64 B per window and point; a Fermat inversion is ~570 products, as much as 60 doublings, and
-// one per window made the inversions 4/5 of this kernel).  One-off per commit key, outside every timed region.
-// `pts` holds points [first, first + count) of the key (a chunk of the stream in plonk_srs_load); the table
-// row of window w starts at w * n.  scratch: [(MSM_W - 1) * 3][count] slots.
-static constexpr uint64_t SRS_TABLE_CHUNK = 1ull << 18;   // points per launch: bounds the scratch at 720 MiB
+// T[r * n + i] = 2^(r * step) * P_i, affine, in the reduced-radix form (x, y < 2p): `rows` = 16, step = 16 (window
+// tables) or rows = 256, step = 1 (bit-position tables).  One lane per point: (rows - 1) * step doublings in XYZZ
+// coordinates, and ONE Fp inversion for the rows - 1 normalisations (Montgomery's trick along the lane's own rows: the
+// unnormalised X, Y wait in their table slots, ZZ, ZZZ and the running product of the ZZ * ZZZ in a scratch array of
+// 3 x 64 B per row and point; a Fermat inversion is ~570 products, as much as 60 doublings, and one per row made the
+// inversions 4/5 of this kernel).  The doubling chain has the same length for both kinds of table (240 / 255
+// doublings); bit-position tables store — and normalise — every step of it.  One-off per commit key, outside every
+// timed region.  `pts` holds points [first, first + count) of the key (a chunk of the stream in plonk_srs_load); row r
+// starts at r * n.  scratch: [(rows - 1) * 3][count] slots.
+static uint64_t srs_table_chunk_points(uint32_t rows) {   // points per launch: bounds the scratch (720 MiB / 3.1 GiB)
+  return rows == MSM_ROWS_BITPOS ? 1ull << 16 : 1ull << 18;
+}
 __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __restrict__ table, uint64_t n,
-                                 uint64_t first, uint64_t count, Fp28Slot* __restrict__ scratch) {
+                                 uint64_t first, uint64_t count, Fp28Slot* __restrict__ scratch, uint32_t rows, uint32_t step) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= count) return;
   const uint64_t i = first + j;
@@ -130,8 +135,8 @@ __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __
   st_f28(&table[i].x, p.X);
   st_f28(&table[i].y, p.Y);
   Fp28 run = Fp28::one();
-  for (int w = 1; w < MSM_W; ++w) {
-    for (int k = 0; k < MSM_C; ++k) p = p.dbl();          // P_i has prime order: never the identity
+  for (uint32_t w = 1; w < rows; ++w) {
+    for (uint32_t k = 0; k < step; ++k) p = p.dbl();          // P_i has prime order: never the identity
     Fp28Slot* sc = scratch + (uint64_t)(w - 1) * 3 * count + j;
     st_f28(&table[(uint64_t)w * n + i].x, p.X.normalized());
     st_f28(&table[(uint64_t)w * n + i].y, p.Y.normalized());
@@ -141,7 +146,7 @@ __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __
     st_f28(sc + 2 * count, run);
   }
   Fp28 inv = fp28_inv(run);                                // 1 / prod_w ZZ_w ZZZ_w
-  for (int w = MSM_W - 1; w >= 1; --w) {
+  for (uint32_t w = rows - 1; w >= 1; --w) {
     const Fp28Slot* sc = scratch + (uint64_t)(w - 1) * 3 * count + j;
     const Fp28 zz = ld_f28(sc), zzz = ld_f28(sc + count);
     const Fp28 before = w > 1 ? ld_f28(sc - 3 * count + 2 * count) : Fp28::one();   // running product up to w - 1
@@ -575,6 +580,11 @@ __global__ void __launch_bounds__(256) msm_heavy_bucket_kernel(const uint32_t* _
 // doubles the row part 7 times and tree-sums everything: ~24 dependent additions instead of the
 // ~70 of a running-sum-per-chunk scheme — these kernels are pure latency (one wave per SIMD).
 static constexpr uint32_t RC_ROWS = 256, RC_COLS = 128;
+__device__ __forceinline__ G1R g1r_neg(const G1R& p) {   // -P: Y -> 16p - Y (Y < 8p), canonicalised
+  G1R r = p;
+  if (!p.is_identity()) r.Y = Fp28::sub<16>(Fp28::zero(), p.Y).canon();
+  return r;
+}
 static_assert(RC_ROWS * RC_COLS == MSM_NB, "row/column split must cover the bucket range");
 
 // One wave (64 lanes) per sum, four sums per workgroup: a lane adds 2 (rows) or 4 (columns)
@@ -623,8 +633,9 @@ __global__ void __launch_bounds__(384) msm_final_kernel(MsmBatch bt, const G1RSl
     __syncthreads();
   }
   // rows: sum_h h R_h = sum_{k=1..255} Suf_k  (drop k = 0), times 128 ; cols: sum_l l C_l = sum_{k=0..127} Suf'_k
+  G1R total = G1R::identity();                          // lane 0: Suf_0 = S, the sum of all buckets
   if (is_row) {
-    if (t == 0) acc = G1R::identity();
+    if (t == 0) { total = acc; acc = G1R::identity(); }
     else for (int k = 0; k < 7; ++k) acc = acc.dbl();
   }
   for (uint32_t d = 256; d >= 1; d >>= 1) {             // tree over 384 (< 512) entries
@@ -633,7 +644,10 @@ __global__ void __launch_bounds__(384) msm_final_kernel(MsmBatch bt, const G1RSl
     if (t < d && t + d < RC_ROWS + RC_COLS) acc = acc.add(sh[t + d]);
     __syncthreads();
   }
-  if (t == 0) st_g1(out, acc.to_g1());
+  if (t == 0) {
+    if (bt.rows == MSM_ROWS_BITPOS) acc = acc.dbl().add(g1r_neg(total));   // entries weigh 2 b + 1: 2 W - S
+    st_g1(out, acc.to_g1());
+  }
 }
 
 // Alternative tail used by the device prover (prover.hip): instead of finishing W on one
@@ -659,8 +673,10 @@ __global__ void __launch_bounds__(128) msm_bits_kernel(MsmBatch bt, const G1RSlo
       const uint32_t l = ((t >> j) << (j + 1)) | (1u << j) | (t & ((1u << j) - 1u));
       acc = ld_g1r(rc + RC_ROWS + (l - 1));
     }
-  } else if (t == 0) {
-    acc = ld_g1r(rc + RC_ROWS + (RC_COLS - 1));   // weight 128
+  } else if (u == 15) {
+    if (t == 0) acc = ld_g1r(rc + RC_ROWS + (RC_COLS - 1));   // weight 128
+  } else {                           // u == 16: S = the sum of all 256 rows = of all buckets (bit-position entries: 2 W - S)
+    acc = ld_g1r(rc + t).add(ld_g1r(rc + t + 128));
   }
   for (uint32_t d = 64; d >= 1; d >>= 1) {
     sh[t] = acc;
@@ -769,16 +785,18 @@ __global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G
   G1* __restrict__ out = bt.out[blockIdx.y] + blockIdx.x;
   const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
   G1R acc = G1R::identity();
-  for (uint32_t i = L; i < 128; i += 64) {
+  for (uint32_t i = L; i < (u == 16 ? 256u : 128u); i += 64) {
     G1R p = G1R::identity();
-    if (u < 8) {                       // 128 of the 256 rows
+    if (u == 16) {                     // S = the sum of all 256 rows = of all buckets (bit-position entries: 2 W - S)
+      p = ld_g1r(rc + i);
+    } else if (u < 8) {                // 128 of the 256 rows
       const uint32_t h = ((i >> u) << (u + 1)) | (1u << u) | (i & ((1u << u) - 1u));
       p = ld_g1r(rc + h);
     } else if (u < 15) {               // 64 of the column weights 1..127, both halves
       const uint32_t j = u - 8, half = i >> 6, tt = i & 63;
       const uint32_t l = ((tt >> j) << (j + 1)) | (1u << j) | (tt & ((1u << j) - 1u));
       p = ld_g1r(rc + RC_ROWS + half * RC_COLS + (l - 1));
-    } else if (i < 2) {                // weight 128
+    } else if (u == 15 && i < 2) {     // weight 128
       p = ld_g1r(rc + RC_ROWS + i * RC_COLS + (RC_COLS - 1));
     }
     acc = g1r_add_quad(acc, p, q);
@@ -875,21 +893,42 @@ __global__ void msm_identity_kernel(G1* out) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-// allocate the window tables of an n-point key (replacing the old key); the rows are filled by srs_table_chunk
+// Rows of the tables of an n-point key.  A row per bit position (256 rows, 32 KiB per point) saves 8 % of the
+// additions of every MSM over the key; it is chosen when the tables take at most a third of the HBM that is free right
+// now (2^20 points: 32 GiB, twice per prover context — commit key and Lagrange-basis key — of 288 GB), else the 16
+// window rows (2^22 points: 8.6 GiB instead of 137).  PLONK_MSM_TABLE=window | bitpos forces either.
+uint32_t msm_table_rows(uint64_t n) {
+  if (const char* e = getenv("PLONK_MSM_TABLE")) {
+    if (e[0] == 'w') return MSM_ROWS_WINDOW;
+    if (e[0] == 'b') return (uint64_t)MSM_ROWS_BITPOS * n <= (1ull << 31) ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
+  }
+  if ((uint64_t)MSM_ROWS_BITPOS * n > (1ull << 31)) return MSM_ROWS_WINDOW;   // 31-bit table index of an entry
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MSM_ROWS_WINDOW;
+  const uint64_t need = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_BITPOS * n + sizeof(Fp28Slot) * 3 * (MSM_ROWS_BITPOS - 1) * (1ull << 16);
+  return need <= fr / 3 ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
+}
+static int table_index_check(uint32_t rows, uint64_t n) {
+  if ((uint64_t)rows * n > (1ull << 31)) return (plonk::set_last_error("invalid argument", "commit key: table rows * points must be <= 2^31 (31-bit table index of an entry)", __FILE__, __LINE__), PLONK_ERR_ARG);
+  return PLONK_OK;
+}
+// allocate the tables of an n-point key (replacing the old key); the rows are filled by srs_table_chunk
 int srs_table_begin(Ctx* c, uint64_t n) {
   ++c->srs_gen;   // provers built on the previous key refuse to prove (prover.hip)
-  if (c->srs_table) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; }
+  if (c->srs_table) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; c->srs_rows = 0; }
   if (n == 0) return PLONK_OK;
-  if ((uint64_t)MSM_W * n > (1ull << 27)) return (plonk::set_last_error("invalid argument", "commit key: MSM_W * points must be <= 2^27 (27-bit table index of the bucket sort)", __FILE__, __LINE__), PLONK_ERR_ARG);
-  HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)MSM_W * n));
+  const uint32_t rows = msm_table_rows(n);
+  { const int rc = table_index_check(rows, n); if (rc) return rc; }
+  HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)rows * n));
+  c->srs_rows = rows;
   return PLONK_OK;
 }
 // scratch of srs_table_kernel, kept on the context between the chunks of one load
-static int srs_table_scratch(Ctx* c, uint64_t count) {
-  if (c->table_scratch_pts >= count) return PLONK_OK;
+static int srs_table_scratch(Ctx* c, uint64_t slots) {
+  if (c->table_scratch_pts >= slots) return PLONK_OK;
   if (c->table_scratch) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->table_scratch)); c->table_scratch = nullptr; c->table_scratch_pts = 0; }
-  HIP_TRY(hipMalloc(&c->table_scratch, sizeof(Fp28Slot) * 3 * (MSM_W - 1) * count));
-  c->table_scratch_pts = count;
+  HIP_TRY(hipMalloc(&c->table_scratch, sizeof(Fp28Slot) * slots));
+  c->table_scratch_pts = slots;   // capacity in 64-byte slots
   return PLONK_OK;
 }
 void srs_table_scratch_free(Ctx* c) {   // after the stream that ran the table kernels was synchronised
@@ -899,32 +938,37 @@ void srs_table_scratch_free(Ctx* c) {   // after the stream that ran the table k
 }
 // table entries of points [first, first + count), read from pts_dev[0 .. count), on `st` (always the context's main
 // stream: the launches share one scratch array and rely on stream order)
-static int srs_table_launch(Ctx* c, const G1Affine* pts_dev, G1AffineR* table, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
-  for (uint64_t off = 0; off < count; off += SRS_TABLE_CHUNK) {
-    const uint64_t cnt = count - off < SRS_TABLE_CHUNK ? count - off : SRS_TABLE_CHUNK;
-    const int rc = srs_table_scratch(c, cnt);
+static int srs_table_launch(Ctx* c, const G1Affine* pts_dev, G1AffineR* table, uint32_t rows, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
+  const uint64_t chunk = srs_table_chunk_points(rows);
+  const uint32_t step = rows == MSM_ROWS_BITPOS ? 1u : (uint32_t)MSM_C;
+  for (uint64_t off = 0; off < count; off += chunk) {
+    const uint64_t cnt = count - off < chunk ? count - off : chunk;
+    const int rc = srs_table_scratch(c, 3ull * (rows - 1) * cnt);
     if (rc) return rc;
     hipLaunchKernelGGL(srs_table_kernel, dim3((uint32_t)((cnt + 63) / 64)), dim3(64), 0, st, pts_dev + off, table, n, first + off, cnt,
-                       (Fp28Slot*)c->table_scratch);
+                       (Fp28Slot*)c->table_scratch, rows, step);
     HIP_TRY(hipGetLastError());
   }
   return PLONK_OK;
 }
 int srs_table_chunk(Ctx* c, const G1Affine* pts_dev, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
   if (!count) return PLONK_OK;
-  return srs_table_launch(c, pts_dev, (G1AffineR*)c->srs_table, n, first, count, st);
+  return srs_table_launch(c, pts_dev, (G1AffineR*)c->srs_table, c->srs_rows, n, first, count, st);
 }
-int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out) {
+int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out, uint32_t* rows_out) {
   *table_out = nullptr;
+  *rows_out = 0;
   if (n == 0) return PLONK_OK;
-  if ((uint64_t)MSM_W * n > (1ull << 27)) return (plonk::set_last_error("invalid argument", "window tables: MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
+  const uint32_t rows = msm_table_rows(n);
+  { const int rc = table_index_check(rows, n); if (rc) return rc; }
   G1AffineR* t = nullptr;
-  HIP_TRY(hipMalloc((void**)&t, sizeof(G1AffineR) * (size_t)MSM_W * n));
-  int rc = srs_table_launch(c, pts_dev, t, n, 0, n, c->stream);
+  HIP_TRY(hipMalloc((void**)&t, sizeof(G1AffineR) * (size_t)rows * n));
+  int rc = srs_table_launch(c, pts_dev, t, rows, n, 0, n, c->stream);
   if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
   srs_table_scratch_free(c);
   if (rc) { (void)hipFree(t); return rc; }
   *table_out = t;
+  *rows_out = rows;
   return PLONK_OK;
 }
 
@@ -935,11 +979,6 @@ int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_ou
 // prover.  The last kernel undoes the bit reversal, multiplies by 1/n, normalises to affine and appends the two
 // points the blinding terms of a wire polynomial need: [tau^n] G - G and [tau^(n+1)] G - [tau] G.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ G1R g1r_neg(const G1R& p) {
-  G1R r = p;
-  if (!p.is_identity()) r.Y = Fp28::sub<16>(Fp28::zero(), p.Y).canon();   // 16p - Y  (Y < 8p)  ->  [0, p)
-  return r;
-}
 __device__ __forceinline__ G1R g1r_mul_fr(const G1R& p, const Fr& k_canonical) {   // 255-bit double-and-add
   G1R acc = G1R::identity();
   for (int w = 7; w >= 0; --w)
@@ -1096,7 +1135,7 @@ int msm_reserve(Ctx* c, uint64_t m) {
     for (void** q : {(void**)&w.tmp_words, (void**)&w.entries, (void**)&w.partial, &w.seg_sum}) {
       if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     }
-    HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint32_t) * MSM_W * cap * KB));  // words grouped by coarse bin
+    HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint64_t) * MSM_W * cap * KB));  // words grouped by coarse bin (64-bit words for tables above 2^27 entries)
     HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
     w.cap_slices = msm_slice_cap(cap);
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
@@ -1114,10 +1153,11 @@ void prof_end(Ctx* c, int slot);
 // latency-bound reduction kernels run once per group instead of once per commitment
 // (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums,
-                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split) {
+                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split, uint32_t table_rows) {
   if (count <= 0) return PLONK_OK;
   if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-  if (!table) { table = c->srs_table; table_n = c->srs_n; }
+  if (!table) { table = c->srs_table; table_n = c->srs_n; table_rows = c->srs_rows; }
+  if (table && table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_BITPOS) return (plonk::set_last_error("invalid argument", "msm: table rows", __FILE__, __LINE__), PLONK_ERR_ARG);
   uint64_t mmax = 0;
   for (int k = 0; k < count; ++k) {
     if (m[k] > table_n) return PLONK_ERR_DEGREE;
@@ -1141,6 +1181,8 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   bt.cap_slices = w.cap_slices;
   bt.table = table;
   bt.table_n = table_n;
+  bt.rows = table_rows;
+  bt.wide = (uint64_t)table_rows * table_n > (1ull << 27) ? 1u : 0u;
   for (int k = 0; k < count; ++k) {
     bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k];
     bt.tail[k] = tail_dev ? tail_dev[k] : nullptr;

@@ -1,0 +1,91 @@
+// Scalar -> table entries: the two digit recodings of the MSM (msm_sort.hip), host- and device-callable so that
+// tests/test_field_host.py checks them on the CPU against the big-int model (tests/msm_wide_model.py).
+//
+// Both produce at most MSM_W = 16 non-zero digits per scalar s < 2^255, s = sum_j d_j * 2^(row_j), and call
+//     f(slot j, row_j, bucket, sign)
+// for each of them in order of increasing row; a table entry T[row][i] = 2^row * P_i (bit-position tables) or
+// 2^(16 row) * P_i (window tables) then contributes sign * weight(bucket) * T[row][i].
+//
+//   * window tables (16 rows): signed 16-bit windows, d in [-2^15, 2^15], bucket = |d| - 1, weight = bucket + 1.
+//     16 digits per scalar (a digit is zero with probability 2^-16).
+//   * bit-position tables (256 rows, round 3): width-17 non-adjacent form.  A digit may start at ANY bit, so it is taken
+//     where the remaining value is odd: d odd, |d| < 2^16, bucket = |d| >> 1 — the SAME 2^15 buckets hold 17-bit
+//     digits, weight = 2 * bucket + 1, and after a digit the next 16 bits are zero: consecutive digits are >= 17 bits
+//     apart and the expected distance is 18 (the run of equal bits after a digit has mean length 1): 254.9 / 18 + 1/2 =
+//     14.7 additions per scalar instead of 16 (measured over random scalars: 14.67).  The price is a table row per bit position — 256 x 128 B per point,
+//     32 GiB at 2^20 points — which is what 288 GB of HBM is for (profiles/r03a/gather_tlb.txt: the random 128-B
+//     gathers of msm_accumulate run at the same rate over 2, 34 or 137 GiB of tables).
+#pragma once
+#include "field.cuh"
+
+namespace plonk {
+
+static constexpr int MSM_DIGITS = 16;          // most non-zero digits of a scalar under either recoding (= MSM_W)
+static constexpr uint32_t MSM_ROWS_WINDOW = 16, MSM_ROWS_BITPOS = 256;
+static constexpr uint32_t MSM_NAF_W = 17;      // digit width of the bit-position recoding: odd |d| < 2^16
+
+// Signed 16-bit windows, least significant first (carry into the next window when the value exceeds 2^15).
+template <class S, class F>
+HD void for_each_digit_window(const S& s, F&& f) {
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < MSM_DIGITS; ++w) {
+    const uint32_t raw = (s.l[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
+    const uint32_t v = raw + carry;
+    carry = 0;
+    if (v > 32768u) {            // negative digit d = v - 65536
+      carry = 1;
+      const uint32_t mag = 65536u - v;
+      if (mag) f(w, (uint32_t)w, mag - 1, 1u);
+    } else if (v) {
+      f(w, (uint32_t)w, v - 1, 0u);
+    }
+  }
+}
+
+// limb k of an 8 x 32-bit integer with a run-time k (a select chain: a register array cannot be indexed); k >= 8 -> 0
+template <class S>
+HD uint32_t limb_select(const S& s, uint32_t k) {
+  uint32_t r = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) r = (k == j) ? s.l[j] : r;
+  return r;
+}
+// bits [p, p + 32) of the 256-bit integer (zero beyond bit 255)
+template <class S>
+HD uint32_t bits32_at(const S& s, uint32_t p) {
+  const uint32_t k = p >> 5, sh = p & 31;
+  const uint64_t v = ((uint64_t)limb_select(s, k + 1) << 32) | limb_select(s, k);
+  return (uint32_t)(v >> sh);
+}
+
+// Width-17 NAF of a canonical scalar (s < 2^255), least significant digit first.  `carry` = 1 after a negative
+// digit: the value that remains above the digit is (s >> p) + carry, and it is odd exactly where bit p differs from the
+// carry.  The top digit starts at bit 255 at the latest (s < 2^255 stops every carry there), so rows 0..255 suffice.
+template <class S, class F>
+HD void for_each_digit_bitpos(const S& s, F&& f) {
+  uint32_t p = 0, carry = 0;
+#pragma unroll
+  for (int j = 0; j < MSM_DIGITS; ++j) {
+    while (p < 256) {                                  // next bit that differs from the carry
+      const uint32_t x = carry ? ~bits32_at(s, p) : bits32_at(s, p);
+      if (x) { p += (uint32_t)__builtin_ctz(x); break; }
+      p += 32;
+    }
+    if (p >= 256) break;
+    const uint32_t v = (bits32_at(s, p) & ((1u << MSM_NAF_W) - 1u)) + carry;   // odd, < 2^17
+    const uint32_t neg = v >> (MSM_NAF_W - 1);                                 // v > 2^16: the digit is v - 2^17
+    const uint32_t mag = neg ? (1u << MSM_NAF_W) - v : v;                      // odd, < 2^16
+    f(j, p, mag >> 1, neg);
+    carry = neg;
+    p += MSM_NAF_W;
+  }
+}
+
+template <class S, class F>
+HD void for_each_digit(const S& s, uint32_t rows, F&& f) {
+  if (rows == MSM_ROWS_BITPOS) for_each_digit_bitpos(s, f);
+  else for_each_digit_window(s, f);
+}
+
+}  // namespace plonk

@@ -3,16 +3,19 @@
 // primitive.  Order inside a bucket is irrelevant to a sum, which is what makes this cheaper than a
 // general (stable) radix sort:
 //
-//   msm_hist_kernel       scalars -> signed 16-bit digits -> histogram of the COARSE bin (top 11 of the
-//                         15 bucket bits) in LDS, flushed with one global atomic per (workgroup, bin).
-//                         Zero digits are dropped here and never touched again.
+//   msm_hist_kernel       scalars -> digits (msm_recode.cuh: signed 16-bit windows for window tables, width-17 NAF
+//                         for bit-position tables) -> histogram of the COARSE bin (top 11 of the 15 bucket bits) in
+//                         LDS, flushed with one global atomic per (workgroup, bin).  Zero digits are dropped here and
+//                         never touched again.
 //   msm_coarse_scan       2048 counts -> coarse offsets (one workgroup per commitment).
 //   msm_partition_kernel  scalars again (32 B per term instead of a 6-byte key/value pair per window):
 //                         a workgroup owns a tile of 2048 scalars = 32768 entries, ranks them per coarse
 //                         bin with LDS atomics, reserves its run in every bin with one global atomic,
 //                         regroups the tile in LDS (128 KiB of the CU's 160 KiB) and writes runs of
-//                         ~16 consecutive 4-byte words.  The word carries what the second level needs:
-//                         fine bucket (4 bits) | sign | table index (27 bits).
+//                         ~16 consecutive words.  The word carries what the second level needs: fine bucket (4 bits) |
+//                         sign | table index — 32 bits while the tables have at most 2^27 entries, 64 bits beyond
+//                         (bit-position tables of more than 2^19 points; the LDS staging keeps a 24-bit tile-local form
+//                         either way: fine | sign | row | index inside the tile).
 //   msm_fine_kernel       one workgroup per coarse bin (~8192 entries, held in registers between the two
 //                         steps): histogram of the 16 fine buckets, then scatter into the final entry array;
 //                         writes the bucket offsets on the way, so no pass over 32768 counters is needed.
@@ -32,9 +35,6 @@ static constexpr uint32_t COARSE = MSM_NB >> FINE_BITS;          // 2048 coarse 
 #ifndef PLONK_SORT_TILE
 #define PLONK_SORT_TILE 2048
 #endif
-#ifndef PLONK_PARTITION_DIRECT
-#define PLONK_PARTITION_DIRECT 0
-#endif
 static constexpr uint32_t TILE = PLONK_SORT_TILE;                // scalars per workgroup of the partition pass
 static constexpr uint32_t SORT_T = 1024;                         // threads per workgroup
 static constexpr uint32_t PER_T = TILE / SORT_T;                 // scalars per thread (partition)
@@ -43,10 +43,25 @@ static constexpr uint32_t PER_T = TILE / SORT_T;                 // scalars per 
 #endif
 static constexpr uint32_t HIST_PER = PLONK_HIST_PER;             // scalars per thread of the histogram pass
 static constexpr uint32_t HIST_TILE = SORT_T * HIST_PER;
-static constexpr uint32_t IDX_BITS = 27;                         // table index field of the intermediate word
-static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
 static_assert(COARSE == 2 * SORT_T, "scan / reservation loops assume two coarse bins per thread");
-static_assert(IDX_BITS + 1 + FINE_BITS == 32, "intermediate word layout");
+// Intermediate (coarse-partitioned) word.  Narrow: fine (4) | sign (1) | table index (27).  Wide: fine in the upper
+// half, the lower half IS the final entry (sign << 31 | 31-bit table index).
+static constexpr uint32_t IDX_BITS = 27;
+static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
+static_assert(IDX_BITS + 1 + FINE_BITS == 32, "narrow intermediate word layout");
+template <class WordT> struct SortWord;
+template <> struct SortWord<uint32_t> {
+  __device__ static __forceinline__ uint32_t make(uint32_t fine, uint32_t sign, uint64_t idx) { return (fine << (IDX_BITS + 1)) | (sign << IDX_BITS) | (uint32_t)idx; }
+  __device__ static __forceinline__ uint32_t fine(uint32_t w) { return w >> (IDX_BITS + 1); }
+  __device__ static __forceinline__ uint32_t entry(uint32_t w) { return (w & IDX_MASK) | (((w >> IDX_BITS) & 1u) << 31); }
+};
+template <> struct SortWord<uint64_t> {
+  __device__ static __forceinline__ uint64_t make(uint32_t fine, uint32_t sign, uint64_t idx) { return ((uint64_t)fine << 32) | ((uint64_t)sign << 31) | idx; }
+  __device__ static __forceinline__ uint32_t fine(uint64_t w) { return (uint32_t)(w >> 32); }
+  __device__ static __forceinline__ uint32_t entry(uint64_t w) { return (uint32_t)w; }
+};
+// tile-local form staged in LDS by msm_partition: fine (4) | sign (1) | table row (8) | scalar inside the tile (11)
+static_assert(TILE <= 2048, "tile-local word: 11 bits of scalar index");
 
 __device__ __forceinline__ Fr ld_scalar(const Fr* p);
 // scalar i of commitment kb: the main array below the split, the tail array above
@@ -69,27 +84,8 @@ __device__ __forceinline__ Fr scalar_canonical(const Fr& mont) {
   return Fr29::mul(Fr29::from_fr(mont), c32).to_fr();
 }
 
-// Signed 16-bit recoding, least significant window first.  f(w, bucket, sign) is called for every
-// NON-ZERO digit: bucket = |d| - 1 in [0, MSM_NB), sign = 1 for a negative digit.
-template <class F>
-__device__ __forceinline__ void for_each_digit(const Fr& s, F&& f) {
-  uint32_t carry = 0;
-#pragma unroll
-  for (int w = 0; w < MSM_W; ++w) {
-    const uint32_t raw = (s.l[w >> 1] >> ((w & 1) * 16)) & 0xffffu;
-    const uint32_t v = raw + carry;
-    carry = 0;
-    if (v > MSM_NB) {            // negative digit d = v - 65536
-      carry = 1;
-      const uint32_t mag = 65536u - v;
-      if (mag) f(w, mag - 1, 1u);
-    } else if (v) {
-      f(w, v - 1, 0u);
-    }
-  }
-}
-
 // ---- level 1a: coarse histogram -------------------------------------------------------------------
+template <bool BITPOS>
 __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t* __restrict__ coarse_cnt_all) {
   __shared__ uint32_t hist[COARSE];
   const int kb = blockIdx.y;
@@ -111,7 +107,8 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
     const uint64_t i = base + t + (uint64_t)k * SORT_T;
     if (i < m) {
       const Fr s = scalar_canonical(raw[k]);
-      for_each_digit(s, [&](int, uint32_t bucket, uint32_t) { atomicAdd(&hist[bucket >> FINE_BITS], 1u); });
+      auto count = [&](int, uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&hist[bucket >> FINE_BITS], 1u); };
+      if (BITPOS) for_each_digit_bitpos(s, count); else for_each_digit_window(s, count);
     }
   }
   __syncthreads();
@@ -175,15 +172,16 @@ __global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t*
 
 // ---- level 1c: partition into the coarse bins -----------------------------------------------------
 // dynamic LDS: stage[TILE * MSM_W] words, then hist / loff / gbase [COARSE] each
-static constexpr size_t PARTITION_LDS = ((PLONK_PARTITION_DIRECT ? 0 : (size_t)TILE * MSM_W) + 3 * COARSE) * sizeof(uint32_t);
+static constexpr size_t PARTITION_LDS = ((size_t)TILE * MSM_W + 3 * COARSE) * sizeof(uint32_t);
 
+template <bool BITPOS, class WordT>
 __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint64_t srs_n,
                                                                const uint32_t* __restrict__ coarse_off_all,
                                                                uint32_t* __restrict__ coarse_cur_all,
-                                                               uint32_t* __restrict__ tmp_all) {
+                                                               WordT* __restrict__ tmp_all) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* stage = lds;                          // TILE * MSM_W
-  uint32_t* hist = lds + (PLONK_PARTITION_DIRECT ? 0 : TILE * MSM_W);   // COARSE: entries of this tile per bin
+  uint32_t* hist = lds + TILE * MSM_W;            // COARSE: entries of this tile per bin
   uint32_t* loff = hist + COARSE;                 // COARSE: start of the bin's run inside `stage`
   uint32_t* gbase = loff + COARSE;                // COARSE: start of the run in the global array
   __shared__ uint32_t sh[SORT_T];
@@ -204,13 +202,13 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
     const uint64_t i = base + t + (uint64_t)k * SORT_T;
     if (i < m) {
       const Fr s = scalar_canonical(ld_scalar_at(bt, kb, i));
-      for_each_digit(s, [&](int w, uint32_t bucket, uint32_t sign) {
+      auto put = [&](int w, uint32_t row, uint32_t bucket, uint32_t sign) {   // w = digit slot (static after unrolling)
         const uint32_t bin = bucket >> FINE_BITS;
         const uint32_t rank = atomicAdd(&hist[bin], 1u);          // < TILE * MSM_W = 2^15
         where[k][w] = (bin << 16) | rank;
-        word[k][w] = ((bucket & ((1u << FINE_BITS) - 1)) << (IDX_BITS + 1)) | (sign << IDX_BITS) |
-                     (uint32_t)((uint64_t)w * srs_n + i);
-      });
+        word[k][w] = ((bucket & ((1u << FINE_BITS) - 1)) << 20) | (sign << 19) | (row << 11) | (t + k * SORT_T);
+      };
+      if (BITPOS) for_each_digit_bitpos(s, put); else for_each_digit_window(s, put);
     }
   }
   __syncthreads();
@@ -226,15 +224,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
     gbase[2 * t + 1] = c1 ? coff[2 * t + 1] + atomicAdd(&cur[2 * t + 1], c1) : 0;
   }
   __syncthreads();
-  uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
-#if PLONK_PARTITION_DIRECT
-  // variant: straight from the registers into the runs (scattered 4-byte stores, merged by the L2)
-#pragma unroll
-  for (uint32_t k = 0; k < PER_T; ++k)
-#pragma unroll
-    for (int w = 0; w < MSM_W; ++w)
-      if (where[k][w] != 0xffffffffu) tmp[gbase[where[k][w] >> 16] + (where[k][w] & 0xffffu)] = word[k][w];
-#else
+  WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
 #pragma unroll
   for (uint32_t k = 0; k < PER_T; ++k)
 #pragma unroll
@@ -245,9 +235,11 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
   const uint32_t sub = t & 15;
   for (uint32_t bin = t >> 4; bin < COARSE; bin += SORT_T / 16) {
     const uint32_t cnt = hist[bin], lo = loff[bin], gb = gbase[bin];
-    for (uint32_t j = sub; j < cnt; j += 16) tmp[gb + j] = stage[lo + j];
+    for (uint32_t j = sub; j < cnt; j += 16) {
+      const uint32_t lw = stage[lo + j];          // tile-local word -> global word: table index = row * points + scalar
+      tmp[gb + j] = SortWord<WordT>::make(lw >> 20, (lw >> 19) & 1u, (uint64_t)((lw >> 11) & 0xffu) * srs_n + base + (lw & 0x7ffu));
+    }
   }
-#endif
 }
 
 // ---- level 2: fine buckets inside a coarse bin ----------------------------------------------------
@@ -260,22 +252,23 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
 static constexpr uint32_t FINE_T = PLONK_FINE_T;
 static constexpr uint32_t FINE_CACHE = PLONK_FINE_CACHE;   // words per thread kept in registers between the two passes: 512 x 20 covers a bin of
                                                            // 10240 words (mean 8192 at 2^20 terms), anything beyond is re-read; A/B r02: -0.25 ms per proof
+template <class WordT>
 __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
-                                                          const uint32_t* __restrict__ tmp_all,
+                                                          const WordT* __restrict__ tmp_all,
                                                           uint32_t* __restrict__ entries_all,
                                                           uint32_t* __restrict__ offsets_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS], start[1u << FINE_BITS], cur[1u << FINE_BITS];
   const int kb = blockIdx.y;
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
-  const uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t beg = coff[bin], end = coff[bin + 1];
   if (end - beg > BIG_LIMIT) return;   // oversized bin: msm_big_hist / msm_big_scatter
   if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
   __syncthreads();
-  uint32_t cache[FINE_CACHE > 0 ? FINE_CACHE : 1];
+  WordT cache[FINE_CACHE > 0 ? FINE_CACHE : 1];
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r) {
     const uint32_t j = beg + t + r * FINE_T;
@@ -283,8 +276,8 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
   }
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r)
-    if (beg + t + r * FINE_T < end) atomicAdd(&cnt[cache[r] >> (IDX_BITS + 1)], 1u);
-  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) atomicAdd(&cnt[tmp[j] >> (IDX_BITS + 1)], 1u);
+    if (beg + t + r * FINE_T < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
+  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) atomicAdd(&cnt[SortWord<WordT>::fine(tmp[j])], 1u);
   __syncthreads();
   if (t == 0) {
     uint32_t run = beg;
@@ -296,10 +289,10 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
     if (bin == COARSE - 1) offsets[MSM_NB] = run;
   }
   __syncthreads();
-  auto place = [&](uint32_t e) {
-    const uint32_t f = e >> (IDX_BITS + 1);
+  auto place = [&](WordT e) {
+    const uint32_t f = SortWord<WordT>::fine(e);
     const uint32_t pos = start[f] + atomicAdd(&cur[f], 1u);
-    entries[pos] = (e & IDX_MASK) | (((e >> IDX_BITS) & 1u) << 31);   // accumulate's format: index | sign << 31
+    entries[pos] = SortWord<WordT>::entry(e);   // accumulate's format: index | sign << 31
   };
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r)
@@ -325,26 +318,28 @@ __device__ __forceinline__ bool big_item(const uint32_t* __restrict__ big, const
 }
 static constexpr uint32_t BIG_T = 512;
 static constexpr uint32_t BIG_PER = BIG_CHUNK / BIG_T;   // words per lane, held in registers
+template <class WordT>
 __global__ void __launch_bounds__(BIG_T) msm_big_hist_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
                                                              const uint32_t* __restrict__ big_off_all,
-                                                             const uint32_t* __restrict__ tmp_all, uint32_t* __restrict__ big_cnt_all) {
+                                                             const WordT* __restrict__ tmp_all, uint32_t* __restrict__ big_cnt_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS];
   const int kb = blockIdx.y;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
   uint32_t bin, beg, end;
   if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
-  const uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint32_t t = threadIdx.x;
   if (t < (1u << FINE_BITS)) cnt[t] = 0;
   __syncthreads();
-  for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[tmp[j] >> (IDX_BITS + 1)], 1u);
+  for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[SortWord<WordT>::fine(tmp[j])], 1u);
   __syncthreads();
   if (t < (1u << FINE_BITS) && cnt[t]) atomicAdd(&big_cnt_all[(uint64_t)kb * MSM_NB + (bin << FINE_BITS) + t], cnt[t]);
 }
+template <class WordT>
 __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
                                                                 const uint32_t* __restrict__ big_off_all,
-                                                                const uint32_t* __restrict__ tmp_all,
+                                                                const WordT* __restrict__ tmp_all,
                                                                 const uint32_t* __restrict__ big_cnt_all, uint32_t* __restrict__ big_cur_all,
                                                                 uint32_t* __restrict__ entries_all, uint32_t* __restrict__ offsets_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS], base[1u << FINE_BITS], cur[1u << FINE_BITS];
@@ -353,7 +348,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
   uint32_t bin, beg, end;
   if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
-  const uint32_t* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ bcnt = big_cnt_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
@@ -361,12 +356,12 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
   const uint32_t t = threadIdx.x;
   if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
   __syncthreads();
-  uint32_t cache[BIG_PER];
+  WordT cache[BIG_PER];
 #pragma unroll
   for (uint32_t r = 0; r < BIG_PER; ++r) {
     const uint32_t j = beg + t + r * BIG_T;
-    cache[r] = j < end ? tmp[j] : 0u;
-    if (j < end) atomicAdd(&cnt[cache[r] >> (IDX_BITS + 1)], 1u);
+    cache[r] = j < end ? tmp[j] : (WordT)0;
+    if (j < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
   }
   __syncthreads();
   if (t == 0) {   // bucket starts inside the bin from the bin-wide counts; this chunk's run in every bucket by one atomic each
@@ -383,9 +378,9 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
 #pragma unroll
   for (uint32_t r = 0; r < BIG_PER; ++r) {
     if (beg + t + r * BIG_T < end) {
-      const uint32_t e = cache[r];
-      const uint32_t f = e >> (IDX_BITS + 1);
-      entries[base[f] + atomicAdd(&cur[f], 1u)] = (e & IDX_MASK) | (((e >> IDX_BITS) & 1u) << 31);
+      const WordT e = cache[r];
+      const uint32_t f = SortWord<WordT>::fine(e);
+      entries[base[f] + atomicAdd(&cur[f], 1u)] = SortWord<WordT>::entry(e);
     }
   }
 }
@@ -468,33 +463,39 @@ int msm_order_slices(Ctx* c, const MsmBatch& bt) {
 }
 
 // Host side: everything between the scalars and msm_accumulate for one commitment group.
-int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
+template <bool BITPOS, class WordT>
+static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   MsmWork& w = c->msm;
   hipStream_t st = c->stream;
-  // intermediate word: 27-bit table index (MSM_W * srs_n entries)
-  if ((uint64_t)MSM_W * bt.table_n > (uint64_t)IDX_MASK + 1)
-    return (set_last_error("commit key too large for the bucket sort", "MSM_W * points must be <= 2^27", __FILE__, __LINE__), PLONK_ERR_ARG);
   const uint32_t tiles = (uint32_t)((mmax + TILE - 1) / TILE);
   const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
+  WordT* tmp = reinterpret_cast<WordT*>(w.tmp_words);
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
-  hipLaunchKernelGGL(msm_hist_kernel, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
+  hipLaunchKernelGGL(msm_hist_kernel<BITPOS>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
-  smem_opt_in(c, (const void*)msm_partition_kernel, PARTITION_LDS);
-  hipLaunchKernelGGL(msm_partition_kernel, dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
-                     w.coarse_off, w.coarse_cur, w.tmp_words);
-  hipLaunchKernelGGL(msm_fine_kernel, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, w.tmp_words,
+  smem_opt_in(c, (const void*)msm_partition_kernel<BITPOS, WordT>, PARTITION_LDS);
+  hipLaunchKernelGGL((msm_partition_kernel<BITPOS, WordT>), dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
+                     w.coarse_off, w.coarse_cur, tmp);
+  hipLaunchKernelGGL(msm_fine_kernel<WordT>, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, (const WordT*)tmp,
                      w.entries, w.offsets);
   {   // oversized bins (skewed digits): upper bound of the chunk count known on the host, surplus workgroups exit at once
     const uint64_t words = (uint64_t)MSM_W * mmax;
     const uint32_t big_wgs = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
     HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
-    hipLaunchKernelGGL(msm_big_hist_kernel, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, w.tmp_words, w.big_cnt);
-    hipLaunchKernelGGL(msm_big_scatter_kernel, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, w.tmp_words,
+    hipLaunchKernelGGL(msm_big_hist_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, (const WordT*)tmp, w.big_cnt);
+    hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, (const WordT*)tmp,
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
   hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
+}
+int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
+  // final entries: sign << 31 | 31-bit table index
+  if ((uint64_t)bt.rows * bt.table_n > (1ull << 31))
+    return (set_last_error("commit key too large for the bucket sort", "table rows * points must be <= 2^31", __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (bt.rows == MSM_ROWS_BITPOS) return bt.wide ? msm_group_sort_t<true, uint64_t>(c, bt, mmax) : msm_group_sort_t<true, uint32_t>(c, bt, mmax);
+  return bt.wide ? msm_group_sort_t<false, uint64_t>(c, bt, mmax) : msm_group_sort_t<false, uint32_t>(c, bt, mmax);
 }
 
 int msm_sort_reserve_fixed(Ctx* c) {

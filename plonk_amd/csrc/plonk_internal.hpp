@@ -10,6 +10,7 @@
 
 #include "../../include/plonk_hip.h"
 #include "curve.cuh"
+#include "msm_recode.cuh"
 
 #define HIP_TRY(expr)                                                    \
   do {                                                                   \
@@ -41,9 +42,11 @@ struct NttTables {
   Fr n_inv;
 };
 
-// MSM geometry: 16-bit signed windows over precomputed 2^(16w) * P_i tables.
+// MSM geometry: 2^15 signed-digit buckets shared by every table row.  Window tables (16 rows, 2^(16 w) * P_i): 16-bit
+// signed windows; bit-position tables (256 rows, 2^r * P_i, round 3): width-17 NAF digits (msm_recode.cuh).  Either
+// way a scalar yields at most MSM_W entries.
 static constexpr int MSM_C = 16;
-static constexpr int MSM_W = 16;
+static constexpr int MSM_W = MSM_DIGITS;
 static constexpr uint32_t MSM_NB = 1u << (MSM_C - 1);   // buckets 1..32768
 static constexpr int MSM_MAX_BATCH = 4;                  // commitments per group launch
 
@@ -54,8 +57,10 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   int count;
   uint32_t ksl;   // entries per slice of this launch
   uint64_t cap_m, cap_slices;
-  const void* table;   // window tables the entries index: the context's commit key, or a prover's Lagrange-basis key
-  uint64_t table_n;    // points per window row of `table`
+  const void* table;   // tables the entries index: the context's commit key, or a prover's Lagrange-basis key
+  uint64_t table_n;    // points per row of `table`
+  uint32_t rows;       // MSM_ROWS_WINDOW (16) or MSM_ROWS_BITPOS (256): which recoding the entries come from
+  uint32_t wide;       // the coarse-partitioned words are 64-bit (rows * table_n above 2^27)
   // scalars of commitment k: scalars[k][i] for i < split[k], tail[k][i - split[k]] above (a wire column in place + its
   // blinders elsewhere); split[k] >= m[k] when the scalars are one array
   const Fr* tail[MSM_MAX_BATCH];
@@ -64,7 +69,7 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
 
 struct MsmWork {   // per-context scratch, grown on demand
   uint64_t cap_m = 0;
-  uint32_t* tmp_words = nullptr;   // W * m words grouped by coarse bin (msm_sort.hip)
+  uint32_t* tmp_words = nullptr;   // W * m words grouped by coarse bin (msm_sort.hip); room for 64-bit words
   uint32_t* entries = nullptr;     // W * m entries grouped by bucket
   uint32_t* coarse_cnt = nullptr;  // 2048 per commitment
   uint32_t* coarse_off = nullptr;  // 2049
@@ -106,7 +111,8 @@ struct Ctx {
   Fr* ntt_tmp = nullptr;
   uint64_t ntt_cap = 0;
   // SRS
-  void* srs_table = nullptr;       // [MSM_W][npoints] 128-B affine entries (Fp28), 2^(16 w) * P_i
+  void* srs_table = nullptr;       // [srs_rows][npoints] 128-B affine entries (Fp28): 2^(16 w) * P_i (16 rows) or 2^r * P_i (256 rows)
+  uint32_t srs_rows = 0;
   void* table_scratch = nullptr;   // srs_table_kernel's per-window ZZ / ZZZ / running products, alive during a key load
   uint64_t table_scratch_pts = 0;
   uint64_t srs_n = 0;
@@ -163,14 +169,18 @@ int srs_export_device(Ctx* c, G1Affine* out_dev);   // the context's commit key 
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 // bit_sums = false: out[k] = the commitment (one XYZZ point).  true: out[k][0..16) = partial sums the
 // host combines with a short doubling chain (msm.hip msm_bits_kernel, prover.hip finish_bit_sums).
-static constexpr int MSM_BIT_SUMS = 16;
-// table == nullptr: the context's commit key; otherwise window tables built by srs_table_build (same layout)
+// [16] = the sum of ALL buckets: bit-position entries weigh 2 b + 1, so their commitment is 2 W - S (hostg1.hpp).
+static constexpr int MSM_BIT_SUMS = 17;
+// table == nullptr: the context's commit key; otherwise tables built by srs_table_build (same layout, table_rows rows)
 int msm_order_slices(Ctx* c, const MsmBatch& bt);   // msm_sort.hip: full_off / part_list from the bucket offsets
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
                      bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0,
-                     const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr);
-// window tables 2^(16 w) * P_i for n points given as G1Affine (caller frees *table_out with hipFree)
-int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out);
+                     const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr, uint32_t table_rows = 0);
+// rows of the tables of an n-point key: 256 (one per bit position) when they fit comfortably in the free HBM, else
+// the 16 window rows; PLONK_MSM_TABLE=window|bitpos forces either
+uint32_t msm_table_rows(uint64_t n);
+// tables for n points given as G1Affine (caller frees *table_out with hipFree); *rows_out = rows chosen
+int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out, uint32_t* rows_out);
 // [L_i(tau)] G for the size-n domain (n = 2^L) from the context's commit key (needs n + 2 points), followed by the
 // two blinding points [tau^n] G - G and [tau^(n+1)] G - [tau] G: n + 2 affine points (an EC inverse FFT)
 int lagrange_points_device(Ctx* c, uint32_t L, G1Affine* out_dev);

@@ -70,6 +70,7 @@ struct Prover {
   Fr* evout = nullptr;             // 16 evaluations
   uint8_t* res = nullptr;          // 16 x 256 B MSM results, XYZZ (device)
   uint8_t* res_host = nullptr;     // pinned mirror
+  bool res_bitpos[16] = {};        // slot holds the sums of bit-position entries (finish_bit_sums: 2 W - S)
   uint8_t* gather_host = nullptr;  // world x 16 x 192 B all-gathered partial sums
   // multi-GPU: this rank owns SRS points [shard_lo, shard_lo + c->srs_n) of srs_total
   int rank = 0, world = 1;
@@ -98,6 +99,7 @@ struct Prover {
   // digits never reach the accumulation) and the wire iNTTs leave the critical path
   void* lag_table = nullptr;       // window tables over n + 2 points (lagrange_points_device), or over this rank's slice of them
   uint64_t lag_n = 0;              // points in lag_table
+  uint32_t lag_rows = 0;           // its rows: 256 (a row per bit position) or 16 (window rows)
   bool lag_on = false;             // wire commitments over the Lagrange key (lag_n may be 0 for a rank without a slice)
   Fr* wscal = nullptr;             // [8] the wire blinders on the device (tail scalars of the four Lagrange-key MSMs)
   Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
@@ -164,7 +166,7 @@ struct SideJoin {   // never leave side work in flight when prove() returns (buf
   ~SideJoin() { (void)hipStreamSynchronize(c->side_stream); }
 };
 
-static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 16 bit sums per commitment (msm_bits_kernel)
+static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 17 bit sums per commitment (msm_bits_kernel)
 
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
 // [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
@@ -175,8 +177,8 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
   uint64_t cnt[MSM_MAX_BATCH];
   G1* out[MSM_MAX_BATCH];
   if (table) {   // a prover-owned key (Lagrange basis, single GPU): no point-range sharding
-    for (int k = 0; k < count; ++k) out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
-    return msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split);
+    for (int k = 0; k < count; ++k) { out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k)); p->res_bitpos[first_slot + k] = p->lag_rows == MSM_ROWS_BITPOS; }
+    return msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split, p->lag_rows);
   }
   for (int k = 0; k < count; ++k) {
     if (m[k] > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
@@ -186,6 +188,7 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
     cnt[k] = hi > lo ? hi - lo : 0;
     sc[k] = scalars[k] + (cnt[k] ? lo : 0);
     out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
+    p->res_bitpos[first_slot + k] = p->c->srs_rows == MSM_ROWS_BITPOS;
   }
   return msm_batch_device(p->c, sc, cnt, count, out, true);
 }
@@ -199,7 +202,7 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
                          hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   std::vector<G1> sums(count);
-  for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)));
+  for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)), p->res_bitpos[first + i]);
   if (p->world > 1) {
     const size_t bytes = sizeof(G1) * (size_t)count;
     PTRY(comm_allgather_host(c, p->link, sums.data(), p->gather_host, bytes));
@@ -535,7 +538,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
       } else {
         rc = lagrange_points_device(c, L, lag_pts);
       }
-      if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table);
+      if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table, &p->lag_rows);
       p->lag_n = n + 2;
       p->lag_on = true;
       if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
@@ -554,7 +557,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
         HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * want));
         int rc = PLONK_OK;
         if (hipMemcpyAsync(lag_pts, d->lagrange_xy96, sizeof(G1Affine) * want, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
-        if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, want, &p->lag_table);
+        if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, want, &p->lag_table, &p->lag_rows);
         if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
         (void)hipFree(lag_pts);
         if (rc) return rc;

@@ -165,16 +165,18 @@ extern "C" void h_quotient_low(const uint32_t* key_low, const uint8_t* has, cons
 #include "../../plonk_amd/csrc/hostg1.hpp"
 // pts: 16 affine points (96 B raw each; a point with x = y = 0 stands for the identity) -> XYZZ bit sums
 // -> finish_bit_sums -> batch affine -> 48-byte compressed.  out48: the commitment.
-extern "C" void h_finish_bit_sums(const uint8_t* pts96, uint8_t out48[48]) {
+// bitpos != 0: 17 points, the last one is S and the result is 2 W - S (bit-position entries weigh 2 b + 1)
+extern "C" void h_finish_bit_sums(const uint8_t* pts96, int bitpos, uint8_t out48[48]) {
   using namespace plonk;
-  G1 bits[16];
-  for (int k = 0; k < 16; ++k) {
+  G1 bits[17];
+  bits[16] = G1::identity();
+  for (int k = 0; k < (bitpos ? 17 : 16); ++k) {
     G1Affine a;
     memcpy(&a, pts96 + 96 * k, 96);
     bits[k] = (a.x.is_zero() && a.y.is_zero()) ? G1::identity() : G1::from_affine(a);
     if (k & 1) bits[k] = bits[k].dbl().add(bits[k].neg());   // a non-trivial ZZ: 2P - P
   }
-  const G1 w = finish_bit_sums(bits);
+  const G1 w = finish_bit_sums(bits, bitpos != 0);
   uint8_t aff[1][97];
   batch_xyzz_to_affine97(&w, 1, aff);
   g1_compress97(aff[0], out48);
@@ -211,4 +213,18 @@ extern "C" int h_g1_decompress48(const uint8_t* in, uint8_t* out96) {
   const int rc = g1_decompress48(in, &a);
   memcpy(out96, &a, 96);
   return rc;
+}
+
+// ---- msm_recode.cuh: scalar -> (row, bucket, sign) digits of both recodings ----
+#include "../../plonk_amd/csrc/msm_recode.cuh"
+// canonical scalar (8 x u32) -> out[4 j .. 4 j + 3] = slot, row, bucket, sign; returns the number of digits
+extern "C" int h_msm_recode(const uint32_t* scalar, int bitpos, uint32_t* out) {
+  Big<8> s;
+  memcpy(s.l, scalar, 32);
+  int n = 0;
+  for_each_digit(s, bitpos ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW, [&](int slot, uint32_t row, uint32_t bucket, uint32_t sign) {
+    out[4 * n] = (uint32_t)slot; out[4 * n + 1] = row; out[4 * n + 2] = bucket; out[4 * n + 3] = sign;
+    ++n;
+  });
+  return n;
 }

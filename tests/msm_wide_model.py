@@ -152,3 +152,53 @@ def idle_fraction(lengths, wave: int = 64):
     """Lane-steps a wave-synchronous machine issues beyond the useful ones: every wave runs as long as its longest lane."""
     issued = sum(max(lengths[k:k + wave]) * wave for k in range(0, len(lengths), wave))
     return issued / max(sum(lengths), 1) - 1
+
+
+# ---- bit-position tables (round 3): one table row per BIT, width-17 non-adjacent form --------------------------------
+NAF_W = 17
+
+
+def bitpos_digits(s: int, w: int = NAF_W):
+    """[(row, d)] with d odd, |d| < 2^(w-1), rows at least w apart, sum d * 2^row = s — msm_recode.cuh for_each_digit_bitpos.
+    After a negative digit the remaining value carries 1: a digit starts where the bit differs from the carry."""
+    out, p, carry = [], 0, 0
+    while (s >> p) + carry:
+        if ((s >> p) & 1) == carry:           # remaining value even
+            p += 1
+            continue
+        v = ((s >> p) & ((1 << w) - 1)) + carry
+        d = v - (1 << w) if v >> (w - 1) else v
+        carry = 1 if d < 0 else 0
+        out.append((p, d))
+        p += w
+    assert sum(d << p for p, d in out) == s
+    return out
+
+
+def bitpos_entries(scalars, w: int = NAF_W):
+    """(bucket = |d| >> 1, negative?, table row = bit position, base index); weight of a bucket = 2 * bucket + 1"""
+    return [(abs(d) >> 1, d < 0, p, i) for i, s in enumerate(scalars) for p, d in bitpos_digits(s % E.Q, w)]
+
+
+def bitpos_msm_model(points, scalars, w: int = NAF_W):
+    """The bucket sums of the bit-position entries through the UNCHANGED row / column / bit-sum reduction, which yields
+    W = sum (b + 1) B_b; the total S = sum B_b is the 17th sum the device emits, and the host returns 2 W - S."""
+    ents = bitpos_entries(scalars, w)
+    groups = {}
+    for b, neg, p, i in ents:
+        groups.setdefault(b, []).append((neg, p, i))
+    sums = {}
+    for b, lst in groups.items():
+        acc = E.JAC_ID
+        for neg, p, i in lst:
+            t = E.to_jac(E.g1_mul(points[i], 1 << p))              # table row p: 2^p P_i
+            acc = E.jac_add(acc, E.jac_neg(t) if neg else t)
+        sums[b] = acc
+    c = w - 1                                                      # 2^(w - 2) buckets = the c = w - 1 window layout
+    T, Tp, C_top = bit_sums(sums, c)
+    W = host_finish(T, Tp, C_top)
+    S = E.JAC_ID
+    for v in sums.values():
+        S = E.jac_add(S, v)
+    Wj = E.to_jac(W) if W is not None else E.JAC_ID
+    return E.to_affine(E.jac_add(E.jac_double(Wj), E.jac_neg(S)))

@@ -59,3 +59,61 @@ def test_length_ordered_lanes_are_a_permutation_of_the_slices_and_waste_nothing(
     in_bucket_order = [l for _, l in sorted(((slice_off[b] + q), l) for b, q, _, l in lanes)]
     assert idle_fraction(lengths) < 0.01
     assert idle_fraction(in_bucket_order) > 2.5 * idle_fraction(lengths)
+
+
+# ---- bit-position tables (round 3) ------------------------------------------------------------------------------
+def _edge_scalars(r):
+    return [0, 1, 2, 3, 4, 0xffff, 0x10000, 0x10001, 0x1ffff, 0x20000, E.Q - 1, E.Q - 2, (E.Q - 1) // 2, (1 << 254) + 1,
+            (1 << 254) - 1, int("5" * 63, 16), int("a" * 62, 16), int("f" * 60, 16) << 8, sum(1 << (17 * k + 16) for k in range(14)),
+            (1 << 239) - 1, ((1 << 16) - 1) << 238, 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000000] + \
+           [r.randrange(E.Q) for _ in range(400)] + [r.randrange(1 << r.randrange(1, 255)) for _ in range(200)]
+
+
+def test_bitpos_digits_are_a_width_17_naf():
+    from msm_wide_model import bitpos_digits
+    r = random.Random(17)
+    total = cnt = 0
+    for s in _edge_scalars(r):
+        dg = bitpos_digits(s)
+        assert len(dg) <= 16
+        assert all(d & 1 and abs(d) < (1 << 16) for _, d in dg)
+        assert all(0 <= p <= 255 for p, _ in dg)
+        assert all(q - p >= 17 for (p, _), (q, _) in zip(dg, dg[1:]))
+    for _ in range(2000):
+        total += len(bitpos_digits(r.randrange(E.Q)))
+        cnt += 1
+    assert 14.4 < total / cnt < 14.9          # ~ 254.9 / 18 + 1/2 = 14.7 additions per scalar instead of 16
+
+
+def test_bitpos_model_equals_the_oracle_msm():
+    from msm_wide_model import bitpos_msm_model
+    r = random.Random(1717)
+    pts = [E.g1_mul(E.G1_GEN, r.randrange(1, E.Q)) for _ in range(10)]
+    cases = [[r.randrange(E.Q) for _ in range(10)],
+             [0, 1, 2, E.Q - 1, 0xffff, 0x10001, 5, 5, E.Q - 5, 3],
+             [r.randrange(4) for _ in range(10)]]
+    for sc in cases:
+        assert bitpos_msm_model(pts, sc) == E.msm_naive(pts, sc)
+    assert bitpos_msm_model(pts, [0] * 10) is None
+
+
+def test_product_recoding_matches_the_models():
+    """msm_recode.cuh compiled for the host (the code msm_hist / msm_partition run) against both models"""
+    import ctypes
+
+    from msm_wide_model import bitpos_digits, signed_digits
+    from test_field_host import build_host_lib
+    lib = build_host_lib()
+    r = random.Random(99)
+    out = (ctypes.c_uint32 * 64)()
+    for s in _edge_scalars(r):
+        limbs = (ctypes.c_uint32 * 8)(*[(s >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+        n = lib.h_msm_recode(limbs, 1, out)
+        got = [(out[4 * j + 1], (2 * out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1)) for j in range(n)]
+        assert [out[4 * j] for j in range(n)] == list(range(n))          # slots are consecutive
+        assert got == bitpos_digits(s), hex(s)
+        n = lib.h_msm_recode(limbs, 0, out)
+        got = {out[4 * j + 1]: (out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1) for j in range(n)}
+        want = {w: d for w, d in enumerate(signed_digits(s, 16)) if d}
+        assert got == want, hex(s)
+        assert all(out[4 * j] == out[4 * j + 1] for j in range(n))       # window recoding: slot = row
