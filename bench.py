@@ -53,6 +53,7 @@ def circuit_polys(ctx, log_n, profile):
     else:
         wires, cols, trivial = BC.arithmetic_circuit(log_n, profile, workers=8 if log_n > 20 else 0)
         polys, pi = dict(trivial), {}
+    circuit_polys.q_m_column = cols.get("q_m")   # one evaluation-form column, for the tests that pin the shared inputs
     buf, tmp = ctx.alloc(32 * n), ctx.alloc(32 * n)
     for name, raw in cols.items():
         buf.upload(raw)
@@ -63,7 +64,9 @@ def circuit_polys(ctx, log_n, profile):
     return wires, polys, pi
 
 
-def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circuit=False):
+def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circuit=False, keep_inputs=False):
+    """keep_inputs: leave (wires, coefficient-form polynomials, public inputs) in build_prover.inputs — the tests hand them to
+    the C oracle for the byte comparison"""
     n = 1 << log_n
     srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
@@ -73,7 +76,17 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
         # full synthetic key and keeps its slice (a real deployment computes it once and ships the slices)
         full = ctx.alloc(96 * (n + 2))
         ctx.srs_generate_dev(TAU, G_SCALAR, n + 2, full.ptr)
-        ctx.srs_load_dev(full.ptr, n + 2)
+        # this load only feeds the group FFT (row 0 of the tables): the 16 window rows are enough, the 256 bit-position
+        # rows of the full key would be 32 GiB per rank of pure setup
+        saved = os.environ.get("PLONK_MSM_TABLE")
+        os.environ["PLONK_MSM_TABLE"] = "window"
+        try:
+            ctx.srs_load_dev(full.ptr, n + 2)
+        finally:
+            if saved is None:
+                del os.environ["PLONK_MSM_TABLE"]
+            else:
+                os.environ["PLONK_MSM_TABLE"] = saved
         full.free()
         key = ctx.lagrange_key(log_n)
         llo, lhi = min(lo, n + 2), min(hi, n + 2)
@@ -103,6 +116,8 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
         build_prover.witness_values = cc["values"]
     else:
         wires, polys, pi = circuit_polys(ctx, log_n, profile)
+        build_prover.inputs = (wires, polys, pi, circuit_polys.q_m_column) if keep_inputs else None
+        circuit_polys.q_m_column = None
         t0 = time.perf_counter()
         prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather, lag_slice)
         build_prover.create_s = time.perf_counter() - t0

@@ -163,16 +163,28 @@ typedef struct {
   uint8_t* srs; u64 srs_n;
   uint8_t vk[15][48];                          /* POLY order (K_*) */
   int threads;
+  int trapdoor; fr tau, gscalar;               /* oracle_prover_set_trapdoor: the key is [g tau^i] G with KNOWN tau, g */
 } oprover;
+
+static const u64 G1_GEN_X[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull, 0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
+static const u64 G1_GEN_Y[6] = {0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull, 0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
+
+static void j_to_affine(g1j p, g1a* out) {   /* p finite */
+  fp zi = fp_inv(p.z), zi2 = fp_mul(zi, zi);
+  out->x = fp_mul(p.x, zi2);
+  out->y = fp_mul(p.y, fp_mul(zi2, zi));
+}
 
 static u64 trimmed_len(const fr* p, u64 len) { while (len && fr_is_zero(p[len - 1])) --len; return len; }
 
 /* CommitKey::commit (key.rs:376-388) on a trimmed polynomial -> 48-byte commitment; -3 = PolynomialDegreeTooLarge */
+static void commit_trapdoor(const oprover* P, const fr* poly, u64 len, uint8_t raw[97]);
 static int commit48(const oprover* P, const fr* poly, u64 len, uint8_t out[48]) {
   len = trimmed_len(poly, len);
   if (len > P->srs_n) return -3;
   uint8_t raw[97];
-  oracle_msm(P->srs, (const u64*)poly, len, raw, P->threads);
+  if (P->trapdoor) commit_trapdoor(P, poly, len, raw);
+  else oracle_msm(P->srs, (const u64*)poly, len, raw, P->threads);
   g1_compress97(raw, out);
   return 0;
 }
@@ -228,6 +240,46 @@ oprover* oracle_prover_new(u64 constraints, const uint8_t* label, u64 label_len,
   return P;
 }
 void oracle_prover_vk(const oprover* P, uint8_t out[15 * 48]) { memcpy(out, P->vk, 15 * 48); }
+
+/* Test keys are synthetic: point i is [g tau^i] G1 for KNOWN tau and g (oracle_srs_generate).  With the trapdoor the
+ * commitment sum_i p_i [g tau^i] G is the single point [g p(tau)] G — the SAME group element CommitKey::commit
+ * (key.rs:376-388) returns, obtained by one polynomial evaluation and one scalar multiplication instead of an MSM.
+ * It exists for the 2^22-gate parity test (BASELINE config 5), where eleven CPU MSMs of 4 M terms would take minutes;
+ * tests/test_oracle_c_prove.py checks that both commit paths give the same proof bytes.  Call before the first prove;
+ * the VerifierKey commitments of oracle_prover_new are unaffected (pass vk48, or let them be MSMs). */
+void oracle_prover_set_trapdoor(oprover* P, const u64 tau_m[4], const u64 g_scalar_m[4]) {
+  P->trapdoor = 1; P->tau = fr_ld(tau_m); P->gscalar = fr_ld(g_scalar_m);
+}
+static void commit_trapdoor(const oprover* P, const fr* poly, u64 len, uint8_t raw[97]) {
+  memset(raw, 0, 97);
+  const u64 chunk = 1 << 14, nch = (len + chunk - 1) / chunk;
+  fr total = fr_zero();
+  if (nch) {
+    fr* part = (fr*)malloc(32 * nch);
+#pragma omp parallel for num_threads(P->threads) schedule(static)
+    for (u64 c = 0; c < nch; ++c) {                                  /* Horner inside a chunk */
+      const u64 lo = c * chunk, hi = lo + chunk < len ? lo + chunk : len;
+      fr acc = fr_zero();
+      for (u64 i = hi; i-- > lo;) acc = fr_add(fr_mul(acc, P->tau), poly[i]);
+      part[c] = acc;
+    }
+    const fr step = fr_pow(P->tau, chunk);
+    for (u64 c = nch; c-- > 0;) total = fr_add(fr_mul(total, step), part[c]);
+    free(part);
+  }
+  uint8_t kb[32];
+  fr_to_bytes(fr_mul(total, P->gscalar), kb);                        /* g p(tau), canonical little-endian */
+  g1a gen; memcpy(gen.x.l, G1_GEN_X, 48); memcpy(gen.y.l, G1_GEN_Y, 48);
+  g1j acc = j_identity();
+  for (int bit = 255; bit >= 0; --bit) {
+    acc = j_double(acc);
+    if ((kb[bit >> 3] >> (bit & 7)) & 1) acc = j_add_mixed(acc, &gen);
+  }
+  if (fp_is_zero(acc.z)) { raw[96] = 1; return; }
+  g1a a;
+  j_to_affine(acc, &a);
+  memcpy(raw, a.x.l, 48); memcpy(raw + 48, a.y.l, 48);
+}
 
 /* ------------------------------------------------------------------ widget identities */
 typedef struct { fr a, b, c, d, a_w, b_w, d_w, q_l, q_r, q_c; } wvals;
@@ -714,14 +766,6 @@ done:
 /* PublicParameters::setup semantics (srs.rs:61-100): out[i] = (g_scalar * tau^i) * G1::generator as 96-byte
  * x || y Montgomery points.  Fixed-base windowed multiplication (8-bit windows, 32 x 255 table)
  * instead of the reference's per-point double-and-add (util.rs:77) — same points. */
-static const u64 G1_GEN_X[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull, 0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
-static const u64 G1_GEN_Y[6] = {0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull, 0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
-
-static void j_to_affine(g1j p, g1a* out) {   /* p finite */
-  fp zi = fp_inv(p.z), zi2 = fp_mul(zi, zi);
-  out->x = fp_mul(p.x, zi2);
-  out->y = fp_mul(p.y, fp_mul(zi2, zi));
-}
 
 int oracle_srs_generate(const u64 tau_m[4], const u64 g_scalar_m[4], u64 n, uint8_t* out96, int threads) {
   if (threads <= 0) threads = omp_get_max_threads();

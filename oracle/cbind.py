@@ -41,6 +41,8 @@ def load() -> ctypes.CDLL:
     lib.oracle_prover_free.restype = None
     lib.oracle_prover_vk.argtypes = [vp, vp]
     lib.oracle_prover_vk.restype = None
+    lib.oracle_prover_set_trapdoor.argtypes = [vp, vp, vp]
+    lib.oracle_prover_set_trapdoor.restype = None
     lib.oracle_srs_generate.argtypes = [vp, vp, u64, vp, ctypes.c_int]
     lib.oracle_prover_prove.argtypes = [vp, ctypes.POINTER(vp), vp, vp, u64, vp, vp, vp]
     _lib = lib
@@ -127,6 +129,10 @@ class CProver:
         self.h = lib.oracle_prover_new(constraints, label, len(label), arr, lens, srs96, len(srs96) // 96, vk48, self.threads)
         if not self.h:
             raise ValueError("oracle_prover_new failed (polynomial longer than the domain, or degree > SRS)")
+
+    def set_trapdoor(self, tau_mont: bytes, g_scalar_mont: bytes):
+        """the key is [g tau^i] G with known tau, g: commitments become [g p(tau)] G (same group elements, no MSM)"""
+        self.lib.oracle_prover_set_trapdoor(self.h, tau_mont, g_scalar_mont)
 
     def vk(self) -> bytes:
         out = ctypes.create_string_buffer(15 * 48)

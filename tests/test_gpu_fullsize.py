@@ -18,7 +18,7 @@ def test_bench_proof_verifies(log_n):
     (bench.build_prover), 8.6 GiB of window tables + 8.5 GiB of key evaluations resident."""
     import plonk_amd
     ctx = plonk_amd.Context(0)
-    prover, wbuf, srs_total = bench.build_prover(ctx, log_n, 0, 1, None)
+    prover, wbuf, srs_total = bench.build_prover(ctx, log_n, 0, 1, None, keep_inputs=log_n == 22)
     tau, g = bench.TAU, bench.G_SCALAR
     srs_g = E.g1_mul(E.G1_GEN, g)
     raw = prover.vk_commitments()
@@ -35,6 +35,25 @@ def test_bench_proof_verifies(log_n):
     bad = bytearray(p1)
     bad[530] ^= 4
     assert not verify_with_tau(bytes(bad), vk, b"bench", n, {}, tau, srs_g)
+    if log_n == 22:
+        # BASELINE config 5's size, BYTE parity: a valid-but-different proof (a misplaced blinder in the split of t, a wrong
+        # coefficient range) passes the verification equation above but not this.  The C oracle proves the same circuit
+        # with the key's trapdoor — the commitment [g p(tau)] G is the group element the MSM over [g tau^i] G returns
+        # (tests/test_oracle_c_prove.py::test_trapdoor_commitments_are_the_msm_commitments) — because eleven CPU MSMs of
+        # 4 M terms would take minutes; the transforms, the quotient and every O(n) pass are the oracle's own.
+        from oracle import cbind
+        wires, polys, _, q_m_column = bench.build_prover.inputs
+        bench.build_prover.inputs = None
+        threads = cbind.max_threads()
+        mont = plonk_amd.fr_to_bytes_mont
+        # the key polynomials are INPUTS of prove() (Compiler::compile made them); pin one GPU-interpolated column to
+        # the CPU transform so that the shared input is not taken on trust
+        assert cbind.ntt_bytes(q_m_column, log_n, True, False, n, threads) == polys["q_m"]
+        cp = cbind.CProver(n, b"bench", polys, bytes(96 * (n + 7)), vk48=raw, threads=threads)
+        cp.set_trapdoor(mont([tau]), mont([g]))
+        expected = cp.prove(wires, [], b"", bl1)
+        cp.close()
+        assert p1 == expected
     prover.close()
     wbuf.free()
     ctx.close()

@@ -53,6 +53,29 @@ def test_sharded_quotient_prove_matches_single_gpu(ranks, log_gates, profile):
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_sharded_prove_matches_single_gpu_at_2p20(ranks):
+    """BASELINE config 4's size: the sharded proof of the 2^20-gate bench circuit — W = 2 (Q = 4 classes) and W = 8
+    (Q = 8: the 8n class layout) — must be the single-GPU proof byte for byte; the single-GPU bytes at this size are
+    compared with the C oracle in tests/test_gpu_prove_sizes.py.  Launched as `python bench.py --gpus N`, i.e. through
+    bench.py's own rank launcher (the ranks share this box's one GPU)."""
+    s = single(20, "dense")
+    m = _run([sys.executable, "bench.py", "--gpus", str(ranks), "--log-gates", "20", "--steps", "1", "--warmup", "0", "--no-extras"],
+             {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
+    assert m["n_gpus"] == ranks and m["config"]["collective"] == "gloo"
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
+def test_self_launcher_starts_the_ranks_on_the_gpu_path():
+    """`python bench.py --gpus 2` with no launcher in front of it (how the driver starts the bench): two ranks, the
+    single-GPU proof"""
+    s = single(12, "dense")
+    m = _run([sys.executable, "bench.py", "--gpus", "2", "--log-gates", "12", "--steps", "1", "--warmup", "0", "--no-extras"],
+             {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
+    assert m["n_gpus"] == 2 and m["proof_blake2b"] == s["proof_blake2b"]
+
+
 @pytest.mark.parametrize("ranks,log_gates,profile", [(1, 13, "widgets"), (2, 13, "widgets"), (4, 12, "dense")])
 def test_compiled_prover_matches_the_coefficient_form_prover(ranks, log_gates, profile):
     """plonk_compile (Compiler::preprocess on the device: gate columns + witness indices in) on 1 / 2 / 4 ranks — the

@@ -113,6 +113,40 @@ def test_unsatisfied_witness_is_circuit_unsatisfied_exactly(ctx, monkeypatch, do
 
 
 @pytest.mark.slow
+@pytest.mark.parametrize("profile", ["bench-like", "widgets"])
+def test_side_workloads_equal_c_oracle_2p20(ctx, monkeypatch, profile):
+    """The two other workloads bench.py times at 2^20 gates (`prove_ms_bench_like`: half of the wire values < 4, the skewed
+    digits of a real witness; `prove_ms_all_widgets_pi`: every widget family + public inputs): the whole proof against the
+    C oracle at the size that is timed, not only at 2^13 / 2^17."""
+    import bench_circuits as BC
+    monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    monkeypatch.delenv("PLONK_WIRE_COMMIT", raising=False)
+    log_n = 20
+    n = 1 << log_n
+    _cases.clear()
+    if profile == "widgets":
+        wires, cols, pi = BC.widget_circuit(log_n)
+        trivial = {}
+    else:
+        wires, cols, trivial = BC.arithmetic_circuit(log_n, profile)
+        pi = {}
+    threads = cbind.max_threads()
+    polys = {k: C.fr_bytes(v) for k, v in trivial.items()}
+    for name, raw in cols.items():
+        polys[name] = cbind.ntt_bytes(raw, log_n, True, False, n, threads)
+    srs = C.synthetic_srs(n + 7)
+    idx = sorted(pi)
+    case = dict(constraints=n, size=n, label=b"bench", polys=polys, wires=wires, pi=pi, pi_idx=idx,
+                pi_val=C.fr_bytes([pi[i] for i in idx]))
+    bl = C.blinders(2021)
+    got, vk = gpu_proof(ctx, case, srs, bl)
+    cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk, threads=threads)
+    expected = cp.prove(wires, idx, case["pi_val"], bl)
+    cp.close()
+    assert got == expected
+
+
+@pytest.mark.slow
 @pytest.mark.parametrize("domain", ["quotient-4n"])   # the 8n domain is compared at 2^12 .. 2^16 above
 def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     """BASELINE config 3 (2^20 gates): the bench circuit of bench.py (dense arithmetic profile) and the

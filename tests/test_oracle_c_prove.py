@@ -91,3 +91,18 @@ def test_c_srs_generator_matches_bigint_setup():
     base = E.g1_mul(E.G1_GEN, g)
     for i in (0, 1, 2, 11):
         assert E.g1_from_raw96(raw[96 * i:96 * i + 96]) == E.g1_mul(base, pow(tau, i, Q))
+
+
+def test_trapdoor_commitments_are_the_msm_commitments():
+    """oracle_prover_set_trapdoor: on a synthetic key [g tau^i] G the commitment [g p(tau)] G is the group element the
+    MSM returns — same proof bytes with and without it (the 2^22-gate GPU parity test relies on this mode)."""
+    case = C.compile_fast(C.big_widget_circuit(512, seed=8)(), b"trapdoor")
+    tau, g = 0x5EED0000 * 0x9E3779B97F4A7C15 % Q, 0xA5A5A5A5DEADBEEF
+    srs = C.synthetic_srs(case["size"] + 7, tau, g)
+    cp = cbind.CProver(case["constraints"], case["label"], case["polys"], srs)
+    want = cp.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31))
+    cp.set_trapdoor(C.fr_bytes([tau]), C.fr_bytes([g]))
+    assert cp.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31)) == want
+    cp.set_trapdoor(C.fr_bytes([tau + 1]), C.fr_bytes([g]))      # a wrong trapdoor is a different proof
+    assert cp.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31)) != want
+    cp.close()
