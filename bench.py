@@ -116,6 +116,9 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
         build_prover.witness_values = cc["values"]
     else:
         wires, polys, pi = circuit_polys(ctx, log_n, profile)
+        build_prover.selectors_nonzero = sum(1 for k in ("q_m", "q_l", "q_r", "q_o", "q_f")
+                                             if isinstance(polys.get(k), (bytes, bytearray)) and polys[k].strip(b"\0")
+                                             or (not isinstance(polys.get(k), (bytes, bytearray)) and polys.get(k) and any(polys[k])))
         build_prover.inputs = (wires, polys, pi, circuit_polys.q_m_column) if keep_inputs else None
         circuit_polys.q_m_column = None
         t0 = time.perf_counter()
@@ -210,6 +213,12 @@ def leaf_costs(ctx, log_n):
     t0 = time.perf_counter()
     ctx._check(lib.plonk_ntt_batch(h, arr, 5, L8, 0, 1, None))
     out["plonk_ntt_batch5_2p%d_ms" % L8] = round((time.perf_counter() - t0) * 1e3, 2)
+    # the way compute_coset_evaluations calls it (quotient_poly.rs:139-157): n + 3 coefficients in, the whole coset out
+    lens = (ctypes.c_uint64 * 5)(*[min(n + 3, n8)] * 5)
+    ctx._check(lib.plonk_ntt_batch(h, arr, 5, L8, 0, 1, lens))
+    t0 = time.perf_counter()
+    ctx._check(lib.plonk_ntt_batch(h, arr, 5, L8, 0, 1, lens))
+    out["plonk_ntt_batch5_2p%d_coset_evaluations_ms" % L8] = round((time.perf_counter() - t0) * 1e3, 2)
     for b in bufs:
         b.free()
     sets = [plonk_amd.PinnedBuffer(32 * (n + 2)) for _ in range(4)]
@@ -226,6 +235,53 @@ def leaf_costs(ctx, log_n):
         sb.free()
     out["note"] = "pinned host buffers in and out, C entry points called directly (PCIe both ways included)"
     return out
+
+
+def quotient_roofline(prover, n, qmul, has_pi, profile, ms_per_launch):
+    nz = getattr(build_prover, "selectors_nonzero", 5)
+    """Algorithmic bytes of the point-wise quotient pass: every array the kernel reads once per point + the one it writes,
+    32 B each (poly.hip quotient_kernel): wires a b c d, z (read at i and at the rotated index: counted once), q_c, q_arith,
+    `linear`, sigma 1-4, L1, the non-zero ones of q_m q_l q_r q_o q_f, the public-input evaluations when there are any, and —
+    with custom gates — the rotated wires come from the same arrays; the widget selectors add one array each."""
+    arrays = 5 + 2 + 1 + 4 + 1 + nz + (1 if has_pi else 0) + (4 if profile == "widgets" else 0)
+    bytes_per_point = 32 * (arrays + 1)
+    pts = qmul * n
+    ach = bytes_per_point * pts / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
+    return {"bound": "hbm", "kernel": "quotient_kernel", "points": pts, "algorithmic_bytes_per_point": bytes_per_point,
+            "arrays_read": arrays, "avg_launch_ms": round(ms_per_launch, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "note": "hipEvent pair around the launch inside the timed region (slot 3)"}
+
+
+def ntt_roofline(ctx, log_n, qd8):
+    """The transforms of one prove() timed on their own (device-resident, same entry point the prover uses): the
+    quotient-domain coset NTT from n + 3 coefficients, the inverse coset NTT and the size-n inverse NTT.  Algorithmic
+    bytes 64 N per transform whatever the number of passes."""
+    n = 1 << log_n
+    Lq = log_n + (3 if qd8 else 2)
+    out = {}
+    for name, L, inv, coset, in_len in (("coset_ntt_quotient_domain", Lq, False, True, n + 3),
+                                        ("coset_intt_quotient_domain", Lq, True, True, 1 << Lq),
+                                        ("intt_n", log_n, True, False, n)):
+        N = 1 << L
+        src, dst, tmp = ctx.alloc(32 * N), ctx.alloc(32 * N), ctx.alloc(32 * N)
+        src.upload(bytes(32 * min(N, 1 << 16)))      # contents do not matter for the timing (no data-dependent branches)
+        ctx.ntt_dev(src.ptr, dst.ptr, tmp.ptr, L, inv, coset, in_len)
+        ctx.sync()
+        iters = 10
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ctx.ntt_dev(src.ptr, dst.ptr, tmp.ptr, L, inv, coset, in_len)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) * 1e3 / iters
+        for b in (src, dst, tmp):
+            b.free()
+        out[name] = {"log_size": L, "ms": round(ms, 4), "melem_per_s": round(N / ms / 1e3, 1),
+                     "achieved": round(64 * N / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return {"bound": "hbm", "kernel": "ntt_pass_kernel (2-3 passes per transform)", "algorithmic_bytes": "64 N per transform",
+            "note": "timed standalone with wall clock around 10 back-to-back launches; integer-VALU bound (Fr29 butterflies), "
+                    "a k-pass plan moves k x 64 N actual bytes", "transforms": out}
 
 
 def cpu_model():
@@ -473,6 +529,9 @@ def main():
                 except Exception:   # noqa: BLE001
                     pass
         qd8 = os.environ.get("PLONK_QUOTIENT_DOMAIN", "")[:1] == "8" or world == 8
+        table_rows = ctx.table_rows()
+        # uniform scalars: 16 signed 16-bit windows, or the width-17 NAF over bit-position tables: 254.9 / 18 + 1/2 digits
+        digits_per_scalar = 16.0 if table_rows == 16 else 14.67
         npoly = 6 if pi else 5
         out = {
             "metric": "prove() wall-clock (ms) at 2^%d gates" % log_n,
@@ -504,10 +563,18 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
+                         # wave-instructions (additions / 64 lanes x instructions per addition) x 4 cycles / (time x 1024 SIMDs x 2.4 GHz): how close the
+                         # kernel runs to one VALU instruction per 4 cycles per SIMD (mixed addition: 4850 instructions,
+                         # profiles/r02c/accumulate_isa.md; additions = non-zero digits of the 11 commitments' scalars)
+                         "valu_issue_fraction": round(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850 * 4 /
+                                                      max(acc_ms_per_prove * 1e-3 * 1024 * 2.4e9, 1e-9), 3),
+                         "additions_per_scalar": digits_per_scalar, "table_rows": table_rows,
                          "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
                          "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
                          "launch_groups_per_prove": list(groups),
                          "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; see DESIGN.md"},
+            # the one HBM-bound pass of a proof: quotient_kernel over the quotient-domain points
+            "roofline_quotient": quotient_roofline(prover, n, 8 if qd8 else 4, bool(pi), args.profile, q_ms / max(q_n, 1)),
             "kernel_ms_per_prove": {"msm_accumulate": round(acc_ms / args.steps, 3),
                                     "msm_other": round(oth_ms / args.steps, 3),
                                     "quotient_pointwise": round(q_ms / args.steps, 3),
@@ -537,6 +604,7 @@ def main():
         if world == 1 and not args.no_extras and args.profile == "dense":
             try:   # the other workloads of SURVEY §8(d) and the seam-level cost; never a reason to lose the line
                 k = max(2, min(args.steps, 5))
+                out["roofline_ntt"] = ntt_roofline(ctx, log_n, qd8)
                 out["leaf_ms"] = leaf_costs(ctx, log_n)          # while the context still holds the 2^log_n key
                 out["prove_ms_bench_like"] = time_profile(ctx, log_n, "bench-like", k, blinders)
                 out["prove_ms_all_widgets_pi"] = time_profile(ctx, log_n, "widgets", k, blinders)

@@ -41,7 +41,7 @@ EXPORTS = [
     "plonk_ctx_create", "plonk_ctx_destroy", "plonk_last_error", "plonk_ntt", "plonk_ntt_batch",
     "plonk_srs_load", "plonk_msm", "plonk_msm_batch", "plonk_ntt_dev", "plonk_msm_dev",
     "plonk_srs_load_dev", "plonk_srs_generate_dev", "plonk_dev_alloc", "plonk_dev_free",
-    "plonk_dev_h2d", "plonk_dev_d2h", "plonk_dev_sync", "plonk_ctx_stream",
+    "plonk_dev_h2d", "plonk_dev_d2h", "plonk_dev_sync", "plonk_ctx_stream", "plonk_ctx_table_rows",
     "plonk_profile_enable", "plonk_profile_read", "plonk_profile_reset",
     "plonk_prover_create", "plonk_prover_destroy", "plonk_prover_vk", "plonk_prover_size",
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
@@ -157,6 +157,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_dev_d2h.argtypes = [vp, vp, vp, u64]
     lib.plonk_dev_sync.argtypes = [vp]
     lib.plonk_ctx_stream.argtypes = [vp]
+    lib.plonk_ctx_table_rows.argtypes = [vp]
     lib.plonk_ctx_stream.restype = vp
     lib.plonk_profile_enable.argtypes = [vp, ci]
     lib.plonk_profile_read.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
@@ -431,6 +432,10 @@ class Context:
     # ---- device-resident API ----------------------------------------------------
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def table_rows(self) -> int:
+        """256: one table row per bit position (width-17 NAF digits), 16: window rows, 0: no key"""
+        return int(self.lib.plonk_ctx_table_rows(self.handle))
 
     def ntt_dev(self, src: int, dst: int, tmp: int, log_n: int, inverse=False, coset=False, in_len=None):
         in_len = (1 << log_n) if in_len is None else in_len

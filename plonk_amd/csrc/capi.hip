@@ -91,11 +91,12 @@ static int ensure_ntt_staging(Ctx* c, uint64_t n) {
   if (n <= c->ntt_cap) return PLONK_OK;
   if (c->ntt_buf) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipFree(c->ntt_buf)); HIP_TRY(hipFree(c->ntt_buf2)); HIP_TRY(hipFree(c->ntt_tmp));
-    c->ntt_buf = c->ntt_buf2 = c->ntt_tmp = nullptr; c->ntt_cap = 0;
+    HIP_TRY(hipFree(c->ntt_buf)); HIP_TRY(hipFree(c->ntt_buf2)); HIP_TRY(hipFree(c->ntt_buf3)); HIP_TRY(hipFree(c->ntt_tmp));
+    c->ntt_buf = c->ntt_buf2 = c->ntt_buf3 = c->ntt_tmp = nullptr; c->ntt_cap = 0;
   }
   HIP_TRY(hipMalloc((void**)&c->ntt_buf, sizeof(Fr) * n));
   HIP_TRY(hipMalloc((void**)&c->ntt_buf2, sizeof(Fr) * n));
+  HIP_TRY(hipMalloc((void**)&c->ntt_buf3, sizeof(Fr) * n));
   HIP_TRY(hipMalloc((void**)&c->ntt_tmp, sizeof(Fr) * n));
   c->ntt_cap = n;
   return PLONK_OK;
@@ -158,7 +159,8 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
     (void)hipFree(t->w512_29); (void)hipFree(t->g_lo29); (void)hipFree(t->g_hi29);
     delete t;
   }
-  (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_buf2); (void)hipFree(c.ntt_tmp);
+  (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_buf2); (void)hipFree(c.ntt_buf3); (void)hipFree(c.ntt_tmp);
+  if (c.down_stream) (void)hipStreamDestroy(c.down_stream);
   if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream); (void)hipFree(c.srs_table); (void)hipFree(c.table_scratch);
   MsmWork& w = c.msm;
   (void)hipFree(w.tmp_words); (void)hipFree(w.entries); (void)hipFree(w.coarse_cnt); (void)hipFree(w.coarse_off); (void)hipFree(w.coarse_cur); (void)hipFree(w.big_off); (void)hipFree(w.big_cnt); (void)hipFree(w.nheavy); (void)hipFree(w.heavy_list); (void)hipFree(w.seg_sum);
@@ -170,6 +172,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   delete ctx;
 }
 
+int plonk_ctx_table_rows(plonk_ctx* ctx) { return ctx ? (int)ctx->c.srs_rows : 0; }
 void* plonk_ctx_stream(plonk_ctx* ctx) { return ctx ? (void*)ctx->c.main_stream : nullptr; }   // never the side stream a running prove() may have swapped in
 
 // ---- device memory helpers ----------------------------------------------------
@@ -242,9 +245,10 @@ int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int cose
 }
 
 // The 5-way fan-out of compute_coset_evaluations (quotient_poly.rs:139-157) / the 4 wire iFFTs
-// (prover.rs:464) as ONE call: the transforms of a batch are pipelined over two device buffers —
-// an uploader thread feeds buffer k+1 over the copy stream while the main stream transforms and
-// downloads buffer k, so both PCIe directions are busy instead of strictly alternating.
+// (prover.rs:464) as ONE call: a FULL-DUPLEX pipeline over three device buffers and three streams — the upload of
+// transform k + 1 (copy stream), the transform of k (main stream) and the download of k - 1 (down stream) run at the same
+// time, ordered by events only (no host thread, no host synchronisation until the end), so both PCIe directions are busy
+// together: the batch costs ~max(upload, download) per transform instead of their sum.
 int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_n, int inverse, int coset,
                     const uint64_t* in_len) {
   if (!ctx || !a || count < 0 || log_n >= 28) return PLONK_ERR_ARG;
@@ -257,51 +261,38 @@ int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_
   int rc = ensure_ntt_staging(&c, n);
   if (rc) return rc;
   if (!c.copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
-  Fr* buf[2] = {c.ntt_buf, c.ntt_buf2};
-  std::mutex mu;
-  std::condition_variable cv;
-  int uploaded = 0, released = 0;     // transforms whose input is on the device / whose buffer is free again
-  int up_rc = PLONK_OK;
-  bool abort = false;
-  std::thread uploader([&] {
-    if (hipSetDevice(c.device) != hipSuccess) { std::lock_guard<std::mutex> g(mu); up_rc = PLONK_ERR_HIP; cv.notify_all(); return; }
-    for (int k = 0; k < count; ++k) {
-      {
-        std::unique_lock<std::mutex> g(mu);
-        cv.wait(g, [&] { return abort || released >= k - 1; });   // buffer k % 2 was last used by transform k - 2
-        if (abort) return;
-      }
-      uint64_t len = in_len ? in_len[k] : n;
-      if (len > n) len = n;
-      hipError_t e = hipMemcpyAsync(buf[k & 1], a[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c.copy_stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c.copy_stream);
-      std::lock_guard<std::mutex> g(mu);
-      if (e != hipSuccess) { up_rc = PLONK_ERR_HIP; cv.notify_all(); return; }
-      uploaded = k + 1;
-      cv.notify_all();
-    }
-  });
-  for (int k = 0; k < count && rc == PLONK_OK; ++k) {
-    {
-      std::unique_lock<std::mutex> g(mu);
-      cv.wait(g, [&] { return up_rc != PLONK_OK || uploaded > k; });
-      if (up_rc != PLONK_OK) { rc = up_rc; break; }
-    }
+  if (!c.down_stream) HIP_TRY(hipStreamCreateWithFlags(&c.down_stream, hipStreamNonBlocking));
+  Fr* buf[3] = {c.ntt_buf, c.ntt_buf2, c.ntt_buf3};
+  hipEvent_t up[3] = {nullptr, nullptr, nullptr}, done[3] = {nullptr, nullptr, nullptr}, freed[3] = {nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+    e = hipEventCreateWithFlags(&up[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&freed[k], hipEventDisableTiming);
+  }
+  for (int k = 0; k < count && e == hipSuccess && rc == PLONK_OK; ++k) {
+    const int b = k % 3;
     uint64_t len = in_len ? in_len[k] : n;
     if (len > n) len = n;
-    rc = ntt_device(&c, buf[k & 1], buf[k & 1], c.ntt_tmp, log_n, inverse != 0, coset != 0, len);
-    if (rc == PLONK_OK && hipMemcpyAsync(a[k], buf[k & 1], sizeof(Fr) * n, hipMemcpyDeviceToHost, c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
-    if (rc == PLONK_OK && hipStreamSynchronize(c.stream) != hipSuccess) rc = PLONK_ERR_HIP;
-    std::lock_guard<std::mutex> g(mu);
-    released = k + 1;
-    cv.notify_all();
+    if (k >= 3) e = hipStreamWaitEvent(c.copy_stream, freed[b], 0);            // transform k - 3 has left this buffer
+    if (e == hipSuccess) e = hipMemcpyAsync(buf[b], a[k], sizeof(Fr) * len, hipMemcpyHostToDevice, c.copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(up[b], c.copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c.stream, up[b], 0);
+    if (e == hipSuccess) rc = ntt_device(&c, buf[b], buf[b], c.ntt_tmp, log_n, inverse != 0, coset != 0, len);
+    if (e == hipSuccess && rc == PLONK_OK) e = hipEventRecord(done[b], c.stream);
+    if (e == hipSuccess && rc == PLONK_OK) e = hipStreamWaitEvent(c.down_stream, done[b], 0);
+    if (e == hipSuccess && rc == PLONK_OK) e = hipMemcpyAsync(a[k], buf[b], sizeof(Fr) * n, hipMemcpyDeviceToHost, c.down_stream);
+    if (e == hipSuccess && rc == PLONK_OK) e = hipEventRecord(freed[b], c.down_stream);
   }
-  {
-    std::lock_guard<std::mutex> g(mu);
-    if (rc != PLONK_OK) abort = true;
-    cv.notify_all();
+  // drain all three streams before the buffers / events go away, error or not
+  const hipError_t e1 = hipStreamSynchronize(c.copy_stream), e2 = hipStreamSynchronize(c.stream), e3 = hipStreamSynchronize(c.down_stream);
+  if (e == hipSuccess) e = e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3);
+  for (int k = 0; k < 3; ++k) {
+    if (up[k]) (void)hipEventDestroy(up[k]);
+    if (done[k]) (void)hipEventDestroy(done[k]);
+    if (freed[k]) (void)hipEventDestroy(freed[k]);
   }
-  uploader.join();
+  if (e != hipSuccess) { set_last_error("plonk_ntt_batch", hipGetErrorString(e), __FILE__, __LINE__); if (rc == PLONK_OK) rc = PLONK_ERR_HIP; }
   return rc;
 }
 

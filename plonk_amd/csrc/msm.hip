@@ -461,35 +461,64 @@ msm_accumulate_lds_kernel(const G1AffineR* __restrict__ table, MsmBatch bt, cons
 // ~14 dependent additions for a bucket of any size, and the heavy buckets — which sit next to each other at the
 // small bucket indices — are spread over the whole chip.
 static constexpr uint32_t HEAVY_SEG = 256;
-struct HeavyItem { uint32_t bucket, seg_base, nseg, pad; };
+// (HeavyItem: plonk_internal.hpp.)  The list of heavy buckets is written by msm_slices_kernel (msm_sort.hip), i.e. BEFORE
+// the accumulation, so that the segment sums do not need a kernel of their own: the first `fused` workgroups of
+// msm_bucket_sum are segment workers (32 quads: 8 slices per quad + a 5-step tree of quad additions, g1r_add_quad below)
+// and run beside the ordinary bucket sums — r03: as separate launches the two heavy kernels cost 0.2 ms per commitment
+// group whenever a witness (or the leftover top digit of the bit-position recoding) makes a few buckets heavy.  A bucket
+// of one segment goes straight to its bucket slot; longer ones leave segment sums for msm_heavy_bucket.
+__device__ __forceinline__ G1R g1r_add_quad(const G1R& a, const G1R& b, uint32_t q);
+static constexpr uint32_t HEAVY_FUSED_WGS = 128;
 template <int BS_G>   // lanes per bucket, chosen from the expected slices per bucket (msm_batch_device)
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all, uint32_t heavy_thresh,
-                                                             uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
+                                                             const uint32_t* __restrict__ nheavy_all, const HeavyItem* __restrict__ heavy_list_all,
+                                                             G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
   G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
-  __shared__ G1R sh[BS_G > 1 ? 128 : 1];
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ G1R sh[BS_G > 1 ? 128 : 32];
+  if (blockIdx.x < fused) {   // ---- heavy-segment worker
+    __shared__ uint32_t found[3];
+    const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
+    G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
+    const uint32_t t = threadIdx.x, q = t & 3, L = t >> 2;
+    const uint32_t nitems = nheavy_all[2 * kb], nsegs = nheavy_all[2 * kb + 1];
+    for (uint32_t sg = blockIdx.x; sg < nsegs; sg += fused) {
+      for (uint32_t i = t; i < nitems; i += 128) {   // which item owns segment sg
+        const HeavyItem it = list[i];
+        if (sg >= it.seg_base && sg < it.seg_base + it.nseg) { found[0] = it.bucket; found[1] = sg - it.seg_base; found[2] = it.nseg; }
+      }
+      __syncthreads();
+      const uint32_t b = found[0], j = found[1], nseg = found[2];
+      const uint32_t beg = slice_off[b] + j * HEAVY_SEG, bend = slice_off[b + 1];
+      G1R acc = G1R::identity();
+      for (uint32_t r = 0; r < HEAVY_SEG / 32; ++r) {
+        const uint32_t k = beg + L + 32 * r;
+        if (k < bend) acc = g1r_add_quad(acc, ld_g1r(partial + k), q);
+      }
+      for (uint32_t d = 16; d >= 1; d >>= 1) {
+        if (q == 0) sh[L] = acc;
+        __syncthreads();
+        if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
+        __syncthreads();
+      }
+      if (t == 0) st_g1r(nseg == 1 ? buckets + b : seg_sum + sg, acc);
+      __syncthreads();
+    }
+    return;
+  }
+  const uint32_t t = (blockIdx.x - fused) * blockDim.x + threadIdx.x;
   const uint32_t b = t / BS_G, g = t % BS_G;
   G1R acc = G1R::identity();
   bool heavy = false;
   if (b < MSM_NB) {
     const uint32_t beg = slice_off[b], end = slice_off[b + 1];
-    heavy = end - beg > heavy_thresh;
-    if (!heavy) {
+    heavy = end - beg > heavy_thresh;   // listed by msm_slices_kernel with the same threshold
+    if (!heavy)
       for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
-    } else if (g == 0) {
-      const uint32_t nseg = (end - beg + HEAVY_SEG - 1) / HEAVY_SEG;
-      HeavyItem it;
-      it.bucket = b;
-      it.nseg = nseg;
-      it.seg_base = atomicAdd(&nheavy_all[2 * kb + 1], nseg);     // [2 kb]: heavy buckets, [2 kb + 1]: segments
-      it.pad = 0;
-      heavy_list_all[(uint64_t)kb * MSM_NB + atomicAdd(&nheavy_all[2 * kb], 1u)] = it;
-    }
   }
   for (int d = BS_G / 2; d >= 1; d >>= 1) {
     sh[threadIdx.x] = acc;
@@ -810,50 +839,12 @@ __global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G
   if (t == 0) st_g1(out, acc.to_g1());
 }
 
-// Heavy buckets (skewed digits) with quad additions: a 256-slice segment per WORKGROUP of 64 logical lanes (four
-// slices each, then a 6-step tree), and the segment sums of one bucket per workgroup.  The list of heavy buckets is
-// short and these kernels are chains of dependent additions like the two above.
-__global__ void __launch_bounds__(256) msm_heavy_seg_quad_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
-                                                                 const uint32_t* __restrict__ slice_off_all,
-                                                                 const uint32_t* __restrict__ nheavy_all,
-                                                                 const HeavyItem* __restrict__ heavy_list_all,
-                                                                 G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap) {
-  const int kb = blockIdx.y;
-  const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
-  const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
-  const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
-  G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
-  __shared__ G1R sh[64];
-  __shared__ uint32_t found[2];
-  const uint32_t t = threadIdx.x, q = t & 3, L = t >> 2;
-  const uint32_t nitems = nheavy_all[2 * kb], nsegs = nheavy_all[2 * kb + 1];
-  for (uint32_t sg = blockIdx.x; sg < nsegs; sg += gridDim.x) {
-    for (uint32_t i = t; i < nitems; i += 256) {   // which item owns segment sg
-      const HeavyItem it = list[i];
-      if (sg >= it.seg_base && sg < it.seg_base + it.nseg) { found[0] = it.bucket; found[1] = sg - it.seg_base; }
-    }
-    __syncthreads();
-    const uint32_t b = found[0], j = found[1];
-    const uint32_t beg = slice_off[b] + j * HEAVY_SEG, bend = slice_off[b + 1];
-    G1R acc = G1R::identity();
-    for (uint32_t r = 0; r < HEAVY_SEG / 64; ++r) {
-      const uint32_t k = beg + L + 64 * r;
-      if (k < bend) acc = g1r_add_quad(acc, ld_g1r(partial + k), q);
-    }
-    for (uint32_t d = 32; d >= 1; d >>= 1) {
-      if (q == 0) sh[L] = acc;
-      __syncthreads();
-      if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
-      __syncthreads();
-    }
-    if (t == 0) st_g1r(seg_sum + sg, acc);
-    __syncthreads();
-  }
-}
+// The segment sums of one heavy bucket per workgroup, with quad additions (the segments themselves are summed by the fused
+// workers of msm_bucket_sum); the list of heavy buckets is short and this is a chain of dependent additions like the two above.
 __global__ void __launch_bounds__(256) msm_heavy_bucket_quad_kernel(const uint32_t* __restrict__ nheavy_all,
                                                                     const HeavyItem* __restrict__ heavy_list_all,
                                                                     const G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap,
-                                                                    G1RSlot* __restrict__ buckets_all) {
+                                                                    G1RSlot* __restrict__ buckets_all, uint32_t fused) {
   const int kb = blockIdx.y;
   const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
   const G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
@@ -863,6 +854,7 @@ __global__ void __launch_bounds__(256) msm_heavy_bucket_quad_kernel(const uint32
   const uint32_t nitems = nheavy_all[2 * kb];
   for (uint32_t i = blockIdx.x; i < nitems; i += gridDim.x) {
     const HeavyItem it = list[i];
+    if (it.nseg == 1 && fused) continue;   // the fused segment worker of msm_bucket_sum wrote the bucket itself (uniform per workgroup)
     G1R acc = G1R::identity();
     for (uint32_t k = L; k < it.nseg; k += 64) acc = g1r_add_quad(acc, ld_g1r(seg_sum + it.seg_base + k), q);
     for (uint32_t d = 32; d >= 1; d >>= 1) {
@@ -1188,6 +1180,11 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     bt.tail[k] = tail_dev ? tail_dev[k] : nullptr;
     bt.split[k] = (tail_dev && split) ? split[k] : ~0ull;
   }
+  {
+    const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
+    // heavy = well above the expected slice count (skewed digits): twice the uniform average, at least 16 slices
+    bt.heavy_thresh = (uint32_t)(2 * avg_slices > 16 ? 2 * avg_slices : 16);
+  }
   prof_begin(c, 2);
   rc = msm_group_sort(c, bt, mmax);
   prof_end(c, 2);
@@ -1220,24 +1217,23 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   prof_begin(c, 2);
   {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
-    // heavy = well above the expected slice count (skewed digits): twice the uniform average, at least 16 slices
-    const uint32_t heavy_thresh = (uint32_t)(2 * avg_slices > 16 ? 2 * avg_slices : 16);
-    HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 2 * MSM_MAX_BATCH, st));
-#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128, count), dim3(128), 0, st, bt, \
-                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list)
+    const uint32_t heavy_thresh = bt.heavy_thresh;                  // the list of heavy buckets was written by msm_slices_kernel
+    // PLONK_MSM_TAIL=serial: one lane per addition in the heavy-bucket, row/column and bit-sum kernels (A/B, fallback)
+    static const bool tail_quad_ = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
+    const uint32_t fused = tail_quad_ ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
+#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128 + fused, count), dim3(128), 0, st, bt, \
+                                   (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (const HeavyItem*)w.heavy_list, \
+                                   (G1RSlot*)w.seg_sum, w.cap_segs, fused)
     if (avg_slices <= 4) BSUM(1);
     else if (avg_slices <= 16) BSUM(2);
     else if (avg_slices <= 32) BSUM(4);
     else BSUM(8);
 #undef BSUM
   }
-  // PLONK_MSM_TAIL=serial: one lane per addition in the heavy-bucket, row/column and bit-sum kernels (A/B, fallback)
   static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
   if (tail_quad) {
-    hipLaunchKernelGGL(msm_heavy_seg_quad_kernel, dim3(HEAVY_WGS, count), dim3(256), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
-                       w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
     hipLaunchKernelGGL(msm_heavy_bucket_quad_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
-                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
+                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets, HEAVY_FUSED_WGS);
   } else {
     hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(4 * HEAVY_WGS, count), dim3(64), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
                        w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);

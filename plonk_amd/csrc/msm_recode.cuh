@@ -12,8 +12,8 @@
 //     where the remaining value is odd: d odd, |d| < 2^16, bucket = |d| >> 1 — the SAME 2^15 buckets hold 17-bit
 //     digits, weight = 2 * bucket + 1, and after a digit the next 16 bits are zero: consecutive digits are >= 17 bits
 //     apart and the expected distance is 18 (the run of equal bits after a digit has mean length 1): 254.9 / 18 + 1/2 =
-//     14.7 additions per scalar instead of 16 (measured over random scalars: 14.67).  The price is a table row per bit position — 256 x 128 B per point,
-//     32 GiB at 2^20 points — which is what 288 GB of HBM is for (profiles/r03a/gather_tlb.txt: the random 128-B
+//     14.7 additions per scalar instead of 16 (measured over random scalars: 14.67).  The price is a table row per bit
+//     position — 256 x 128 B per point, 32 GiB at 2^20 points — which is what 288 GB of HBM is for (profiles/r03a/gather_tlb.txt: the random 128-B
 //     gathers of msm_accumulate run at the same rate over 2, 34 or 137 GiB of tables).
 #pragma once
 #include "field.cuh"
@@ -43,7 +43,10 @@ HD void for_each_digit_window(const S& s, F&& f) {
   }
 }
 
-// limb k of an 8 x 32-bit integer with a run-time k (a select chain: a register array cannot be indexed); k >= 8 -> 0
+// limb k of an 8 x 32-bit integer with a run-time k; k >= 8 -> 0.  Registers cannot be indexed at run time: a scalar
+// held in registers goes through a select chain (8 compares + 8 selects per limb, ~70 instructions per digit — fine for
+// the host and for tests); the kernels park the scalar in LDS instead (StridedLimbs: limb k of this lane's scalar at
+// base[k * stride], one ds_read per limb, ~20 instructions per digit; r03: the select chains cost ~1 ms per proof).
 template <class S>
 HD uint32_t limb_select(const S& s, uint32_t k) {
   uint32_t r = 0;
@@ -51,6 +54,11 @@ HD uint32_t limb_select(const S& s, uint32_t k) {
   for (uint32_t j = 0; j < 8; ++j) r = (k == j) ? s.l[j] : r;
   return r;
 }
+struct StridedLimbs {     // NINE limbs are parked: limb 8 = 0, so that the 64-bit window at bit p < 256 needs no bounds test
+  const uint32_t* base;   // limb 0 of the scalar
+  uint32_t stride;        // words between consecutive limbs
+};
+HD uint32_t limb_select(const StridedLimbs& s, uint32_t k) { return s.base[k * s.stride]; }   // k <= 8
 // bits [p, p + 32) of the 256-bit integer (zero beyond bit 255)
 template <class S>
 HD uint32_t bits32_at(const S& s, uint32_t p) {
@@ -67,8 +75,9 @@ HD void for_each_digit_bitpos(const S& s, F&& f) {
   uint32_t p = 0, carry = 0;
 #pragma unroll
   for (int j = 0; j < MSM_DIGITS; ++j) {
+    const uint32_t flip = 0u - carry;                  // all ones after a negative digit
     while (p < 256) {                                  // next bit that differs from the carry
-      const uint32_t x = carry ? ~bits32_at(s, p) : bits32_at(s, p);
+      const uint32_t x = bits32_at(s, p) ^ flip;
       if (x) { p += (uint32_t)__builtin_ctz(x); break; }
       p += 32;
     }

@@ -88,6 +88,7 @@ __device__ __forceinline__ Fr scalar_canonical(const Fr& mont) {
 template <bool BITPOS>
 __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t* __restrict__ coarse_cnt_all) {
   __shared__ uint32_t hist[COARSE];
+  __shared__ uint32_t park[BITPOS ? 9 * SORT_T : 1];   // bit-position recoding: the canonical scalar, limb-major, + a zero limb (StridedLimbs)
   const int kb = blockIdx.y;
   const uint64_t m = bt.m[kb];
   const uint64_t base = (uint64_t)blockIdx.x * HIST_TILE;
@@ -108,7 +109,14 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
     if (i < m) {
       const Fr s = scalar_canonical(raw[k]);
       auto count = [&](int, uint32_t, uint32_t bucket, uint32_t) { atomicAdd(&hist[bucket >> FINE_BITS], 1u); };
-      if (BITPOS) for_each_digit_bitpos(s, count); else for_each_digit_window(s, count);
+      if (BITPOS) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) park[j * SORT_T + t] = s.l[j];   // read back by this lane only: no barrier
+        park[8 * SORT_T + t] = 0;
+        for_each_digit_bitpos(StridedLimbs{park + t, SORT_T}, count);
+      } else {
+        for_each_digit_window(s, count);
+      }
     }
   }
   __syncthreads();
@@ -208,10 +216,18 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
         where[k][w] = (bin << 16) | rank;
         word[k][w] = ((bucket & ((1u << FINE_BITS) - 1)) << 20) | (sign << 19) | (row << 11) | (t + k * SORT_T);
       };
-      if (BITPOS) for_each_digit_bitpos(s, put); else for_each_digit_window(s, put);
+      if (BITPOS) {   // the canonical scalar parked in the (still unused) staging area, limb-major; only this lane reads it back
+        uint32_t* park = stage + k * (9 * SORT_T);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) park[j * SORT_T + t] = s.l[j];
+        park[8 * SORT_T + t] = 0;
+        for_each_digit_bitpos(StridedLimbs{park + t, SORT_T}, put);
+      } else {
+        for_each_digit_window(s, put);
+      }
     }
   }
-  __syncthreads();
+  __syncthreads();   // (also: every parked scalar has been read before the staging area is written below)
   {
     const uint32_t c0 = hist[2 * t], c1 = hist[2 * t + 1];
     uint32_t total;
@@ -386,11 +402,17 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
 }
 
 // ---- slice offsets: slice_off[b] = sum_{b' < b} ceil(count[b'] / ksl), one workgroup per commitment
+// Also lists the HEAVY buckets (more than heavy_thresh slices: skewed digits) with their 256-slice segments —
+// nheavy[2 kb] buckets, nheavy[2 kb + 1] segments — for the segment workers inside msm_bucket_sum (msm.hip).
+static constexpr uint32_t HEAVY_SEG_SLICES = 256;
 __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __restrict__ offsets_all,
-                                                            uint32_t* __restrict__ slice_off_all, uint32_t ksl) {
+                                                            uint32_t* __restrict__ slice_off_all, uint32_t ksl, uint32_t heavy_thresh,
+                                                            uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
   __shared__ uint32_t sh[SORT_T];
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
   uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  uint32_t* __restrict__ nheavy = nheavy_all + 2 * blockIdx.x;
+  HeavyItem* __restrict__ heavy_list = heavy_list_all + (uint64_t)blockIdx.x * MSM_NB;
   constexpr uint32_t PER = MSM_NB / SORT_T;
   const uint32_t t = threadIdx.x;
   uint32_t mine = 0;
@@ -403,7 +425,16 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
   for (uint32_t k = 0; k < PER; ++k) {
     const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
     slice_off[t * PER + k] = run;
-    run += (c + ksl - 1) / ksl;
+    const uint32_t ns = (c + ksl - 1) / ksl;
+    run += ns;
+    if (ns > heavy_thresh) {
+      HeavyItem it;
+      it.bucket = t * PER + k;
+      it.nseg = (ns + HEAVY_SEG_SLICES - 1) / HEAVY_SEG_SLICES;
+      it.seg_base = atomicAdd(&nheavy[1], it.nseg);
+      it.pad = 0;
+      heavy_list[atomicAdd(&nheavy[0], 1u)] = it;
+    }
   }
   if (t == SORT_T - 1) slice_off[MSM_NB] = total;
 }
@@ -486,7 +517,9 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
     hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, (const WordT*)tmp,
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
-  hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl);
+  HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 2 * MSM_MAX_BATCH, st));
+  hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
+                     w.nheavy, (HeavyItem*)w.heavy_list);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

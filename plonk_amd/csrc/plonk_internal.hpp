@@ -61,11 +61,14 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   uint64_t table_n;    // points per row of `table`
   uint32_t rows;       // MSM_ROWS_WINDOW (16) or MSM_ROWS_BITPOS (256): which recoding the entries come from
   uint32_t wide;       // the coarse-partitioned words are 64-bit (rows * table_n above 2^27)
+  uint32_t heavy_thresh;   // a bucket with more slices than this is "heavy" (msm_slices_kernel lists it, msm.hip sums it by segments)
   // scalars of commitment k: scalars[k][i] for i < split[k], tail[k][i - split[k]] above (a wire column in place + its
   // blinders elsewhere); split[k] >= m[k] when the scalars are one array
   const Fr* tail[MSM_MAX_BATCH];
   uint64_t split[MSM_MAX_BATCH];
 };
+
+struct HeavyItem { uint32_t bucket, seg_base, nseg, pad; };   // a bucket with far more slices than expected, cut into 256-slice segments
 
 struct MsmWork {   // per-context scratch, grown on demand
   uint64_t cap_m = 0;
@@ -106,8 +109,10 @@ struct Ctx {
   std::set<const void*> smem_opt_in;   // kernels whose dynamic-LDS limit was raised on THIS device (hipFuncSetAttribute is per device)
   // NTT staging for the host-pointer API
   Fr* ntt_buf = nullptr;
-  Fr* ntt_buf2 = nullptr;          // second transform buffer of plonk_ntt_batch's upload/compute/download pipeline
+  Fr* ntt_buf2 = nullptr;          // second and third transform buffer of plonk_ntt_batch's upload / compute / download pipeline
+  Fr* ntt_buf3 = nullptr;
   hipStream_t copy_stream = nullptr;
+  hipStream_t down_stream = nullptr;   // device -> host leg of that pipeline
   Fr* ntt_tmp = nullptr;
   uint64_t ntt_cap = 0;
   // SRS

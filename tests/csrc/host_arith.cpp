@@ -222,9 +222,16 @@ extern "C" int h_msm_recode(const uint32_t* scalar, int bitpos, uint32_t* out) {
   Big<8> s;
   memcpy(s.l, scalar, 32);
   int n = 0;
-  for_each_digit(s, bitpos ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW, [&](int slot, uint32_t row, uint32_t bucket, uint32_t sign) {
+  auto emit = [&](int slot, uint32_t row, uint32_t bucket, uint32_t sign) {
     out[4 * n] = (uint32_t)slot; out[4 * n + 1] = row; out[4 * n + 2] = bucket; out[4 * n + 3] = sign;
     ++n;
-  });
+  };
+  if (bitpos == 2) {   // the kernels' form: the scalar parked limb-major with a stride (StridedLimbs)
+    uint32_t park[9 * 3];
+    for (int j = 0; j < 9; ++j) { park[3 * j] = 0xdeadbeefu; park[3 * j + 1] = j < 8 ? s.l[j] : 0u; park[3 * j + 2] = 0x12345678u; }
+    for_each_digit_bitpos(StridedLimbs{park + 1, 3}, emit);
+  } else {
+    for_each_digit(s, bitpos ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW, emit);
+  }
   return n;
 }

@@ -112,6 +112,8 @@ def test_product_recoding_matches_the_models():
         got = [(out[4 * j + 1], (2 * out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1)) for j in range(n)]
         assert [out[4 * j] for j in range(n)] == list(range(n))          # slots are consecutive
         assert got == bitpos_digits(s), hex(s)
+        n2 = lib.h_msm_recode(limbs, 2, out)                                # the LDS-parked form the kernels use
+        assert [(out[4 * j + 1], (2 * out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1)) for j in range(n2)] == got
         n = lib.h_msm_recode(limbs, 0, out)
         got = {out[4 * j + 1]: (out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1) for j in range(n)}
         want = {w: d for w, d in enumerate(signed_digits(s, 16)) if d}
