@@ -164,7 +164,11 @@ typedef struct {
    * shard_world <= 1: all size + 2 points (lagrange_count == size + 2) of a key computed earlier for the same
    *   commit key and size — the prover then skips the group FFT (the bulk of its build time); NULL = derive it.
    * shard_world > 1: the slice [shard_rank * S, shard_rank * S + lagrange_count) of those points, S as above;
-   *   NULL / 0 = commit to the wire polynomials in coefficient form. */
+   *   NULL / 0 = commit to the wire polynomials in coefficient form.
+   * A supplied key is validated: every point on the curve and in the prime-order subgroup (PLONK_ERR_POINT) and, on one
+   * GPU, the whole key against the context's commit key by a random linear combination — one inverse transform and two
+   * MSMs (PLONK_ERR_DATA for the key of another setup, a permuted or otherwise wrong key).  A rank of a sharded prover
+   * holds only slices of both keys and checks the points alone. */
   const uint8_t* lagrange_xy96;
   uint64_t lagrange_count;
 } plonk_prover_desc;
@@ -185,7 +189,9 @@ int plonk_prover_peek(plonk_prover* p, int which, uint64_t offset, uint64_t coun
  * interpolated on the 4n coset and de-aliased — the same t(X), hence the same proof
  * bytes — and an unsatisfied witness is recognised by the quotient identity failing at the evaluation
  * challenge (probability of missing it <= 5n/q); PLONK_QUOTIENT_DOMAIN=8 in the environment selects the
- * reference's 8n evaluation with its exact degree test. */
+ * reference's 8n evaluation with its exact degree test.
+ * One deviation: when the evaluation challenge z or z * omega is ZERO (probability 2^-254) the opening quotients are
+ * computed with 1 / z, and the call returns PLONK_ERR_STATE where the reference would go on to emit a proof. */
 int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const uint64_t* pi_idx,
                        const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
                        uint8_t proof[1008]);
@@ -283,7 +289,12 @@ int plonk_comm_destroy(plonk_ctx* ctx);
  * (Prover::try_from_bytes) or by plonk_prover_from_bytes later.  plonk_verifier_to_bytes writes Verifier::to_bytes()
  * (src/compiler/verifier.rs:88-117) from the prover's label / sizes / VerifierKey, the caller's OpeningKey::to_bytes()
  * (opaque here: G2 never enters this library) and the public-input indexes.
- * Both: out == NULL reports the length in *len; otherwise cap >= *len bytes are written.  Single-GPU provers only. */
+ * Both: out == NULL reports the length in *len; otherwise cap >= *len bytes are written.  Single-GPU provers only.
+ * Known differences from the reference's bytes (format parity is pinned only to the restated layout):
+ * plonk_prover_from_bytes keeps the size + 8 commit-key points prove() can touch, so from_bytes -> to_bytes writes a
+ * SHORTER commit key than a blob whose key was trimmed to (constraints + 6).next_power_of_two() + 7 points (the proofs
+ * are identical; the blob is not byte-identical, and generic plonk_msm calls on that context cannot use the dropped
+ * degrees).  No new format entry points are planned until a reference-produced blob pins these (tools/dump_kat_blob.rs). */
 int plonk_prover_to_bytes(plonk_prover* p, uint8_t* out, uint64_t cap, uint64_t* len);
 int plonk_verifier_to_bytes(plonk_prover* p, const uint8_t* opening_key, uint64_t opening_key_len,
                             const uint64_t* pi_idx, uint64_t pi_count, uint8_t* out, uint64_t cap, uint64_t* len);

@@ -71,6 +71,7 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
 struct HeavyItem { uint32_t bucket, seg_base, nseg, pad; };   // a bucket with far more slices than expected, cut into 256-slice segments
 
 struct MsmWork {   // per-context scratch, grown on demand
+  bool fixed_ok = false;           // every size-independent buffer below is allocated (msm_reserve: all or nothing)
   uint64_t cap_m = 0;
   uint32_t* tmp_words = nullptr;   // W * m words grouped by coarse bin (msm_sort.hip); room for 64-bit words
   uint32_t* entries = nullptr;     // W * m entries grouped by bucket

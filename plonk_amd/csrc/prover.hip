@@ -193,6 +193,48 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
   return msm_batch_device(p->c, sc, cnt, count, out, true);
 }
 static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) { return msm_group(p, &scalars, &m, 1, slot); }
+static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48]);
+
+// A Lagrange-basis key handed in by the caller (plonk_prover_desc.lagrange_xy96, kept from an earlier plonk_lagrange_key)
+// must be THE Lagrange form of the context's commit key — a key cached from another SRS would give wire commitments that
+// disagree with every other commitment of the proof, and the prover's own identity check would not notice.  Checked the
+// way the wire commitments use it: for pseudo-random values r_0 .. r_{n+1},
+//     sum_{i<n} r_i [L_i(tau)] G + r_n ([tau^n] G - G) + r_{n+1} ([tau^(n+1)] G - [tau] G)   (an MSM over the supplied key)
+// must be the commitment of interpolate(r_0 .. r_{n-1}) + (r_n + r_{n+1} X)(X^n - 1) over the context's key — one inverse
+// transform and two MSMs, once per prover.  A wrong point survives with probability ~2^-64 (the r_i are 64-bit).
+__device__ __host__ static inline uint64_t lag_check_mix(uint64_t i) {
+  uint64_t x = (i + 1) * 0x9e3779b97f4a7c15ull;
+  x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+  return x | 1ull;
+}
+__global__ void lag_check_fill_kernel(Fr* r, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) r[i] = Fr::from_u64(lag_check_mix(i));
+}
+static int check_lagrange_key(Prover* p, uint32_t L) {
+  Ctx* c = p->c;
+  const uint64_t n = 1ull << L;
+  Fr* r = p->agg;        // n + 2 values
+  Fr* coef = p->wit;     // n + 2 coefficients
+  hipLaunchKernelGGL(lag_check_fill_kernel, dim3((uint32_t)((n + 2 + 255) / 256)), dim3(256), 0, c->stream, r, n + 2);
+  HIP_TRY(hipGetLastError());
+  uint64_t m = n + 2;
+  const Fr* sc = r;
+  PTRY(msm_group(p, &sc, &m, 1, 0, p->lag_table, p->lag_n));
+  PTRY(ntt_device(c, r, coef, p->wit2, L, true, false, n));
+  BlindArgs ba;
+  ba.count = 2;
+  ba.b[0] = Fr::from_u64(lag_check_mix(n));
+  ba.b[1] = Fr::from_u64(lag_check_mix(n + 1));
+  ba.b[2] = Fr::zero();
+  PTRY(poly_blind(c, coef, n, ba));     // coef -= (b0 + b1 X), coef[n], coef[n + 1] = b0, b1: + (b0 + b1 X)(X^n - 1)
+  PTRY(msm_to(p, coef, n + 2, 1));
+  uint8_t out[2][48];
+  PTRY(fetch_commitments(p, 0, 2, out));
+  if (memcmp(out[0], out[1], 48) != 0)
+    return (plonk::set_last_error("lagrange_xy96", "not the Lagrange-basis form of this context's commit key", __FILE__, __LINE__), PLONK_ERR_DATA);
+  return PLONK_OK;
+}
 // Bring `count` results to the host, all-gather the per-rank partial sums (EC addition is not
 // an RCCL reduction, so the "bucket-sum all-reduce" is an all-gather + local add), normalise
 // to affine on the host (one Fp inversion each) and compress.
@@ -538,12 +580,19 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
       } else {
         rc = lagrange_points_device(c, L, lag_pts);
       }
+      if (rc == PLONK_OK && d->lagrange_xy96) rc = srs_validate_device(c, lag_pts, n + 2, p->flag_dev);   // on the curve, in the subgroup
       if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table, &p->lag_rows);
       p->lag_n = n + 2;
       p->lag_on = true;
       if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
       (void)hipFree(lag_pts);
       if (rc) return rc;
+      if (d->lagrange_xy96) {
+        int bad = 0;
+        HIP_TRY(hipMemcpy(&bad, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad) return (plonk::set_last_error("lagrange_xy96", "point off the curve or outside the prime-order subgroup", __FILE__, __LINE__), PLONK_ERR_POINT);
+        PTRY(check_lagrange_key(p, L));
+      }
       HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
     } else if (p->world > 1 && !(wc && wc[0] == 'c') && d->lagrange_xy96) {
       // multi-GPU: the rank's slice [shard_lo, shard_lo + count) of the (n + 2)-point Lagrange key, computed where the whole
@@ -557,10 +606,16 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
         HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * want));
         int rc = PLONK_OK;
         if (hipMemcpyAsync(lag_pts, d->lagrange_xy96, sizeof(G1Affine) * want, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
+        // a rank holds a SLICE of both keys, so only the points themselves can be checked here (curve, subgroup); the
+        // consistency of the whole key with the commit key is the single-GPU check above, run where plonk_lagrange_key ran
+        if (rc == PLONK_OK) rc = srs_validate_device(c, lag_pts, want, p->flag_dev);
         if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, want, &p->lag_table, &p->lag_rows);
         if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
         (void)hipFree(lag_pts);
         if (rc) return rc;
+        int bad = 0;
+        HIP_TRY(hipMemcpy(&bad, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+        if (bad) return (plonk::set_last_error("lagrange_xy96", "point off the curve or outside the prime-order subgroup", __FILE__, __LINE__), PLONK_ERR_POINT);
       }
       p->lag_n = want;
       p->lag_on = true;

@@ -235,3 +235,20 @@ extern "C" int h_msm_recode(const uint32_t* scalar, int bitpos, uint32_t* out) {
   }
   return n;
 }
+
+// ---- fp_safegcd.cuh: Bernstein-Yang inversion against Fermat (fp28_inv) and the oracle ----
+#include "../../plonk_amd/csrc/fp_safegcd.cuh"
+// a: Fp (12 x u32, R = 2^384 Montgomery) -> o: its inverse in the same form, through Fp28 and the safegcd inverse
+extern "C" void h_fp_inv_gcd(const uint32_t* a, uint32_t* o) {
+  Fp x; memcpy(&x, a, 48);
+  Fp r = fp28_inv_gcd(Fp28::from_fp(x)).to_fp();
+  memcpy(o, &r, 48);
+}
+// same input scaled lazily (value 5x + 3x = 8x as unreduced limbs < 64p): the inverse of 8x
+extern "C" void h_fp_inv_gcd_lazy(const uint32_t* a, uint32_t* o) {
+  Fp x; memcpy(&x, a, 48);
+  const Fp28 A = Fp28::from_fp(x);
+  const Fp28 A8 = Fp28::add(Fp28::add(A.dbl().dbl(), A), Fp28::add(A.dbl(), A));
+  Fp r = fp28_inv_gcd(A8).to_fp();
+  memcpy(o, &r, 48);
+}

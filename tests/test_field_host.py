@@ -19,7 +19,8 @@ def build_host_lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
     hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
-            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp", "g1codec.cuh")]
+            for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp", "g1codec.cuh",
+                      "msm_recode.cuh", "fp_safegcd.cuh")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -334,3 +335,16 @@ def test_g1_decompress48_matches_the_oracle(lib):
             y = min(y, P - y)
             assert out.raw == E.g1_to_raw96((x, y))
     assert bad > 5
+
+
+def test_safegcd_inverse_matches_the_oracle(lib):
+    """fp_safegcd.cuh (Bernstein-Yang division steps, 13 signed 30-bit limbs) through the Fp28 interface: x -> x^-1 for edge
+    values and random ones, lazily reduced inputs included; 0 -> 0."""
+    rnd = random.Random(381)
+    out = (ctypes.c_uint32 * 12)()
+    vals = edge_values(P, rnd, 150) + [(1 << k) % P for k in (1, 29, 30, 31, 59, 60, 380)] + [P - (1 << 30), (P + 1) // 2, 3, P - 3]
+    for a in vals:
+        lib.h_fp_inv_gcd(fp_limbs(a), out)
+        assert fp_val(out) == (pow(a, -1, P) if a else 0), hex(a)
+        lib.h_fp_inv_gcd_lazy(fp_limbs(a), out)
+        assert fp_val(out) == (pow(8 * a % P, -1, P) if a else 0), hex(a)

@@ -139,11 +139,30 @@ def test_cached_lagrange_key_gives_the_same_prover(ctx):
     with pytest.raises(plonk_amd.PlonkError) as e:
         plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=key[:-96])
     assert e.value.code == -1
-    # a corrupted key is a different commit key for the wires: the proof changes (nothing validates 2^20 points per build)
+    # a supplied key is checked against the context's commit key (a stale cached key used to yield proofs that
+    # only the verifier rejected): two points swapped -> valid points, wrong key: PLONK_ERR_DATA
     bad = bytearray(key)
-    bad[96 * 5:96 * 6] = key[96 * 6:96 * 7]
-    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=bytes(bad))
-    assert gp.prove(case["wires"], case["pi"], C.fr_vals(bl)) != want
+    bad[96 * 5:96 * 6], bad[96 * 6:96 * 7] = key[96 * 6:96 * 7], key[96 * 5:96 * 6]
+    with pytest.raises(plonk_amd.PlonkError) as e:
+        plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=bytes(bad))
+    assert e.value.code == -9
+    # the key of ANOTHER setup (tau + 1): PLONK_ERR_DATA as well
+    other = C.synthetic_srs(n + 7, tau=(0x5EED0000 * 0x9E3779B97F4A7C15 + 1) % C.Q)
+    ctx.srs_load_bytes(other, len(other) // 96)
+    stale = ctx.lagrange_key(log_n)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    with pytest.raises(plonk_amd.PlonkError) as e:
+        plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=stale)
+    assert e.value.code == -9
+    # a point off the curve: PLONK_ERR_POINT
+    bad = bytearray(key)
+    bad[96 * 9] ^= 1
+    with pytest.raises(plonk_amd.PlonkError) as e:
+        plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=bytes(bad))
+    assert e.value.code == -10
+    # and the honest key still works afterwards
+    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], lagrange_slice=key)
+    assert gp.prove(case["wires"], case["pi"], C.fr_vals(bl)) == want
     gp.close()
 
 
