@@ -170,9 +170,13 @@ HD Fp28 fp28_inv(const Fp28& a) {
   return acc;
 }
 
-// affine coordinates (x, y) < 2p of a finite point
+}  // namespace plonk
+#include "fp_safegcd.cuh"
+namespace plonk {
+
+// affine coordinates (x, y) < 2p of a finite point (safegcd inverse: ~23 k instructions instead of ~300 k)
 HD void g1r_to_affine(const G1R& p, Fp28* x, Fp28* y) {
-  const Fp28 inv = fp28_inv(Fp28::mul(p.ZZ, p.ZZZ));
+  const Fp28 inv = fp28_inv_gcd(Fp28::mul(p.ZZ, p.ZZZ));
   const Fp28 izz = Fp28::mul(inv, p.ZZZ);
   const Fp28 izzz = Fp28::mul(inv, p.ZZ);
   *x = Fp28::mul(p.X, izz);

@@ -117,8 +117,8 @@ __device__ __forceinline__ void st_g1r(G1RSlot* p, const G1R& v) {
 // tables) or rows = 256, step = 1 (bit-position tables).  One lane per point: (rows - 1) * step doublings in XYZZ
 // coordinates, and ONE Fp inversion for the rows - 1 normalisations (Montgomery's trick along the lane's own rows: the
 // unnormalised X, Y wait in their table slots, ZZ, ZZZ and the running product of the ZZ * ZZZ in a scratch array of
-// 3 x 64 B per row and point; a Fermat inversion is ~570 products, as much as 60 doublings, and one per row made the
-// inversions 4/5 of this kernel).  The doubling chain has the same length for both kinds of table (240 / 255
+// 3 x 64 B per row and point; one inversion per row made the inversions 4/5 of this kernel; the one that remains is the
+// safegcd inverse of fp_safegcd.cuh).  The doubling chain has the same length for both kinds of table (240 / 255
 // doublings); bit-position tables store — and normalise — every step of it.  One-off per commit key, outside every
 // timed region.  `pts` holds points [first, first + count) of the key (a chunk of the stream in plonk_srs_load); row r
 // starts at r * n.  scratch: [(rows - 1) * 3][count] slots.
@@ -145,7 +145,7 @@ __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __
     run = Fp28::mul(run, Fp28::mul(p.ZZ, p.ZZZ));
     st_f28(sc + 2 * count, run);
   }
-  Fp28 inv = fp28_inv(run);                                // 1 / prod_w ZZ_w ZZZ_w
+  Fp28 inv = fp28_inv_gcd(run);                            // 1 / prod_w ZZ_w ZZZ_w
   for (uint32_t w = rows - 1; w >= 1; --w) {
     const Fp28Slot* sc = scratch + (uint64_t)(w - 1) * 3 * count + j;
     const Fp28 zz = ld_f28(sc), zzz = ld_f28(sc + count);

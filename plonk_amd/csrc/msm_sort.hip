@@ -60,6 +60,26 @@ template <> struct SortWord<uint64_t> {
   __device__ static __forceinline__ uint32_t fine(uint64_t w) { return (uint32_t)(w >> 32); }
   __device__ static __forceinline__ uint32_t entry(uint64_t w) { return (uint32_t)w; }
 };
+// The coarse-partitioned words in HBM.  Narrow: one u32 plane.  Wide (register form fine << 32 | entry): a u32 plane with
+// the entry and a BYTE plane with the fine bucket — 5 bytes per word out and back instead of 8, and the histogram passes
+// read only the byte plane.  Both planes live in MsmWork::tmp_words: [KB][W * cap] u32, then [KB][W * cap] u8.
+template <class WordT> struct TmpPlanes;
+template <> struct TmpPlanes<uint32_t> {
+  uint32_t* lo;
+  __device__ __forceinline__ TmpPlanes(void* all, int kb, uint64_t words) : lo((uint32_t*)all + (uint64_t)kb * words) {}
+  __device__ __forceinline__ uint32_t ld(uint32_t j) const { return lo[j]; }
+  __device__ __forceinline__ uint32_t ld_fine(uint32_t j) const { return SortWord<uint32_t>::fine(lo[j]); }
+  __device__ __forceinline__ void st(uint32_t j, uint32_t w) const { lo[j] = w; }
+};
+template <> struct TmpPlanes<uint64_t> {
+  uint32_t* lo;
+  uint8_t* hi;
+  __device__ __forceinline__ TmpPlanes(void* all, int kb, uint64_t words)
+      : lo((uint32_t*)all + (uint64_t)kb * words), hi((uint8_t*)((uint32_t*)all + (uint64_t)MSM_MAX_BATCH * words) + (uint64_t)kb * words) {}
+  __device__ __forceinline__ uint64_t ld(uint32_t j) const { return ((uint64_t)hi[j] << 32) | lo[j]; }
+  __device__ __forceinline__ uint32_t ld_fine(uint32_t j) const { return hi[j]; }
+  __device__ __forceinline__ void st(uint32_t j, uint64_t w) const { lo[j] = (uint32_t)w; hi[j] = (uint8_t)(w >> 32); }
+};
 // tile-local form staged in LDS by msm_partition: fine (4) | sign (1) | table row (8) | scalar inside the tile (11)
 static_assert(TILE <= 2048, "tile-local word: 11 bits of scalar index");
 
@@ -186,7 +206,7 @@ template <bool BITPOS, class WordT>
 __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint64_t srs_n,
                                                                const uint32_t* __restrict__ coarse_off_all,
                                                                uint32_t* __restrict__ coarse_cur_all,
-                                                               WordT* __restrict__ tmp_all) {
+                                                               void* __restrict__ tmp_all) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* stage = lds;                          // TILE * MSM_W
   uint32_t* hist = lds + TILE * MSM_W;            // COARSE: entries of this tile per bin
@@ -240,7 +260,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
     gbase[2 * t + 1] = c1 ? coff[2 * t + 1] + atomicAdd(&cur[2 * t + 1], c1) : 0;
   }
   __syncthreads();
-  WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
 #pragma unroll
   for (uint32_t k = 0; k < PER_T; ++k)
 #pragma unroll
@@ -253,7 +273,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
     const uint32_t cnt = hist[bin], lo = loff[bin], gb = gbase[bin];
     for (uint32_t j = sub; j < cnt; j += 16) {
       const uint32_t lw = stage[lo + j];          // tile-local word -> global word: table index = row * points + scalar
-      tmp[gb + j] = SortWord<WordT>::make(lw >> 20, (lw >> 19) & 1u, (uint64_t)((lw >> 11) & 0xffu) * srs_n + base + (lw & 0x7ffu));
+      tmp.st(gb + j, SortWord<WordT>::make(lw >> 20, (lw >> 19) & 1u, (uint64_t)((lw >> 11) & 0xffu) * srs_n + base + (lw & 0x7ffu)));
     }
   }
 }
@@ -270,14 +290,14 @@ static constexpr uint32_t FINE_CACHE = PLONK_FINE_CACHE;   // words per thread k
                                                            // 10240 words (mean 8192 at 2^20 terms), anything beyond is re-read; A/B r02: -0.25 ms per proof
 template <class WordT>
 __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
-                                                          const WordT* __restrict__ tmp_all,
+                                                          void* __restrict__ tmp_all,
                                                           uint32_t* __restrict__ entries_all,
                                                           uint32_t* __restrict__ offsets_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS], start[1u << FINE_BITS], cur[1u << FINE_BITS];
   const int kb = blockIdx.y;
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
-  const WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
   uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t beg = coff[bin], end = coff[bin + 1];
@@ -288,12 +308,12 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r) {
     const uint32_t j = beg + t + r * FINE_T;
-    cache[r] = j < end ? tmp[j] : 0u;
+    cache[r] = j < end ? tmp.ld(j) : (WordT)0;
   }
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r)
     if (beg + t + r * FINE_T < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
-  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) atomicAdd(&cnt[SortWord<WordT>::fine(tmp[j])], 1u);
+  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) atomicAdd(&cnt[tmp.ld_fine(j)], 1u);
   __syncthreads();
   if (t == 0) {
     uint32_t run = beg;
@@ -313,7 +333,7 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r)
     if (beg + t + r * FINE_T < end) place(cache[r]);
-  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) place(tmp[j]);
+  for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) place(tmp.ld(j));
 }
 
 // ---- level 2 for oversized bins: one workgroup per BIG_CHUNK words --------------------------------
@@ -337,25 +357,25 @@ static constexpr uint32_t BIG_PER = BIG_CHUNK / BIG_T;   // words per lane, held
 template <class WordT>
 __global__ void __launch_bounds__(BIG_T) msm_big_hist_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
                                                              const uint32_t* __restrict__ big_off_all,
-                                                             const WordT* __restrict__ tmp_all, uint32_t* __restrict__ big_cnt_all) {
+                                                             void* __restrict__ tmp_all, uint32_t* __restrict__ big_cnt_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS];
   const int kb = blockIdx.y;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
   uint32_t bin, beg, end;
   if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
-  const WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
   const uint32_t t = threadIdx.x;
   if (t < (1u << FINE_BITS)) cnt[t] = 0;
   __syncthreads();
-  for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[SortWord<WordT>::fine(tmp[j])], 1u);
+  for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[tmp.ld_fine(j)], 1u);
   __syncthreads();
   if (t < (1u << FINE_BITS) && cnt[t]) atomicAdd(&big_cnt_all[(uint64_t)kb * MSM_NB + (bin << FINE_BITS) + t], cnt[t]);
 }
 template <class WordT>
 __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
                                                                 const uint32_t* __restrict__ big_off_all,
-                                                                const WordT* __restrict__ tmp_all,
+                                                                void* __restrict__ tmp_all,
                                                                 const uint32_t* __restrict__ big_cnt_all, uint32_t* __restrict__ big_cur_all,
                                                                 uint32_t* __restrict__ entries_all, uint32_t* __restrict__ offsets_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS], base[1u << FINE_BITS], cur[1u << FINE_BITS];
@@ -364,7 +384,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
   uint32_t bin, beg, end;
   if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
-  const WordT* __restrict__ tmp = tmp_all + (uint64_t)kb * MSM_W * bt.cap_m;
+  const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
   uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ bcnt = big_cnt_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
@@ -376,7 +396,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
 #pragma unroll
   for (uint32_t r = 0; r < BIG_PER; ++r) {
     const uint32_t j = beg + t + r * BIG_T;
-    cache[r] = j < end ? tmp[j] : (WordT)0;
+    cache[r] = j < end ? tmp.ld(j) : (WordT)0;
     if (j < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
   }
   __syncthreads();
@@ -500,21 +520,21 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   hipStream_t st = c->stream;
   const uint32_t tiles = (uint32_t)((mmax + TILE - 1) / TILE);
   const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
-  WordT* tmp = reinterpret_cast<WordT*>(w.tmp_words);
+  void* tmp = (void*)w.tmp_words;
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
   hipLaunchKernelGGL(msm_hist_kernel<BITPOS>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
   smem_opt_in(c, (const void*)msm_partition_kernel<BITPOS, WordT>, PARTITION_LDS);
   hipLaunchKernelGGL((msm_partition_kernel<BITPOS, WordT>), dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
                      w.coarse_off, w.coarse_cur, tmp);
-  hipLaunchKernelGGL(msm_fine_kernel<WordT>, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, (const WordT*)tmp,
+  hipLaunchKernelGGL(msm_fine_kernel<WordT>, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, tmp,
                      w.entries, w.offsets);
   {   // oversized bins (skewed digits): upper bound of the chunk count known on the host, surplus workgroups exit at once
     const uint64_t words = (uint64_t)MSM_W * mmax;
     const uint32_t big_wgs = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
     HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
-    hipLaunchKernelGGL(msm_big_hist_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, (const WordT*)tmp, w.big_cnt);
-    hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, (const WordT*)tmp,
+    hipLaunchKernelGGL(msm_big_hist_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp, w.big_cnt);
+    hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp,
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
   HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 2 * MSM_MAX_BATCH, st));

@@ -252,3 +252,11 @@ extern "C" void h_fp_inv_gcd_lazy(const uint32_t* a, uint32_t* o) {
   Fp r = fp28_inv_gcd(A8).to_fp();
   memcpy(o, &r, 48);
 }
+
+// Fr: a (8 x u32, R = 2^256 Montgomery) -> its inverse in the same form, through twiddle form and the safegcd inverse
+extern "C" void h_fr_inv_gcd(const uint32_t* a, uint32_t* o) {
+  Fr x; memcpy(&x, a, 32);
+  const Fr29 inv_t = fr29_inv_gcd_tw(Fr29::twiddle_from_fr(x));          // x^-1 * 2^261
+  Fr r = Fr29::mul(inv_t, Fr29::from_fr(Fr::one())).to_fr();              // * R / 2^261 = x^-1 R
+  memcpy(o, &r, 32);
+}

@@ -348,3 +348,12 @@ def test_safegcd_inverse_matches_the_oracle(lib):
         assert fp_val(out) == (pow(a, -1, P) if a else 0), hex(a)
         lib.h_fp_inv_gcd_lazy(fp_limbs(a), out)
         assert fp_val(out) == (pow(8 * a % P, -1, P) if a else 0), hex(a)
+
+
+def test_safegcd_inverse_in_fr_matches_the_oracle(lib):
+    """the 9-limb instance (batch_inverse_kernel's workgroup inversion): x -> x^-1 mod q in twiddle form"""
+    rnd = random.Random(255)
+    out = (ctypes.c_uint32 * 8)()
+    for a in edge_values(Q, rnd, 200) + [Q - (1 << 30), (Q + 1) // 2, 7, pow(7, (Q - 1) >> 32, Q)]:
+        lib.h_fr_inv_gcd(fr_limbs(a), out)
+        assert fr_val(out) == (pow(a, -1, Q) if a else 0), hex(a)

@@ -49,6 +49,7 @@ def test_bench_proof_verifies(log_n):
         # the key polynomials are INPUTS of prove() (Compiler::compile made them); pin one GPU-interpolated column to
         # the CPU transform so that the shared input is not taken on trust
         assert cbind.ntt_bytes(q_m_column, log_n, True, False, n, threads) == polys["q_m"]
+        polys = {k: (v if isinstance(v, (bytes, bytearray)) else mont(v)) for k, v in polys.items()}   # short ones come as integers
         cp = cbind.CProver(n, b"bench", polys, bytes(96 * (n + 7)), vk48=raw, threads=threads)
         cp.set_trapdoor(mont([tau]), mont([g]))
         expected = cp.prove(wires, [], b"", bl1)

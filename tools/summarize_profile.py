@@ -23,7 +23,7 @@ for r in list(csv.DictReader(open(base + "trace/bench_kernel_stats.csv")))[:22]:
                                                 float(r["AverageNs"]) / 1e3, r["Percentage"]))
 try:   # the launches that belong to proofs (bench.py's roofline leg times exactly these): 4 per proof, at the end
     tr = sorted(csv.DictReader(open(base + "trace/bench_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
-    acc_d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if "msm_accumulate" in r["Kernel_Name"]]
+    acc_d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if "msm_accumulate" in r["Kernel_Name"]]   # any variant (ordered lanes by default)
     nproofs = (len(acc_d) - 4) // 4          # setup commits the 15 key polynomials in 4 group launches
     prove_d = acc_d[-4 * nproofs:]
     out.append(f"\n`msm_accumulate_kernel` launches inside prove() only ({len(prove_d)} launches = {nproofs} proofs x 4 commitment groups): "
@@ -36,7 +36,10 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(base + f"pmc_{C}/bench_counter_collection.csv")))
     agg = collections.defaultdict(list)
     for r in rows:
-        agg[r["Kernel_Name"].split("(")[0][:70]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0][:70]
+        if name.startswith("plonk::msm_accumulate"):
+            name = "plonk::msm_accumulate_kernel"       # the ordered-lane variant is the default from 2^19 terms: one row
+        agg[name].append(float(r["Counter_Value"]))
     pm[C] = agg
     out.append(f"\n## {C} per launch (raw counter value, KiB)\n\n| kernel | launches | avg per launch |\n|---|---|---|")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:10]:
@@ -47,6 +50,8 @@ try:
     cnt = collections.Counter()
     for r in rows:
         k = r["Kernel_Name"].split("(")[0][:50]
+        if k.startswith("plonk::msm_accumulate"):
+            k = "plonk::msm_accumulate_kernel"
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     out.append("\n## SQ counters (summed over launches of 1 proof + setup)\n\n| kernel | SQ_WAVES | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAIT_INST_ANY | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES |\n|---|---|---|---|---|---|---|")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:8]:
@@ -62,8 +67,9 @@ if acc in pm["FETCH_SIZE"]:
     out.append(f"* MI355X_MICROARCH.md §HBM correction (gfx950 FETCH_SIZE = 1/2 of wide-read bytes): read = 2 x FETCH = {2 * fa * 1024 / 1e9:.2f} GB, "
                f"+ written {wa * 1024 / 1e9:.2f} GB = **{(2 * fa + wa) * 1024 / 1e9:.2f} GB per launch** (upper bound — the gather pattern here is 4 x 16 B per lane "
                f"from random 128-B table entries, for which the guide gives no calibration; uncorrected it is {(fa + wa) * 1024 / 1e9:.2f} GB).")
-    out.append("* algorithmic bytes per launch (bench.py): (32 b + 96) m averaged over the groups = 0.193 GB.  The excess is by design: 16 precomputed "
-               "window tables are gathered (16 x 128 B per term) so that all windows share one bucket set; the kernel is integer-VALU bound, not HBM bound.")
+    out.append("* algorithmic bytes per launch (bench.py): (32 b + 96) m averaged over the groups = 0.193 GB.  The excess is by design: one precomputed "
+               "table row per digit position is gathered (~14.7 x 128 B per term with bit-position tables, 16 x 128 B with window tables) so that all digits "
+               "share one bucket set; the kernel is integer-VALU bound, not HBM bound.")
     import json
     valu = None
     try:
