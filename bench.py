@@ -599,13 +599,19 @@ def main():
                     b.free()
             except Exception as e:   # noqa: BLE001
                 out["host_wires_error"] = repr(e)
+        if world == 1 and not args.no_extras and args.profile == "dense":
+            try:   # seam-level cost, measured while the prover is still alive: once a process has FREED tens of GB of device
+                   # buffers the runtime stops overlapping the two copy directions of plonk_ntt_batch (33 -> 53 ms; bisected in
+                   # profiles/r03b/ntt_batch_overlap_bisect.txt — variant C = prover.close() before the call)
+                out["roofline_ntt"] = ntt_roofline(ctx, log_n, qd8)
+                out["leaf_ms"] = leaf_costs(ctx, log_n)
+            except Exception as e:   # noqa: BLE001
+                out["leaf_error"] = repr(e)
         prover.close()
         wbuf.free()
         if world == 1 and not args.no_extras and args.profile == "dense":
-            try:   # the other workloads of SURVEY §8(d) and the seam-level cost; never a reason to lose the line
+            try:   # the other workloads of SURVEY §8(d); never a reason to lose the line
                 k = max(2, min(args.steps, 5))
-                out["roofline_ntt"] = ntt_roofline(ctx, log_n, qd8)
-                out["leaf_ms"] = leaf_costs(ctx, log_n)          # while the context still holds the 2^log_n key
                 out["prove_ms_bench_like"] = time_profile(ctx, log_n, "bench-like", k, blinders)
                 out["prove_ms_all_widgets_pi"] = time_profile(ctx, log_n, "widgets", k, blinders)
                 if log_n != 16:

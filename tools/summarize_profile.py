@@ -81,8 +81,9 @@ if acc in pm["FETCH_SIZE"]:
         valu = min(valu_raw, 1.0)   # waves that retire early make the 2-waves-per-SIMD denominator a slight underestimate
         out.append(f"\n## VALU utilisation of msm_accumulate\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu_raw:.2f}** — "
                    "the integer VALU pipe is saturated; only fewer instructions per point addition make this kernel faster.")
-        b = agg["void plonk::ntt_pass_kernel<8, false>"]
-        out.append(f"Same ratio for `ntt_pass_kernel<8,false>` (2 workgroups x 4 waves per CU = 2 waves per SIMD): {b['SQ_ACTIVE_INST_VALU'] / (b['SQ_WAVE_CYCLES'] / 2):.2f}.")
+        nk = max((k for k in agg if "ntt_pass_kernel" in k), key=lambda k: agg[k]["SQ_WAVE_CYCLES"])
+        b = agg[nk]
+        out.append(f"Same ratio for `{nk}` (2 workgroups x 4 waves per CU = 2 waves per SIMD): {b['SQ_ACTIVE_INST_VALU'] / (b['SQ_WAVE_CYCLES'] / 2):.2f}.")
     except Exception as e:  # noqa
         out.append(f"\n(VALU utilisation unavailable: {e})")
     json.dump({"kernel": "msm_accumulate_kernel", "workload": "bench.py 2^20 gates, 1 GPU", "fetch_size_kib_per_launch": fa,
