@@ -447,7 +447,7 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, sizeof(G1) * MSM_BIT_SUMS, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
-  xyzz_to_affine97_host(finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host), c.srs_rows == MSM_ROWS_BITPOS), out_xy_inf);
+  xyzz_to_affine97_host(finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host), c.msm.last_rowbits, c.srs_rows == MSM_ROWS_BITPOS), out_xy_inf);
   return PLONK_OK;
 }
 
@@ -488,7 +488,7 @@ int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64
     HIP_TRY(hipMemcpyAsync(c.msm.result_host, c.msm.result, sizeof(G1) * MSM_BIT_SUMS * cnt, hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     G1 sums[MSM_MAX_BATCH];
-    for (int k = 0; k < cnt; ++k) sums[k] = finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host) + (size_t)k * MSM_BIT_SUMS, c.srs_rows == MSM_ROWS_BITPOS);
+    for (int k = 0; k < cnt; ++k) sums[k] = finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host) + (size_t)k * MSM_BIT_SUMS, c.msm.last_rowbits, c.srs_rows == MSM_ROWS_BITPOS);
     batch_xyzz_to_affine97(sums, cnt, reinterpret_cast<uint8_t (*)[97]>(out + 97 * (size_t)k0));
   }
   return PLONK_OK;

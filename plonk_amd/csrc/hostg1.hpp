@@ -177,24 +177,26 @@ static H1 h1_add(const H1& a, const H1& b) {
   r.ZZZ = fp64_mul(fp64_mul(a.ZZZ, b.ZZZ), PPP);
   return r;
 }
-// W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j  from the first 16 bit sums of msm_bits_kernel
-// (rows T_0..T_7, columns T'_0..T'_6, C_128): Horner over U_0..U_14.  W weighs bucket b with b + 1 — the commitment
-// for window-table entries.  Bit-position entries (width-17 NAF, msm_recode.cuh) weigh 2 b + 1: their commitment is
-// 2 W - S with S = bits[16], the sum of all buckets.
-static G1 finish_bit_sums(const G1* bits, bool bitpos) {
-  H1 u[17];
-  for (int k = 0; k < 17; ++k) {
+// W = sum_j 2^j T'_j + 2^7 C_128 + sum_j 2^(7+j) T_j  from the bit sums of msm_bits_kernel: rows T_0..T_{rb-1} (rb = 8 for
+// 2^15 buckets = 256 rows of 128, 12 for 2^19 buckets), columns T'_0..T'_6, C_128 — Horner over U_0..U_{6+rb}.  W weighs
+// bucket b with b + 1: the commitment for window-table entries.  Bit-position entries (NAF digits, msm_recode.cuh) weigh
+// 2 b + 1: their commitment is 2 W - S with S = the sum of all buckets.  Layout: rows [0, rb), columns [rb, rb + 7),
+// C_128 at rb + 7, S at rb + 8.
+static constexpr int MSM_ROWBITS_MAX = 12;
+static G1 finish_bit_sums(const G1* bits, int rb, bool bitpos) {
+  H1 u[MSM_ROWBITS_MAX + 9];
+  for (int k = 0; k < rb + 9; ++k) {
     memcpy(u[k].X.l, bits[k].X.l, 48); memcpy(u[k].Y.l, bits[k].Y.l, 48);
     memcpy(u[k].ZZ.l, bits[k].ZZ.l, 48); memcpy(u[k].ZZZ.l, bits[k].ZZZ.l, 48);
   }
-  H1 U[15];
-  for (int j = 0; j < 7; ++j) U[j] = u[8 + j];
-  U[7] = h1_add(u[15], u[0]);
-  for (int j = 1; j < 8; ++j) U[7 + j] = u[j];
-  H1 acc = U[14];
-  for (int j = 13; j >= 0; --j) acc = h1_add(h1_dbl(acc), U[j]);
+  H1 U[MSM_ROWBITS_MAX + 7];
+  for (int j = 0; j < 7; ++j) U[j] = u[rb + j];
+  U[7] = h1_add(u[rb + 7], u[0]);
+  for (int j = 1; j < rb; ++j) U[7 + j] = u[j];
+  H1 acc = U[6 + rb];
+  for (int j = 5 + rb; j >= 0; --j) acc = h1_add(h1_dbl(acc), U[j]);
   if (bitpos) {
-    H1 negS = u[16];
+    H1 negS = u[rb + 8];
     Fp64 zero;
     memset(&zero, 0, sizeof zero);
     if (!negS.inf()) negS.Y = fp64_sub(zero, negS.Y);   // p - Y

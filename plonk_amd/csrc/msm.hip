@@ -109,7 +109,13 @@ __device__ __forceinline__ G1R ld_g1r(const G1RSlot* p) {
 __device__ __forceinline__ void st_g1r(G1RSlot* p, const G1R& v) {
   st_f28(&p->X, v.X); st_f28(&p->Y, v.Y); st_f28(&p->ZZ, v.ZZ); st_f28(&p->ZZZ, v.ZZZ);
 }
+__device__ __forceinline__ G1R g1r_neg(const G1R& p) {   // -P: Y -> 16p - Y (Y < 8p), canonicalised
+  G1R r = p;
+  if (!p.is_identity()) r.Y = Fp28::sub<16>(Fp28::zero(), p.Y).canon();
+  return r;
+}
 
+#if PLONK_MSM_NB_BITS == 15   // ---- shared code: compiled once (the 2^15-bucket build of this file) ----
 // ---------------------------------------------------------------------------
 // SRS tables
 // ---------------------------------------------------------------------------
@@ -209,6 +215,9 @@ __global__ void srs_generate_kernel(Fr tau, Fr g_scalar, uint64_t n, G1Affine* _
   st_aff(out + i, a);
 }
 
+#endif   // shared
+
+namespace PLONK_MSM_NS {   // ---- per bucket count: accumulation, bucket sums, reduction tail ----
 // ---------------------------------------------------------------------------
 // accumulation
 // ---------------------------------------------------------------------------
@@ -282,7 +291,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
                                                                      const uint32_t* __restrict__ slice_off_all,
                                                                      const uint32_t* __restrict__ full_off_all,
                                                                      const uint32_t* __restrict__ part_list_all,
-                                                                     G1RSlot* __restrict__ partial_all) {
+                                                                     G1RSlot* __restrict__ partial_all, G1RSlot* __restrict__ buckets_all) {
   const int kb = blockIdx.y;
   const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
@@ -290,11 +299,16 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
   const uint32_t* __restrict__ full_off = full_off_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ part_list = part_list_all + (uint64_t)kb * (MSM_NB + 1);
   G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
+  G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ uint32_t coarse[MSM_NB / 64];
-  for (uint32_t j = threadIdx.x; j < MSM_NB / 64; j += blockDim.x) coarse[j] = full_off[j * 64];
-  __syncthreads();
   const uint32_t nfull = full_off[MSM_NB], npart = part_list[MSM_NB];
+  // only the lanes of FULL slices search for their bucket; a workgroup that holds none (with 2^19 buckets: almost all of
+  // them, a bucket being one partial slice) skips the staging of the search table
+  __shared__ uint32_t coarse[MSM_NB / 64];
+  if (blockIdx.x * blockDim.x < nfull) {   // uniform per workgroup
+    for (uint32_t j = threadIdx.x; j < MSM_NB / 64; j += blockDim.x) coarse[j] = full_off[j * 64];
+    __syncthreads();
+  }
   if (s >= nfull + npart) return;
   uint32_t b, q, end;
   if (s < nfull) {
@@ -336,7 +350,10 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
     for (int i = 0; i < Fp28::N; ++i) y2.l[i] = neg ? Fp28::pad<4>(i) - yc.l[i] : yc.l[i];
     acc = acc.add_affine(xc, y2);
   }
-  st_g1r(partial + slice_off[b] + q, acc);
+  // a bucket that is ONE slice needs no bucket sum: its lane writes the bucket itself (msm_bucket_sum skips it)
+  const uint32_t so = slice_off[b];
+  if (slice_off[b + 1] - so == 1) st_g1r(buckets + b, acc);
+  else st_g1r(partial + so + q, acc);
 }
 
 // Occupancy experiment (PLONK_MSM_ACC=lds), kept as the measured answer to "would a third wave per SIMD help?":
@@ -474,7 +491,7 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all, uint32_t heavy_thresh,
                                                              const uint32_t* __restrict__ nheavy_all, const HeavyItem* __restrict__ heavy_list_all,
-                                                             G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused) {
+                                                             G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused, uint32_t direct) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -517,6 +534,7 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   if (b < MSM_NB) {
     const uint32_t beg = slice_off[b], end = slice_off[b + 1];
     heavy = end - beg > heavy_thresh;   // listed by msm_slices_kernel with the same threshold
+    if (direct && end - beg == 1) heavy = true;   // written by its own lane of msm_accumulate_ordered: nothing to do here
     if (!heavy)
       for (uint32_t k = beg + g; k < end; k += BS_G) acc = acc.add(ld_g1r(partial + k));
   }
@@ -609,12 +627,7 @@ __global__ void __launch_bounds__(256) msm_heavy_bucket_kernel(const uint32_t* _
 // doubles the row part 7 times and tree-sums everything: ~24 dependent additions instead of the
 // ~70 of a running-sum-per-chunk scheme — these kernels are pure latency (one wave per SIMD).
 static constexpr uint32_t RC_ROWS = 256, RC_COLS = 128;
-__device__ __forceinline__ G1R g1r_neg(const G1R& p) {   // -P: Y -> 16p - Y (Y < 8p), canonicalised
-  G1R r = p;
-  if (!p.is_identity()) r.Y = Fp28::sub<16>(Fp28::zero(), p.Y).canon();
-  return r;
-}
-static_assert(RC_ROWS * RC_COLS == MSM_NB, "row/column split must cover the bucket range");
+static_assert(MSM_NB_BITS != 15 || RC_ROWS * RC_COLS == MSM_NB, "row/column split must cover the bucket range (2^15 buckets; more buckets fold to this shape)");
 
 // One wave (64 lanes) per sum, four sums per workgroup: a lane adds 2 (rows) or 4 (columns)
 // buckets serially, then a 6-step LDS tree — depth 7 / 9 additions and ~1.5 waves per SIMD for a
@@ -808,15 +821,21 @@ __global__ void __launch_bounds__(64 * WV) msm_rowcol_quad_kernel(const G1RSlot*
 // The 16 bit sums of msm_bits_kernel from the 512 sums above: every bit sum is a plain sum of <= 128 points
 // (rows with bit j set; both halves of the 64 columns whose weight has bit j set; the two halves of column 128).
 // 64 logical lanes, two points each, a 6-step tree: depth 7.
-__global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G1RSlot* __restrict__ rc_all) {
+// rc_stride: sums per commitment in rc; extra = E: the 2^19-bucket variant's 256 "rows" are the folded G_g, its outputs sit E
+// slots further (row bits E .. E + 7, columns, C_128, S) and blocks 17 .. 17 + E - 1 add the low row bits from the H_r that
+// follow the 2^15 layout in rc (msm_fold_quad_kernel).
+__global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G1RSlot* __restrict__ rc_all, uint32_t rc_stride, uint32_t extra) {
   __shared__ G1R sh[64];
-  const G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * RCQ_SUMS;
-  G1* __restrict__ out = bt.out[blockIdx.y] + blockIdx.x;
+  const G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * rc_stride;
   const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
+  G1* __restrict__ out = bt.out[blockIdx.y] + (u < 17 ? u + extra : u - 17);
   G1R acc = G1R::identity();
   for (uint32_t i = L; i < (u == 16 ? 256u : 128u); i += 64) {
     G1R p = G1R::identity();
-    if (u == 16) {                     // S = the sum of all 256 rows = of all buckets (bit-position entries: 2 W - S)
+    if (u >= 17) {                     // low row bit j = u - 17: the H_r whose index has bit j set (2^(E-1) of them)
+      const uint32_t j = u - 17;
+      if (i < (1u << extra) && ((i >> j) & 1u)) p = ld_g1r(rc + RCQ_SUMS + i);
+    } else if (u == 16) {              // S = the sum of all 256 rows = of all buckets (bit-position entries: 2 W - S)
       p = ld_g1r(rc + i);
     } else if (u < 8) {                // 128 of the 256 rows
       const uint32_t h = ((i >> u) << (u + 1)) | (1u << u) | (i & ((1u << u) - 1u));
@@ -868,6 +887,9 @@ __global__ void __launch_bounds__(256) msm_heavy_bucket_quad_kernel(const uint32
   }
 }
 
+}  // namespace PLONK_MSM_NS
+
+#if PLONK_MSM_NB_BITS == 15   // ---- shared ----
 __global__ void xyzz_to_affine97_kernel(const G1* __restrict__ in, uint8_t* __restrict__ out97) {
   if (threadIdx.x != 0) return;
   G1Affine a;
@@ -1090,109 +1112,113 @@ int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G
   return PLONK_OK;
 }
 
-// Slice length: 32 entries from m = 2^20 up; halved with m below that (down to 4) so that a smaller
-// MSM still spreads over ~2^19 lanes instead of leaving most SIMDs idle behind 32 serial additions.
+#endif   // shared
+
+// ---------------------------------------------------------------------------
+// host side of the MSM
+// ---------------------------------------------------------------------------
+void prof_begin(Ctx* c, int slot);
+void prof_end(Ctx* c, int slot);
+
+namespace PLONK_MSM_NS {
+
+// Slice length.  2^15 buckets: 32 entries from m = 2^20 up; halved with m below that (down to 4) so that a smaller MSM
+// still spreads over ~2^19 lanes instead of leaving most SIMDs idle behind 32 serial additions.  2^19 buckets: always 32 —
+// a bucket holds ~24 entries at m = 2^20, i.e. one lane per bucket (in order of length) and almost no second slices.
 static uint32_t msm_ksl(uint64_t m) {
   static const int forced = [] { const char* e = getenv("PLONK_MSM_KSL"); return e ? atoi(e) : 0; }();   // tuning experiments only
   if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64 || forced == 128) return (uint32_t)forced;
+  if (MSM_NB_BITS > 15) return MSM_KSL;
   uint32_t r = 4;
   while (r < MSM_KSL && (uint64_t)r * MSM_NB < m) r *= 2;   // smallest power of two >= m / 2^15, clamped to [4, 32]
   return r;
 }
-// upper bound of the slice count over every m <= cap (MSM_W * m / msm_ksl(m) <= 16 * 2^15 below 2^20)
-static uint64_t msm_slice_cap(uint64_t cap) {
-  if (const char* e = getenv("PLONK_MSM_KSL")) { const int f = atoi(e); if (f >= 4) return (uint64_t)MSM_W * cap / f + MSM_NB + 1; }
-  const uint64_t small = (uint64_t)MSM_W * cap / 4 < (uint64_t)MSM_W * MSM_NB ? (uint64_t)MSM_W * cap / 4 : (uint64_t)MSM_W * MSM_NB;
-  const uint64_t large = (uint64_t)MSM_W * cap / MSM_KSL;
-  return (small > large ? small : large) + MSM_NB + 1;
-}
 
-int msm_reserve(Ctx* c, uint64_t m) {
+#if PLONK_MSM_NB_BITS > 15
+// ---- reduction tail for MANY buckets: throughput first ---------------------------------------------------------------
+// W = sum_b (b + 1) B_b over 2^19 buckets = 4096 rows x 128 columns.  With 16x the buckets of the 2^15 layout the row /
+// column sums are no longer a latency problem but 2 x 2^19 full additions per commitment: stage 1 runs them at full lane
+// efficiency (a lane adds 16 buckets serially, 8 lanes finish a sum of 128 with a 3-step tree):
+//     R_h          = sum of row h                         (ROWS sums)
+//     CP[p][l]     = sum over the 128 rows of part p of column l   (PARTS x 128 sums)
+// Stage 1.5 folds them to the 2^15 layout's shapes — row index h = 2^E g + r:  G_g = sum_r R_h (256 sums), H_r = sum_g R_h
+// (2^E sums), C_l = sum_p CP[p][l] (128 sums) — and the bit sums follow: row bits >= E from the G_g exactly as the 2^15
+// variant takes them from its 256 rows (msm_bits_quad_kernel, outputs shifted by E), row bits < E from the H_r.
+static constexpr uint32_t TP_E = MSM_NB_BITS - 15;
+static constexpr uint32_t TP_ROWS = MSM_NB / 128, TP_PARTS = TP_ROWS / 128;
+static constexpr uint32_t TP_RC1 = 2 * TP_ROWS;                  // stage-1 sums per commitment
+static constexpr uint32_t TP_RC2 = RCQ_SUMS + (1u << TP_E);      // stage-1.5 sums per commitment: the 2^15 layout + H_r
+// LPS lanes per sum of 128 buckets: a lane adds 128 / LPS buckets serially, then a log2(LPS)-step tree.  8 for groups of 3-4
+// commitments (throughput: 15 + 3 additions per lane, 88 % useful), 16 / 32 for groups of 2 / 1 (depth 11 / 9: latency).
+template <int LPS>
+__global__ void __launch_bounds__(128) msm_rowcol_tp_kernel(const G1RSlot* __restrict__ buckets_all, G1RSlot* __restrict__ rc1_all) {
+  constexpr uint32_t PER = 128 / LPS;          // buckets per lane = sums per workgroup
+  __shared__ G1R sh[128];
+  const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
+  G1RSlot* __restrict__ rc1 = rc1_all + (uint64_t)blockIdx.y * TP_RC1;
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x < TP_ROWS / PER) {         // PER rows per workgroup, LPS lanes per row
+    const uint32_t row = PER * blockIdx.x + t / LPS, s = t % LPS;
+    const G1RSlot* base = buckets + (uint64_t)row * 128 + PER * s;
+    G1R acc = ld_g1r(base);
+    for (uint32_t k = 1; k < PER; ++k) acc = acc.add(ld_g1r(base + k));
+    for (uint32_t d = LPS / 2; d >= 1; d >>= 1) {
+      sh[t] = acc;
+      __syncthreads();
+      if (s < d) acc = acc.add(sh[t + d]);
+      __syncthreads();
+    }
+    if (s == 0) st_g1r(rc1 + row, acc);
+  } else {                                    // (part, PER columns) per workgroup, LPS lanes (PER rows each) per column
+    const uint32_t w = blockIdx.x - TP_ROWS / PER, p = w / LPS, l0 = PER * (w % LPS) + (t % PER), s = t / PER;
+    const G1RSlot* base = buckets + ((uint64_t)128 * p + PER * s) * 128 + l0;
+    G1R acc = ld_g1r(base);
+    for (uint32_t k = 1; k < PER; ++k) acc = acc.add(ld_g1r(base + (uint64_t)k * 128));
+    for (uint32_t d = LPS / 2; d >= 1; d >>= 1) {
+      sh[t] = acc;
+      __syncthreads();
+      if (s < d) acc = acc.add(sh[t + PER * d]);
+      __syncthreads();
+    }
+    if (s == 0) st_g1r(rc1 + TP_ROWS + p * 128 + l0, acc);
+  }
+}
+// stage 1.5 (quad additions, 64 logical lanes per sum): rc2 = [G_g (256) | C_l (128) | identity (128) | H_r (2^E)]
+__global__ void __launch_bounds__(256) msm_fold_quad_kernel(const G1RSlot* __restrict__ rc1_all, G1RSlot* __restrict__ rc2_all) {
+  __shared__ G1R sh[64];
+  const G1RSlot* __restrict__ rc1 = rc1_all + (uint64_t)blockIdx.y * TP_RC1;
+  G1RSlot* __restrict__ rc2 = rc2_all + (uint64_t)blockIdx.y * TP_RC2;
+  const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
+  uint32_t npts, first, stride, dst;
+  if (u < 256) { npts = 1u << TP_E; first = u << TP_E; stride = 1; dst = u; }                                   // G_g
+  else if (u < 256 + (1u << TP_E)) { npts = 256; first = u - 256; stride = 1u << TP_E; dst = RCQ_SUMS + (u - 256); }   // H_r
+  else { const uint32_t l0 = u - 256 - (1u << TP_E); npts = TP_PARTS; first = TP_ROWS + l0; stride = 128; dst = RC_ROWS + l0; }   // C_l
+  G1R acc = G1R::identity();
+  for (uint32_t i = L; i < npts; i += 64) acc = g1r_add_quad(acc, ld_g1r(rc1 + first + (uint64_t)i * stride), q);
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
+    if (q == 0) sh[L] = acc;
+    __syncthreads();
+    if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
+    __syncthreads();
+  }
+  if (t == 0) {
+    st_g1r(rc2 + dst, acc);
+    if (dst >= RC_ROWS && dst < RC_ROWS + RC_COLS) st_g1r(rc2 + dst + RC_COLS, G1R::identity());   // the second half-column of the 2^15 layout
+  }
+}
+#endif
+
+// One commitment group through the pipeline: bucket grouping, accumulation, bucket sums, reduction tail.
+// bt arrives filled (scalars, sizes, outputs, table); ksl / wide / heavy_thresh are decided here.
+int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   MsmWork& w = c->msm;
-  constexpr int KB = MSM_MAX_BATCH;
-  if (!w.fixed_ok) {
-    // all-or-nothing: a failure half way must not leave some of these set (the next call would skip the block and
-    // launch kernels on null pointers) — free whatever exists and start over
-    for (void** q : {(void**)&w.offsets, (void**)&w.slice_off, (void**)&w.nheavy, &w.heavy_list, (void**)&w.coarse_cnt, (void**)&w.coarse_off,
-                     (void**)&w.coarse_cur, (void**)&w.big_off, (void**)&w.big_cnt, (void**)&w.full_off, (void**)&w.part_list, &w.buckets, &w.chunk,
-                     (void**)&w.result}) {
-      if (*q) { (void)hipFree(*q); *q = nullptr; }
-    }
-    if (w.result_host) { (void)hipHostFree(w.result_host); w.result_host = nullptr; }
-    HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB + 1) * KB));
-    HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
-    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * 2 * KB));
-    HIP_TRY(hipMalloc((void**)&w.heavy_list, sizeof(HeavyItem) * MSM_NB * KB));
-    { const int rc_s = msm_sort_reserve_fixed(c); if (rc_s) return rc_s; }
-    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB * KB));
-    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (MSM_NB / MSM_CHUNK) * KB));
-    HIP_TRY(hipMalloc((void**)&w.result, sizeof(G1) * MSM_BIT_SUMS * KB));          // one point, or 16 bit sums per commitment of a group
-    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(G1) * MSM_BIT_SUMS * KB, hipHostMallocDefault));
-    w.fixed_ok = true;
-  }
-  if (m > w.cap_m) {
-    const uint64_t cap = m;
-    // release first (the stream may still be reading the old buffers), and forget the old capacity so
-    // that a failed reallocation cannot leave a stale cap_m pointing at freed memory
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    w.cap_m = 0;
-    for (void** q : {(void**)&w.tmp_words, (void**)&w.entries, (void**)&w.partial, &w.seg_sum}) {
-      if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
-    }
-    HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint64_t) * MSM_W * cap * KB));  // words grouped by coarse bin (64-bit words for tables above 2^27 entries)
-    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
-    w.cap_slices = msm_slice_cap(cap);
-    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
-    w.cap_segs = w.cap_slices / HEAVY_SEG + MSM_NB + 1;   // sum over heavy buckets of ceil(slices / HEAVY_SEG)
-    HIP_TRY(hipMalloc((void**)&w.seg_sum, sizeof(G1RSlot) * w.cap_segs * KB));
-    w.cap_m = cap;
-  }
-  return PLONK_OK;
-}
-
-void prof_begin(Ctx* c, int slot);
-void prof_end(Ctx* c, int slot);
-
-// `count` (<= MSM_MAX_BATCH) independent MSMs over the same bases, launched together: the
-// latency-bound reduction kernels run once per group instead of once per commitment
-// (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
-int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums,
-                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split, uint32_t table_rows) {
-  if (count <= 0) return PLONK_OK;
-  if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
-  if (!table) { table = c->srs_table; table_n = c->srs_n; table_rows = c->srs_rows; }
-  if (table && table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_BITPOS) return (plonk::set_last_error("invalid argument", "msm: table rows", __FILE__, __LINE__), PLONK_ERR_ARG);
-  uint64_t mmax = 0;
-  for (int k = 0; k < count; ++k) {
-    if (m[k] > table_n) return PLONK_ERR_DEGREE;
-    if (m[k] > mmax) mmax = m[k];
-  }
   hipStream_t st = c->stream;
-  if (mmax == 0) {
-    for (int k = 0; k < count; ++k)
-      for (int j = 0; j < (bit_sums ? MSM_BIT_SUMS : 1); ++j) hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, st, out_dev[k] + j);
-    HIP_TRY(hipGetLastError());
-    if (c->acc_done) HIP_TRY(hipEventRecord(c->acc_done, st));   // callers gate side-stream work on it: never leave a stale event
-    return PLONK_OK;
-  }
-  if (!table) return PLONK_ERR_NO_SRS;
-  int rc = msm_reserve(c, mmax);
-  if (rc) return rc;
-  MsmWork& w = c->msm;
-  MsmBatch bt{};
-  bt.count = count;
+  const int count = bt.count;
+  const void* table = bt.table;
+  int rc = PLONK_OK;
   bt.ksl = msm_ksl(mmax);
-  bt.cap_m = w.cap_m;
-  bt.cap_slices = w.cap_slices;
-  bt.table = table;
-  bt.table_n = table_n;
-  bt.rows = table_rows;
-  bt.wide = (uint64_t)table_rows * table_n > (1ull << 27) ? 1u : 0u;
-  for (int k = 0; k < count; ++k) {
-    bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k];
-    bt.tail[k] = tail_dev ? tail_dev[k] : nullptr;
-    bt.split[k] = (tail_dev && split) ? split[k] : ~0ull;
-  }
+  bt.wide = msm_needs_wide_words(bt.rows, bt.table_n) ? 1u : 0u;
+  if (MSM_NB_BITS > 15 && !bit_sums) return (plonk::set_last_error("msm", "the 2^19-bucket variant only emits bit sums", __FILE__, __LINE__), PLONK_ERR_ARG);
   {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
     // heavy = well above the expected slice count (skewed digits): twice the uniform average, at least 16 slices
@@ -1218,7 +1244,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     rc = msm_order_slices(c, bt);
     if (rc) return rc;
     hipLaunchKernelGGL(msm_accumulate_ordered_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
-                       (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, w.full_off, w.part_list, (G1RSlot*)w.partial);
+                       (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, w.full_off, w.part_list, (G1RSlot*)w.partial, (G1RSlot*)w.buckets);
   } else if (acc_lds)
     hipLaunchKernelGGL(msm_accumulate_lds_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
                        (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
@@ -1233,10 +1259,10 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     const uint32_t heavy_thresh = bt.heavy_thresh;                  // the list of heavy buckets was written by msm_slices_kernel
     // PLONK_MSM_TAIL=serial: one lane per addition in the heavy-bucket, row/column and bit-sum kernels (A/B, fallback)
     static const bool tail_quad_ = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
-    const uint32_t fused = tail_quad_ ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
+    const uint32_t fused = (tail_quad_ || MSM_NB_BITS > 15) ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
 #define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128 + fused, count), dim3(128), 0, st, bt, \
                                    (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (const HeavyItem*)w.heavy_list, \
-                                   (G1RSlot*)w.seg_sum, w.cap_segs, fused)
+                                   (G1RSlot*)w.seg_sum, w.cap_segs, fused, (acc_ordered && !acc_lds) ? 1u : 0u)
     if (avg_slices <= 4) BSUM(1);
     else if (avg_slices <= 16) BSUM(2);
     else if (avg_slices <= 32) BSUM(4);
@@ -1244,7 +1270,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
 #undef BSUM
   }
   static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
-  if (tail_quad) {
+  if (tail_quad || MSM_NB_BITS > 15) {
     hipLaunchKernelGGL(msm_heavy_bucket_quad_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
                        (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets, HEAVY_FUSED_WGS);
   } else {
@@ -1253,12 +1279,27 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
                        (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
   }
+  c->msm.last_rowbits = 8 + (MSM_NB_BITS - 15);
+#if PLONK_MSM_NB_BITS > 15
+  {   // many buckets: throughput row / column sums, the fold to the 2^15 shapes, then the same bit sums (outputs shifted by E)
+    G1RSlot* rc1 = (G1RSlot*)w.chunk;
+    G1RSlot* rc2 = rc1 + (size_t)TP_RC1 * MSM_MAX_BATCH;
+#define TPK(LPS) hipLaunchKernelGGL(msm_rowcol_tp_kernel<LPS>, dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1)
+    if (count >= 3) TPK(8); else if (count == 2) TPK(16); else TPK(32);
+#undef TPK
+    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + (1u << TP_E) + 128, count), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
+    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
+    prof_end(c, 2);
+    HIP_TRY(hipGetLastError());
+    return PLONK_OK;
+  }
+#else
   if (bit_sums && tail_quad) {
     // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
     if (count >= 3) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     else if (count == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     else hipLaunchKernelGGL(msm_rowcol_quad_kernel<4>, dim3(RCQ_SUMS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
-    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(MSM_BIT_SUMS, count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk);
+    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17, count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk, (uint32_t)RCQ_SUMS, 0u);
     prof_end(c, 2);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
@@ -1266,7 +1307,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);
   if (bit_sums) {
-    hipLaunchKernelGGL(msm_bits_kernel, dim3(MSM_BIT_SUMS, count), dim3(128), 0, st, bt, (const G1RSlot*)w.chunk);
+    hipLaunchKernelGGL(msm_bits_kernel, dim3(17, count), dim3(128), 0, st, bt, (const G1RSlot*)w.chunk);
   } else {
     constexpr size_t smem = sizeof(G1R) * (RC_ROWS + RC_COLS);
     smem_opt_in(c, (const void*)msm_final_kernel, smem);
@@ -1275,6 +1316,130 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   prof_end(c, 2);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
+#endif
+}
+
+
+}  // namespace PLONK_MSM_NS
+
+#if PLONK_MSM_NB_BITS == 15   // ---- shared: buffers, variant choice, single-result entry points ----
+// upper bound of the slice count over every m <= cap and either bucket count: 2^15 buckets use slices of 4..32 entries
+// (MSM_W * m / ksl(m) <= 16 * 2^15 below 2^20), 2^19 buckets slices of 32; + one partial slice per bucket
+static uint64_t msm_slice_cap(uint64_t cap) {
+  if (const char* e = getenv("PLONK_MSM_KSL")) { const int f = atoi(e); if (f >= 4) return (uint64_t)MSM_W * cap / f + MSM_NB_MAX + 1; }
+  const uint64_t nb15 = 1ull << 15;
+  const uint64_t small = (uint64_t)MSM_W * cap / 4 < (uint64_t)MSM_W * nb15 ? (uint64_t)MSM_W * cap / 4 : (uint64_t)MSM_W * nb15;
+  const uint64_t large = (uint64_t)MSM_W * cap / MSM_KSL;
+  return (small > large ? small : large) + MSM_NB_MAX + 1;
+}
+
+int msm_sort_reserve_fixed(Ctx* c) {   // the bucket sort's size-independent buffers (msm_sort.hip), sized for the larger bucket count
+  MsmWork& w = c->msm;
+  constexpr int KB = MSM_MAX_BATCH;
+  constexpr uint32_t COARSE = 2048;
+  HIP_TRY(hipMalloc((void**)&w.coarse_cnt, sizeof(uint32_t) * COARSE * KB));
+  HIP_TRY(hipMalloc((void**)&w.coarse_off, sizeof(uint32_t) * (COARSE + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.coarse_cur, sizeof(uint32_t) * COARSE * KB));
+  HIP_TRY(hipMalloc((void**)&w.big_off, sizeof(uint32_t) * (COARSE + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.big_cnt, sizeof(uint32_t) * 2 * MSM_NB_MAX * KB));   // bin-wide bucket counts, then the run cursors
+  HIP_TRY(hipMalloc((void**)&w.full_off, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.part_list, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.layout, sizeof(uint32_t) * (2 * (MSM_NB_MAX / 1024) + (MSM_NB_MAX / 1024 + 1) * 132) * KB));
+  return PLONK_OK;
+}
+
+int msm_reserve(Ctx* c, uint64_t m) {
+  MsmWork& w = c->msm;
+  constexpr int KB = MSM_MAX_BATCH;
+  if (!w.fixed_ok) {
+    // all-or-nothing: a failure half way must not leave some of these set (the next call would skip the block and
+    // launch kernels on null pointers) — free whatever exists and start over
+    for (void** q : {(void**)&w.offsets, (void**)&w.slice_off, (void**)&w.nheavy, &w.heavy_list, (void**)&w.coarse_cnt, (void**)&w.coarse_off,
+                     (void**)&w.coarse_cur, (void**)&w.big_off, (void**)&w.big_cnt, (void**)&w.full_off, (void**)&w.part_list, (void**)&w.layout, &w.buckets, &w.chunk,
+                     (void**)&w.result}) {
+      if (*q) { (void)hipFree(*q); *q = nullptr; }
+    }
+    if (w.result_host) { (void)hipHostFree(w.result_host); w.result_host = nullptr; }
+    HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
+    HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
+    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * 2 * KB));
+    HIP_TRY(hipMalloc((void**)&w.heavy_list, sizeof(HeavyItem) * MSM_NB_MAX * KB));
+    { const int rc_s = msm_sort_reserve_fixed(c); if (rc_s) return rc_s; }
+    HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB_MAX * KB));
+    // row / column sums: 512 per commitment (2^15 buckets); 2 x 4096 stage-1 sums + 528 folded sums (2^19 buckets)
+    HIP_TRY(hipMalloc((void**)&w.chunk, sizeof(G1RSlot) * (2 * (MSM_NB_MAX / 128) + 1024) * KB));
+    HIP_TRY(hipMalloc((void**)&w.result, sizeof(G1) * MSM_BIT_SUMS * KB));          // one point, or the bit sums of every commitment of a group
+    HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(G1) * MSM_BIT_SUMS * KB, hipHostMallocDefault));
+    w.fixed_ok = true;
+  }
+  if (m > w.cap_m) {
+    const uint64_t cap = m;
+    // release first (the stream may still be reading the old buffers), and forget the old capacity so
+    // that a failed reallocation cannot leave a stale cap_m pointing at freed memory
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    w.cap_m = 0;
+    for (void** q : {(void**)&w.tmp_words, (void**)&w.entries, (void**)&w.partial, &w.seg_sum}) {
+      if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
+    }
+    HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint64_t) * MSM_W * cap * KB));  // words grouped by coarse bin (two planes for tables above 2^27 entries)
+    HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
+    w.cap_slices = msm_slice_cap(cap);
+    HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
+    w.cap_segs = w.cap_slices / 256 + MSM_NB_MAX + 1;   // sum over heavy buckets of ceil(slices / 256)
+    HIP_TRY(hipMalloc((void**)&w.seg_sum, sizeof(G1RSlot) * w.cap_segs * KB));
+    w.cap_m = cap;
+  }
+  return PLONK_OK;
+}
+
+// `count` (<= MSM_MAX_BATCH) independent MSMs over the same bases, launched together: the
+// latency-bound reduction kernels run once per group instead of once per commitment
+// (Prover::commit_polynomials' 4-way fan-out, prover.rs:187-210).  m[k] == 0 -> identity.
+// Which bucket count: 2^19 buckets (nb19) for bit-position tables, the bit-sum tail and more than 2^19 terms — 12.1
+// instead of 14.7 additions per scalar, a bucket is one lane of ~24 entries — else 2^15 (nb15).  PLONK_MSM_BUCKETS=15 / 19
+// forces either wherever it is possible (19 needs bit-position tables and the bit-sum tail).
+int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums,
+                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split, uint32_t table_rows) {
+  if (count <= 0) return PLONK_OK;
+  if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (!table) { table = c->srs_table; table_n = c->srs_n; table_rows = c->srs_rows; }
+  if (table && table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_BITPOS) return (plonk::set_last_error("invalid argument", "msm: table rows", __FILE__, __LINE__), PLONK_ERR_ARG);
+  uint64_t mmax = 0;
+  for (int k = 0; k < count; ++k) {
+    if (m[k] > table_n) return PLONK_ERR_DEGREE;
+    if (m[k] > mmax) mmax = m[k];
+  }
+  hipStream_t st = c->stream;
+  if (mmax == 0) {
+    c->msm.last_rowbits = 8;
+    for (int k = 0; k < count; ++k)
+      for (int j = 0; j < (bit_sums ? MSM_BIT_SUMS : 1); ++j) hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, st, out_dev[k] + j);
+    HIP_TRY(hipGetLastError());
+    if (c->acc_done) HIP_TRY(hipEventRecord(c->acc_done, st));   // callers gate side-stream work on it: never leave a stale event
+    return PLONK_OK;
+  }
+  if (!table) return PLONK_ERR_NO_SRS;
+  int rc = msm_reserve(c, mmax);
+  if (rc) return rc;
+  MsmWork& w = c->msm;
+  MsmBatch bt{};
+  bt.count = count;
+  bt.cap_m = w.cap_m;
+  bt.cap_slices = w.cap_slices;
+  bt.table = table;
+  bt.table_n = table_n;
+  bt.rows = table_rows;
+  for (int k = 0; k < count; ++k) {
+    bt.scalars[k] = scalars_dev[k]; bt.m[k] = m[k]; bt.out[k] = out_dev[k];
+    bt.tail[k] = tail_dev ? tail_dev[k] : nullptr;
+    bt.split[k] = (tail_dev && split) ? split[k] : ~0ull;
+  }
+  static const int buckets_env = [] { const char* e = getenv("PLONK_MSM_BUCKETS"); return e ? atoi(e) : 0; }();
+  static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
+  static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
+  const bool can19 = table_rows == MSM_ROWS_BITPOS && bit_sums && tail_quad && !acc_lds;
+  const bool use19 = can19 && (buckets_env == 19 || (buckets_env != 15 && mmax > (1ull << 19)));
+  return use19 ? nb19::msm_batch_device_v(c, bt, mmax, bit_sums) : nb15::msm_batch_device_v(c, bt, mmax, bit_sums);
 }
 
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {
@@ -1286,5 +1451,6 @@ int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev) {
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
+#endif   // shared
 
 }  // namespace plonk

@@ -22,7 +22,7 @@ namespace plonk {
 
 static constexpr int MSM_DIGITS = 16;          // most non-zero digits of a scalar under either recoding (= MSM_W)
 static constexpr uint32_t MSM_ROWS_WINDOW = 16, MSM_ROWS_BITPOS = 256;
-static constexpr uint32_t MSM_NAF_W = 17;      // digit width of the bit-position recoding: odd |d| < 2^16
+static constexpr uint32_t MSM_NAF_W = 17;      // digit width of the bit-position recoding over 2^15 buckets: odd |d| < 2^16
 
 // Signed 16-bit windows, least significant first (carry into the next window when the value exceeds 2^15).
 template <class S, class F>
@@ -70,8 +70,9 @@ HD uint32_t bits32_at(const S& s, uint32_t p) {
 // Width-17 NAF of a canonical scalar (s < 2^255), least significant digit first.  `carry` = 1 after a negative
 // digit: the value that remains above the digit is (s >> p) + carry, and it is odd exactly where bit p differs from the
 // carry.  The top digit starts at bit 255 at the latest (s < 2^255 stops every carry there), so rows 0..255 suffice.
-template <class S, class F>
-HD void for_each_digit_bitpos(const S& s, F&& f) {
+// W = digit width: odd digits |d| < 2^(W-1), bucket = |d| >> 1 in [0, 2^(W-2)); W = 17 for 2^15 buckets, 21 for 2^19.
+template <uint32_t W, class S, class F>
+HD void for_each_digit_naf(const S& s, F&& f) {
   uint32_t p = 0, carry = 0;
 #pragma unroll
   for (int j = 0; j < MSM_DIGITS; ++j) {
@@ -82,14 +83,16 @@ HD void for_each_digit_bitpos(const S& s, F&& f) {
       p += 32;
     }
     if (p >= 256) break;
-    const uint32_t v = (bits32_at(s, p) & ((1u << MSM_NAF_W) - 1u)) + carry;   // odd, < 2^17
-    const uint32_t neg = v >> (MSM_NAF_W - 1);                                 // v > 2^16: the digit is v - 2^17
-    const uint32_t mag = neg ? (1u << MSM_NAF_W) - v : v;                      // odd, < 2^16
+    const uint32_t v = (bits32_at(s, p) & ((1u << W) - 1u)) + carry;   // odd, < 2^W
+    const uint32_t neg = v >> (W - 1);                                 // v > 2^(W-1): the digit is v - 2^W
+    const uint32_t mag = neg ? (1u << W) - v : v;                      // odd, < 2^(W-1)
     f(j, p, mag >> 1, neg);
     carry = neg;
-    p += MSM_NAF_W;
+    p += W;
   }
 }
+template <class S, class F>
+HD void for_each_digit_bitpos(const S& s, F&& f) { for_each_digit_naf<MSM_NAF_W>(s, f); }
 
 template <class S, class F>
 HD void for_each_digit(const S& s, uint32_t rows, F&& f) {

@@ -29,8 +29,9 @@
 #include "fr29.cuh"
 
 namespace plonk {
+namespace PLONK_MSM_NS {   // compiled once per bucket count (plonk_internal.hpp)
 
-static constexpr uint32_t FINE_BITS = 4;
+static constexpr uint32_t FINE_BITS = MSM_NB_BITS - 11;          // 4 fine bits for 2^15 buckets, 8 for 2^19
 static constexpr uint32_t COARSE = MSM_NB >> FINE_BITS;          // 2048 coarse bins
 #ifndef PLONK_SORT_TILE
 #define PLONK_SORT_TILE 2048
@@ -46,7 +47,7 @@ static constexpr uint32_t HIST_TILE = SORT_T * HIST_PER;
 static_assert(COARSE == 2 * SORT_T, "scan / reservation loops assume two coarse bins per thread");
 // Intermediate (coarse-partitioned) word.  Narrow: fine (4) | sign (1) | table index (27).  Wide: fine in the upper
 // half, the lower half IS the final entry (sign << 31 | 31-bit table index).
-static constexpr uint32_t IDX_BITS = 27;
+static constexpr uint32_t IDX_BITS = 31 - FINE_BITS;             // 27 (2^15 buckets) / 23 (2^19)
 static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1;
 static_assert(IDX_BITS + 1 + FINE_BITS == 32, "narrow intermediate word layout");
 template <class WordT> struct SortWord;
@@ -133,8 +134,8 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
 #pragma unroll
         for (int j = 0; j < 8; ++j) park[j * SORT_T + t] = s.l[j];   // read back by this lane only: no barrier
         park[8 * SORT_T + t] = 0;
-        for_each_digit_bitpos(StridedLimbs{park + t, SORT_T}, count);
-      } else {
+        for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, SORT_T}, count);
+      } else if constexpr (MSM_NB_BITS == 15) {
         for_each_digit_window(s, count);
       }
     }
@@ -241,8 +242,8 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
 #pragma unroll
         for (int j = 0; j < 8; ++j) park[j * SORT_T + t] = s.l[j];
         park[8 * SORT_T + t] = 0;
-        for_each_digit_bitpos(StridedLimbs{park + t, SORT_T}, put);
-      } else {
+        for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, SORT_T}, put);
+      } else if constexpr (MSM_NB_BITS == 15) {
         for_each_digit_window(s, put);
       }
     }
@@ -505,12 +506,113 @@ __global__ void __launch_bounds__(SORT_T) msm_order_kernel(const uint32_t* __res
   }
   if (t == 0) part_list[MSM_NB] = hist[0];
 }
+#if PLONK_MSM_NB_BITS > 15
+// ---- the same two layouts (slice offsets + heavy list, full-slice offsets + partial slices by length) for MANY buckets --
+// The two single-workgroup kernels above walk the bucket counts with 1024 threads x NB / 1024 strided reads each: fine for
+// 2^15 buckets (40-70 us), a millisecond each for 2^19 (r03c first cut: 1.09 + 0.97 ms per launch).  Here: one workgroup
+// per 1024 buckets counts and scans locally (coalesced), one workgroup per commitment scans the 512 block totals and the
+// 512 x (ksl - 1) remainder-class counts, and a third pass applies the bases.  layout: [NBLK] slices | [NBLK] full |
+// [NBLK][LAY_H] class counts -> exclusive prefixes | [LAY_H] class starts.
+static constexpr uint32_t LAY_NBLK = MSM_NB / SORT_T, LAY_H = 132;
+static constexpr uint32_t LAY_WORDS = 2 * LAY_NBLK + (LAY_NBLK + 1) * LAY_H;
+__global__ void __launch_bounds__(SORT_T) msm_layout_count_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ slice_off_all,
+                                                                  uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ lay_all, uint32_t ksl) {
+  __shared__ uint32_t sh[SORT_T];
+  __shared__ uint32_t hist[LAY_H];
+  const int kb = blockIdx.y;
+  const uint32_t blk = blockIdx.x, t = threadIdx.x, b = blk * SORT_T + t;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  uint32_t* __restrict__ lay = lay_all + (uint64_t)kb * LAY_WORDS;
+  if (t < LAY_H) hist[t] = 0;
+  __syncthreads();
+  const uint32_t cnt = offsets[b + 1] - offsets[b];
+  const uint32_t nf = cnt / ksl, r = cnt % ksl, ns = nf + (r ? 1u : 0u);
+  if (r) atomicAdd(&hist[r], 1u);
+  uint32_t tot_ns, tot_nf;
+  const uint32_t ex_ns = block_exclusive_scan(ns, sh, &tot_ns);
+  const uint32_t ex_nf = block_exclusive_scan(nf, sh, &tot_nf);
+  slice_off_all[(uint64_t)kb * (MSM_NB + 1) + b] = ex_ns;   // local to the block until msm_layout_apply adds the base
+  full_off_all[(uint64_t)kb * (MSM_NB + 1) + b] = ex_nf;
+  if (t == 0) { lay[blk] = tot_ns; lay[LAY_NBLK + blk] = tot_nf; }
+  if (t < LAY_H) lay[2 * LAY_NBLK + blk * LAY_H + t] = hist[t];   // (the scans' barriers completed the histogram)
+}
+__global__ void __launch_bounds__(SORT_T) msm_layout_scan_kernel(uint32_t* __restrict__ slice_off_all, uint32_t* __restrict__ full_off_all,
+                                                                 uint32_t* __restrict__ part_list_all, uint32_t* __restrict__ lay_all, uint32_t ksl) {
+  __shared__ uint32_t sh[SORT_T];
+  __shared__ uint32_t ctot[LAY_H];
+  const int kb = blockIdx.x;
+  const uint32_t t = threadIdx.x;
+  uint32_t* __restrict__ lay = lay_all + (uint64_t)kb * LAY_WORDS;
+  static_assert(LAY_NBLK <= SORT_T, "one thread per block total");
+  uint32_t tot;
+  const uint32_t a = t < LAY_NBLK ? lay[t] : 0u;
+  const uint32_t ea = block_exclusive_scan(a, sh, &tot);
+  if (t < LAY_NBLK) lay[t] = ea;
+  if (t == 0) slice_off_all[(uint64_t)kb * (MSM_NB + 1) + MSM_NB] = tot;
+  const uint32_t f = t < LAY_NBLK ? lay[LAY_NBLK + t] : 0u;
+  const uint32_t ef = block_exclusive_scan(f, sh, &tot);
+  if (t < LAY_NBLK) lay[LAY_NBLK + t] = ef;
+  if (t == 0) full_off_all[(uint64_t)kb * (MSM_NB + 1) + MSM_NB] = tot;
+  if (t < LAY_H) {   // remainder class t: exclusive prefix over the blocks (reads coalesced across the classes)
+    uint32_t run = 0;
+    if (t >= 1 && t < ksl)
+      for (uint32_t blk = 0; blk < LAY_NBLK; ++blk) {
+        uint32_t* q = lay + 2 * LAY_NBLK + blk * LAY_H + t;
+        const uint32_t h = *q;
+        *q = run;
+        run += h;
+      }
+    ctot[t] = run;
+  }
+  __syncthreads();
+  if (t == 0) {   // start of every class, longest first
+    uint32_t acc = 0;
+    uint32_t* cstart = lay + 2 * LAY_NBLK + LAY_NBLK * LAY_H;
+    for (uint32_t r = ksl - 1; r >= 1; --r) { cstart[r] = acc; acc += ctot[r]; }
+    part_list_all[(uint64_t)kb * (MSM_NB + 1) + MSM_NB] = acc;
+  }
+}
+__global__ void __launch_bounds__(SORT_T) msm_layout_apply_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ slice_off_all,
+                                                                  uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ part_list_all,
+                                                                  const uint32_t* __restrict__ lay_all, uint32_t ksl, uint32_t heavy_thresh,
+                                                                  uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
+  __shared__ uint32_t rank[LAY_H];
+  const int kb = blockIdx.y;
+  const uint32_t blk = blockIdx.x, t = threadIdx.x, b = blk * SORT_T + t;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
+  const uint32_t* __restrict__ lay = lay_all + (uint64_t)kb * LAY_WORDS;
+  if (t < LAY_H) rank[t] = 0;
+  __syncthreads();
+  const uint32_t cnt = offsets[b + 1] - offsets[b];
+  const uint32_t nf = cnt / ksl, r = cnt % ksl, ns = nf + (r ? 1u : 0u);
+  slice_off_all[(uint64_t)kb * (MSM_NB + 1) + b] += lay[blk];
+  full_off_all[(uint64_t)kb * (MSM_NB + 1) + b] += lay[LAY_NBLK + blk];
+  if (r) {
+    const uint32_t pos = lay[2 * LAY_NBLK + LAY_NBLK * LAY_H + r] + lay[2 * LAY_NBLK + blk * LAY_H + r] + atomicAdd(&rank[r], 1u);
+    part_list_all[(uint64_t)kb * (MSM_NB + 1) + pos] = b;
+  }
+  if (ns > heavy_thresh) {
+    HeavyItem it;
+    it.bucket = b;
+    it.nseg = (ns + HEAVY_SEG_SLICES - 1) / HEAVY_SEG_SLICES;
+    it.seg_base = atomicAdd(&nheavy_all[2 * kb + 1], it.nseg);
+    it.pad = 0;
+    heavy_list_all[(uint64_t)kb * MSM_NB + atomicAdd(&nheavy_all[2 * kb], 1u)] = it;
+  }
+}
+#endif
+
 int msm_order_slices(Ctx* c, const MsmBatch& bt) {
+#if PLONK_MSM_NB_BITS > 15
+  (void)c; (void)bt;
+  return PLONK_OK;   // msm_group_sort's layout kernels already wrote full_off / part_list
+#else
   MsmWork& w = c->msm;
   if (bt.ksl > 128) return (set_last_error("msm_order_slices", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
   hipLaunchKernelGGL(msm_order_kernel, dim3(bt.count), dim3(SORT_T), 0, c->stream, w.offsets, w.full_off, w.part_list, bt.ksl);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
+#endif
 }
 
 // Host side: everything between the scalars and msm_accumulate for one commitment group.
@@ -538,8 +640,16 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
   HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 2 * MSM_MAX_BATCH, st));
+#if PLONK_MSM_NB_BITS > 15
+  if (bt.ksl > 128) return (set_last_error("msm_group_sort", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
+  hipLaunchKernelGGL(msm_layout_count_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.layout, bt.ksl);
+  hipLaunchKernelGGL(msm_layout_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.slice_off, w.full_off, w.part_list, w.layout, bt.ksl);
+  hipLaunchKernelGGL(msm_layout_apply_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.part_list,
+                     (const uint32_t*)w.layout, bt.ksl, bt.heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list);
+#else
   hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
                      w.nheavy, (HeavyItem*)w.heavy_list);
+#endif
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
@@ -548,20 +658,14 @@ int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   if ((uint64_t)bt.rows * bt.table_n > (1ull << 31))
     return (set_last_error("commit key too large for the bucket sort", "table rows * points must be <= 2^31", __FILE__, __LINE__), PLONK_ERR_ARG);
   if (bt.rows == MSM_ROWS_BITPOS) return bt.wide ? msm_group_sort_t<true, uint64_t>(c, bt, mmax) : msm_group_sort_t<true, uint32_t>(c, bt, mmax);
+#if PLONK_MSM_NB_BITS == 15
   return bt.wide ? msm_group_sort_t<false, uint64_t>(c, bt, mmax) : msm_group_sort_t<false, uint32_t>(c, bt, mmax);
+#else
+  return (set_last_error("msm_group_sort", "window tables need the 2^15-bucket variant", __FILE__, __LINE__), PLONK_ERR_ARG);
+#endif
 }
+// the narrow (32-bit) intermediate word holds IDX_BITS bits of table index
+bool msm_needs_wide_words(uint32_t rows, uint64_t table_n) { return (uint64_t)rows * table_n > (1ull << IDX_BITS); }
 
-int msm_sort_reserve_fixed(Ctx* c) {
-  MsmWork& w = c->msm;
-  constexpr int KB = MSM_MAX_BATCH;
-  HIP_TRY(hipMalloc((void**)&w.coarse_cnt, sizeof(uint32_t) * COARSE * KB));
-  HIP_TRY(hipMalloc((void**)&w.coarse_off, sizeof(uint32_t) * (COARSE + 1) * KB));
-  HIP_TRY(hipMalloc((void**)&w.coarse_cur, sizeof(uint32_t) * COARSE * KB));
-  HIP_TRY(hipMalloc((void**)&w.big_off, sizeof(uint32_t) * (COARSE + 1) * KB));
-  HIP_TRY(hipMalloc((void**)&w.big_cnt, sizeof(uint32_t) * 2 * MSM_NB * KB));   // bin-wide bucket counts, then the run cursors
-  HIP_TRY(hipMalloc((void**)&w.full_off, sizeof(uint32_t) * (MSM_NB + 1) * KB));
-  HIP_TRY(hipMalloc((void**)&w.part_list, sizeof(uint32_t) * (MSM_NB + 1) * KB));
-  return PLONK_OK;
-}
-
+}  // namespace PLONK_MSM_NS
 }  // namespace plonk

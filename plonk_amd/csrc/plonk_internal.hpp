@@ -45,9 +45,28 @@ struct NttTables {
 // MSM geometry: 2^15 signed-digit buckets shared by every table row.  Window tables (16 rows, 2^(16 w) * P_i): 16-bit
 // signed windows; bit-position tables (256 rows, 2^r * P_i, round 3): width-17 NAF digits (msm_recode.cuh).  Either
 // way a scalar yields at most MSM_W entries.
-static constexpr int MSM_C = 16;
+//
+// The bucket count is a COMPILE-TIME constant of the MSM kernels (msm.hip, msm_sort.hip), and those two files are compiled
+// twice: PLONK_MSM_NB_BITS = 15 (namespace nb15: 2^15 buckets, both recodings, every size) and 19 (namespace nb19: 2^19
+// buckets for bit-position tables and large MSMs — width-21 NAF digits, 12.1 additions per scalar, one lane per bucket).
+// msm_batch_device (msm.hip, compiled once) picks the variant per call; Ctx / MsmWork are shared and sized for the larger.
+#ifndef PLONK_MSM_NB_BITS
+#define PLONK_MSM_NB_BITS 15
+#endif
+#if PLONK_MSM_NB_BITS == 15
+#define PLONK_MSM_NS nb15
+#elif PLONK_MSM_NB_BITS == 19
+#define PLONK_MSM_NS nb19
+#else
+#error "PLONK_MSM_NB_BITS must be 15 or 19"
+#endif
+static constexpr int MSM_C = 16;                          // window tables: signed 16-bit windows (2^15 buckets only)
 static constexpr int MSM_W = MSM_DIGITS;
-static constexpr uint32_t MSM_NB = 1u << (MSM_C - 1);   // buckets 1..32768
+static constexpr int MSM_NB_BITS = PLONK_MSM_NB_BITS;
+static constexpr uint32_t MSM_NB = 1u << MSM_NB_BITS;     // buckets of THIS translation unit's variant
+static constexpr int MSM_NB_BITS_MAX = 19;
+static constexpr uint32_t MSM_NB_MAX = 1u << MSM_NB_BITS_MAX;   // what the shared work buffers are sized for
+static constexpr uint32_t MSM_NAF_WIDTH = MSM_NB_BITS + 2;      // bit-position digits: odd, |d| < 2^(NB_BITS + 1), bucket = |d| >> 1
 static constexpr int MSM_MAX_BATCH = 4;                  // commitments per group launch
 
 struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the same bases, launched together
@@ -84,6 +103,7 @@ struct MsmWork {   // per-context scratch, grown on demand
   uint32_t* slice_off = nullptr;   // NB + 1
   uint32_t* full_off = nullptr;    // NB + 1: scan of the FULL slices per bucket (PLONK_MSM_ORDER=1: lanes in order of slice length)
   uint32_t* part_list = nullptr;   // NB + 1: buckets with a partial slice, longest first; [NB] = their number
+  uint32_t* layout = nullptr;      // 2^19-bucket variant: block totals / remainder-class counts of the multi-workgroup layout pass
   uint64_t cap_slices = 0;
   void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
   void* buckets = nullptr;         // NB
@@ -92,6 +112,7 @@ struct MsmWork {   // per-context scratch, grown on demand
   void* seg_sum = nullptr;         // segment sums of the heavy buckets
   uint64_t cap_segs = 0;
   void* chunk = nullptr;           // row / column sums
+  int last_rowbits = 8;            // row bit sums written by the last msm_batch_device call (8: 2^15 buckets, 12: 2^19)
   uint8_t* result = nullptr;       // 97 B device
   uint8_t* result_host = nullptr;  // pinned
   Fr* scalars_stage = nullptr;     // H2D staging for the host-pointer API
@@ -176,9 +197,18 @@ int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_xyzz_dev);
 // bit_sums = false: out[k] = the commitment (one XYZZ point).  true: out[k][0..16) = partial sums the
 // host combines with a short doubling chain (msm.hip msm_bits_kernel, prover.hip finish_bit_sums).
 // [16] = the sum of ALL buckets: bit-position entries weigh 2 b + 1, so their commitment is 2 W - S (hostg1.hpp).
-static constexpr int MSM_BIT_SUMS = 17;
-// table == nullptr: the context's commit key; otherwise tables built by srs_table_build (same layout, table_rows rows)
-int msm_order_slices(Ctx* c, const MsmBatch& bt);   // msm_sort.hip: full_off / part_list from the bucket offsets
+// Layout with rb = log2(rows) row bits (8 for 2^15 buckets, 12 for 2^19): rows [0, rb), columns [rb, rb + 7), C_128, S.
+static constexpr int MSM_BIT_SUMS = 12 + 9;          // slots per commitment (the larger variant's count)
+// variant entry points (msm.hip / msm_sort.hip, one set per compiled bucket count)
+#define PLONK_MSM_VARIANT_DECLS                                                                                          \
+  int msm_order_slices(Ctx* c, const MsmBatch& bt);                                                                      \
+  int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax);                                                         \
+  bool msm_needs_wide_words(uint32_t rows, uint64_t table_n);                                                            \
+  int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums);
+namespace nb15 { PLONK_MSM_VARIANT_DECLS }
+namespace nb19 { PLONK_MSM_VARIANT_DECLS }
+// table == nullptr: the context's commit key; otherwise tables built by srs_table_build (same layout, table_rows rows).
+// c->msm.last_rowbits tells the caller how the bit sums of THIS call are laid out (finish_bit_sums).
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
                      bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0,
                      const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr, uint32_t table_rows = 0);
@@ -194,8 +224,6 @@ int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
 // host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);
 int msm_reserve(Ctx* c, uint64_t m);
-// msm_sort.hip: scalars of a commitment group -> entries grouped by bucket, bucket offsets, slice offsets
-int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax);
 int msm_sort_reserve_fixed(Ctx* c);
 
 }  // namespace plonk

@@ -71,6 +71,7 @@ struct Prover {
   uint8_t* res = nullptr;          // 16 x 256 B MSM results, XYZZ (device)
   uint8_t* res_host = nullptr;     // pinned mirror
   bool res_bitpos[16] = {};        // slot holds the sums of bit-position entries (finish_bit_sums: 2 W - S)
+  int res_rowbits[16] = {};        // row bit sums in the slot (8: 2^15 buckets, 12: 2^19; msm_batch_device reports it per call)
   uint8_t* gather_host = nullptr;  // world x 16 x 192 B all-gathered partial sums
   // multi-GPU: this rank owns SRS points [shard_lo, shard_lo + c->srs_n) of srs_total
   int rank = 0, world = 1;
@@ -178,7 +179,9 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
   G1* out[MSM_MAX_BATCH];
   if (table) {   // a prover-owned key (Lagrange basis, single GPU): no point-range sharding
     for (int k = 0; k < count; ++k) { out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k)); p->res_bitpos[first_slot + k] = p->lag_rows == MSM_ROWS_BITPOS; }
-    return msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split, p->lag_rows);
+    const int rc = msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split, p->lag_rows);
+    for (int k = 0; k < count; ++k) p->res_rowbits[first_slot + k] = p->c->msm.last_rowbits;
+    return rc;
   }
   for (int k = 0; k < count; ++k) {
     if (m[k] > p->srs_total) return PLONK_ERR_DEGREE;   // check_commit_degree_is_within_bounds, key.rs:362-370
@@ -190,7 +193,9 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
     out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k));
     p->res_bitpos[first_slot + k] = p->c->srs_rows == MSM_ROWS_BITPOS;
   }
-  return msm_batch_device(p->c, sc, cnt, count, out, true);
+  const int rc = msm_batch_device(p->c, sc, cnt, count, out, true);
+  for (int k = 0; k < count; ++k) p->res_rowbits[first_slot + k] = p->c->msm.last_rowbits;
+  return rc;
 }
 static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) { return msm_group(p, &scalars, &m, 1, slot); }
 static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48]);
@@ -244,7 +249,7 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
                          hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   std::vector<G1> sums(count);
-  for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)), p->res_bitpos[first + i]);
+  for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)), p->res_rowbits[first + i], p->res_bitpos[first + i]);
   if (p->world > 1) {
     const size_t bytes = sizeof(G1) * (size_t)count;
     PTRY(comm_allgather_host(c, p->link, sums.data(), p->gather_host, bytes));

@@ -165,18 +165,18 @@ extern "C" void h_quotient_low(const uint32_t* key_low, const uint8_t* has, cons
 #include "../../plonk_amd/csrc/hostg1.hpp"
 // pts: 16 affine points (96 B raw each; a point with x = y = 0 stands for the identity) -> XYZZ bit sums
 // -> finish_bit_sums -> batch affine -> 48-byte compressed.  out48: the commitment.
-// bitpos != 0: 17 points, the last one is S and the result is 2 W - S (bit-position entries weigh 2 b + 1)
-extern "C" void h_finish_bit_sums(const uint8_t* pts96, int bitpos, uint8_t out48[48]) {
+// rb row bit sums, 7 column bit sums, C_128, and (bitpos != 0) S: the result is 2 W - S (bit-position entries weigh 2 b + 1)
+extern "C" void h_finish_bit_sums(const uint8_t* pts96, int rb, int bitpos, uint8_t out48[48]) {
   using namespace plonk;
-  G1 bits[17];
-  bits[16] = G1::identity();
-  for (int k = 0; k < (bitpos ? 17 : 16); ++k) {
+  G1 bits[MSM_ROWBITS_MAX + 9];
+  bits[rb + 8] = G1::identity();
+  for (int k = 0; k < rb + 8 + (bitpos ? 1 : 0); ++k) {
     G1Affine a;
     memcpy(&a, pts96 + 96 * k, 96);
     bits[k] = (a.x.is_zero() && a.y.is_zero()) ? G1::identity() : G1::from_affine(a);
     if (k & 1) bits[k] = bits[k].dbl().add(bits[k].neg());   // a non-trivial ZZ: 2P - P
   }
-  const G1 w = finish_bit_sums(bits, bitpos != 0);
+  const G1 w = finish_bit_sums(bits, rb, bitpos != 0);
   uint8_t aff[1][97];
   batch_xyzz_to_affine97(&w, 1, aff);
   g1_compress97(aff[0], out48);
@@ -226,7 +226,9 @@ extern "C" int h_msm_recode(const uint32_t* scalar, int bitpos, uint32_t* out) {
     out[4 * n] = (uint32_t)slot; out[4 * n + 1] = row; out[4 * n + 2] = bucket; out[4 * n + 3] = sign;
     ++n;
   };
-  if (bitpos == 2) {   // the kernels' form: the scalar parked limb-major with a stride (StridedLimbs)
+  if (bitpos == 21) {  // the 2^19-bucket variant's digit width
+    for_each_digit_naf<21>(s, emit);
+  } else if (bitpos == 2) {   // the kernels' form: the scalar parked limb-major with a stride (StridedLimbs)
     uint32_t park[9 * 3];
     for (int j = 0; j < 9; ++j) { park[3 * j] = 0xdeadbeefu; park[3 * j + 1] = j < 8 ? s.l[j] : 0u; park[3 * j + 2] = 0x12345678u; }
     for_each_digit_bitpos(StridedLimbs{park + 1, 3}, emit);

@@ -272,9 +272,10 @@ def test_host_msm_finish_and_group_normalisation(lib):
     64-bit-limb host arithmetic, against the oracle's group law."""
     rnd = random.Random(64)
     G = E.G1_GEN
-    for trial in range(8):
-        bitpos = trial >= 4                       # 17th sum S: the result is 2 W - S (bit-position entries weigh 2 b + 1)
-        pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(17 if bitpos else 16)]
+    for trial in range(12):
+        bitpos = trial >= 4                       # last sum S: the result is 2 W - S (bit-position entries weigh 2 b + 1)
+        rb = 12 if trial >= 8 else 8              # row bit sums: 8 for 2^15 buckets, 12 for 2^19
+        pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(rb + 8 + (1 if bitpos else 0))]
         if trial % 4 == 1:
             pts[3] = None                         # an empty bit sum
             pts[9] = None
@@ -284,18 +285,18 @@ def test_host_msm_finish_and_group_normalisation(lib):
             pts = [pts[0]] * len(pts)             # equal points: the additions hit the doubling branch
         raw = b"".join(E.g1_to_raw96(p) if p is not None else bytes(96) for p in pts)
         out = (ctypes.c_uint8 * 48)()
-        lib.h_finish_bit_sums(raw, 1 if bitpos else 0, out)
-        # rows weigh 2^(7+j) (j = 0..7 -> indices 0..7), columns 2^j (indices 8..14), C_128 weighs 2^7 (index 15)
+        lib.h_finish_bit_sums(raw, rb, 1 if bitpos else 0, out)
+        # rows weigh 2^(7+j) (indices 0..rb-1), columns 2^j (indices rb..rb+6), C_128 weighs 2^7 (index rb+7)
         want = None
-        for k, p in enumerate(pts[:16]):
+        for k, p in enumerate(pts[:rb + 8]):
             if p is None:
                 continue
-            w = (1 << (7 + k)) if k < 8 else ((1 << (k - 8)) if k < 15 else (1 << 7))
+            w = (1 << (7 + k)) if k < rb else ((1 << (k - rb)) if k < rb + 7 else (1 << 7))
             want = E.g1_add(want, E.g1_mul(p, w))
         if bitpos:
             want = E.g1_add(want, want)
-            if pts[16] is not None:
-                want = E.g1_add(want, E.g1_mul(pts[16], Q - 1))
+            if pts[rb + 8] is not None:
+                want = E.g1_add(want, E.g1_mul(pts[rb + 8], Q - 1))
         assert bytes(out) == E.g1_compress(want), trial
     pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(15)]
     pts[4] = None

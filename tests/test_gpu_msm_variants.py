@@ -21,9 +21,27 @@ def run_variant(env_extra, select=SELECT, marker="gpu", target="tests/test_gpu_m
     {"PLONK_MSM_ORDER": "1"},      # lanes of msm_accumulate in order of slice length
     {"PLONK_MSM_ACC": "lds"},      # three waves per SIMD, table entries prefetched into LDS
     {"PLONK_MSM_TAIL": "serial"},  # one lane per addition in the reduction tail
+    {"PLONK_MSM_TABLE": "window"},                               # 16 window rows, signed 16-bit windows (the default below 2^17 points)
+    {"PLONK_MSM_TABLE": "bitpos"},                               # a table row per bit position, width-17 NAF digits, 2^15 buckets
+    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"},    # width-21 NAF digits over 2^19 buckets (the default above 2^19 terms)
+    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_ORDER": "0"},
 ], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_variant_matches_the_oracle_on_the_edge_cases(variant):
     r = run_variant(variant)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"}],
+                         ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_prover_parity_holds_with_every_table_and_bucket_layout(variant):
+    """whole proofs (reference KAT digest, random circuits, widget circuits vs the C oracle at 2^12 / 2^13) with the table /
+    bucket layouts that the size rules would only pick for large circuits"""
+    r = run_variant(variant, select="kat or random_arithmetic or proof_bytes_equal_c_oracle and not 16 and not 2p20",
+                    marker="gpu and not slow", target="tests/test_gpu_prover.py tests/test_gpu_prove_sizes.py".split()[0])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = run_variant(variant, select="proof_bytes_equal_c_oracle and not 16 and not 2p20", marker="gpu and not slow", target="tests/test_gpu_prove_sizes.py")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 

@@ -114,6 +114,9 @@ def test_product_recoding_matches_the_models():
         assert got == bitpos_digits(s), hex(s)
         n2 = lib.h_msm_recode(limbs, 2, out)                                # the LDS-parked form the kernels use
         assert [(out[4 * j + 1], (2 * out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1)) for j in range(n2)] == got
+        n21 = lib.h_msm_recode(limbs, 21, out)                              # width-21 digits of the 2^19-bucket variant
+        assert [(out[4 * j + 1], (2 * out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1)) for j in range(n21)] == bitpos_digits(s, 21)
+        assert n21 <= 13 and all(out[4 * j + 2] < (1 << 19) for j in range(n21))
         n = lib.h_msm_recode(limbs, 0, out)
         got = {out[4 * j + 1]: (out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1) for j in range(n)}
         want = {w: d for w, d in enumerate(signed_digits(s, 16)) if d}
