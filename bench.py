@@ -530,8 +530,15 @@ def main():
                     pass
         qd8 = os.environ.get("PLONK_QUOTIENT_DOMAIN", "")[:1] == "8" or world == 8
         table_rows = ctx.table_rows()
-        # uniform scalars: 16 signed 16-bit windows, or the width-17 NAF over bit-position tables: 254.9 / 18 + 1/2 digits
-        digits_per_scalar = 16.0 if table_rows == 16 else 14.67
+        # uniform scalars: 16 signed 16-bit windows; NAF digits over bit-position tables: 254.9 / (w + 1) + 1/2 per scalar, minus
+        # the first entry of every slice (an assignment, not an addition) — w = 21 over 2^19 buckets from 2^19 terms on (one slice
+        # of ~24 entries per bucket), w = 17 over 2^15 buckets below
+        if table_rows == 16:
+            digits_per_scalar = 16.0 - 0.5
+        elif m_local > (1 << 19) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":
+            digits_per_scalar = round(254.86 / 22 + 0.5 - (1 << 19) / max(m_local, 1), 2)
+        else:
+            digits_per_scalar = 14.67 - 0.5
         npoly = 6 if pi else 5
         out = {
             "metric": "prove() wall-clock (ms) at 2^%d gates" % log_n,

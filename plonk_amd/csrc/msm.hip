@@ -477,7 +477,7 @@ msm_accumulate_lds_kernel(const G1AffineR* __restrict__ table, MsmBatch bt, cons
 // (one slice per lane + an 8-step LDS tree), msm_heavy_bucket_kernel the segment sums of one bucket per workgroup:
 // ~14 dependent additions for a bucket of any size, and the heavy buckets — which sit next to each other at the
 // small bucket indices — are spread over the whole chip.
-static constexpr uint32_t HEAVY_SEG = 256;
+static constexpr uint32_t HEAVY_SEG = 128;
 // (HeavyItem: plonk_internal.hpp.)  The list of heavy buckets is written by msm_slices_kernel (msm_sort.hip), i.e. BEFORE
 // the accumulation, so that the segment sums do not need a kernel of their own: the first `fused` workgroups of
 // msm_bucket_sum are segment workers (32 quads: 8 slices per quad + a 5-step tree of quad additions, g1r_add_quad below)
@@ -485,13 +485,14 @@ static constexpr uint32_t HEAVY_SEG = 256;
 // group whenever a witness (or the leftover top digit of the bit-position recoding) makes a few buckets heavy.  A bucket
 // of one segment goes straight to its bucket slot; longer ones leave segment sums for msm_heavy_bucket.
 __device__ __forceinline__ G1R g1r_add_quad(const G1R& a, const G1R& b, uint32_t q);
-static constexpr uint32_t HEAVY_FUSED_WGS = 128;
+static constexpr uint32_t HEAVY_FUSED_WGS = MSM_NB_BITS > 15 ? 512 : 128;   // many buckets: the ordinary part of the grid is nearly empty, the skewed low buckets are the kernel
 template <int BS_G>   // lanes per bucket, chosen from the expected slices per bucket (msm_batch_device)
 __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const G1RSlot* __restrict__ partial_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ buckets_all, uint32_t heavy_thresh,
                                                              const uint32_t* __restrict__ nheavy_all, const HeavyItem* __restrict__ heavy_list_all,
-                                                             G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused, uint32_t direct) {
+                                                             G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused, uint32_t direct,
+                                                             const uint32_t* __restrict__ multi_list_all) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -524,6 +525,20 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
       }
       if (t == 0) st_g1r(nseg == 1 ? buckets + b : seg_sum + sg, acc);
       __syncthreads();
+    }
+    return;
+  }
+  if (multi_list_all) {
+    // many buckets: only the listed buckets of 2 .. heavy_thresh slices (every other one is already written), one lane each,
+    // over a SMALL grid with a stride loop — 4096 nearly empty workgroups per commitment cost 0.2 ms of dispatch alone (r03c)
+    const uint32_t nmulti = nheavy_all[2 * MSM_MAX_BATCH + kb];
+    const uint32_t* __restrict__ list = multi_list_all + (uint64_t)kb * MSM_NB;
+    for (uint32_t i = (blockIdx.x - fused) * blockDim.x + threadIdx.x; i < nmulti; i += (gridDim.x - fused) * blockDim.x) {
+      const uint32_t mb = list[i];
+      const uint32_t beg = slice_off[mb], end = slice_off[mb + 1];
+      G1R acc = ld_g1r(partial + beg);
+      for (uint32_t k = beg + 1; k < end; ++k) acc = acc.add(ld_g1r(partial + k));
+      st_g1r(buckets + mb, acc);
     }
     return;
   }
@@ -908,22 +923,25 @@ __global__ void msm_identity_kernel(G1* out) {
 // host side
 // ---------------------------------------------------------------------------
 // Rows of the tables of an n-point key.  A row per bit position (256 rows, 32 KiB per point) saves 8 % of the
-// additions of every MSM over the key; it is chosen when the tables take at most a third of the HBM that is free right
-// now (2^20 points: 32 GiB, twice per prover context — commit key and Lagrange-basis key — of 288 GB), else the 16
-// window rows (2^22 points: 8.6 GiB instead of 137).  PLONK_MSM_TABLE=window | bitpos forces either.
+// additions of every MSM over the key (25 % with the 2^19-bucket layout it also enables); it is chosen when the tables
+// take at most HALF of the HBM that is free right now — 2^20 points: 32 GiB, twice per prover context (commit key and
+// Lagrange-basis key) of 288 GB; 2^22 points: 137 GB for the commit key, after which the Lagrange-basis key (4 of the 11
+// commitments) falls back to the 16 window rows (8.6 GiB).  PLONK_MSM_TABLE=window | bitpos forces either.
 uint32_t msm_table_rows(uint64_t n) {
   if (const char* e = getenv("PLONK_MSM_TABLE")) {
     if (e[0] == 'w') return MSM_ROWS_WINDOW;
     if (e[0] == 'b') return (uint64_t)MSM_ROWS_BITPOS * n <= (1ull << 31) ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
   }
   if ((uint64_t)MSM_ROWS_BITPOS * n > (1ull << 31)) return MSM_ROWS_WINDOW;   // 31-bit table index of an entry
-  // small keys: the saved additions no longer pay for the longer recoding and the skewed top digit (r03e, same box:
-  // 2^16 gates 5.33 ms with window rows, 5.59 with bit-position rows; 2^20: 37.4 -> 36.5)
-  if (n < (1ull << 17) + 8) return MSM_ROWS_WINDOW;
+  // small keys: the saved additions do not pay for the longer recoding, the skewed top digit and — with the 2^19-bucket
+  // layout — a reduction over 16x the buckets (same-box pairs, window rows vs bit-position rows: 2^16 gates 5.33 / 5.59 ms,
+  // 2^18 11.16 / 11.37, 2^19 20.23 / 20.43; 2^20 37.8 / 34.9, 2^21 71.9* / 64.4, 2^22 147.0 / 131.8; * = 2^15 buckets).
+  // profiles/r03c/sizes_2p18_to_2p22.txt
+  if (n <= (1ull << 19) + 64) return MSM_ROWS_WINDOW;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MSM_ROWS_WINDOW;
   const uint64_t need = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_BITPOS * n + sizeof(Fp28Slot) * 3 * (MSM_ROWS_BITPOS - 1) * (1ull << 16);
-  return need <= fr / 3 ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
+  return need <= fr / 2 ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
 }
 static int table_index_check(uint32_t rows, uint64_t n) {
   if ((uint64_t)rows * n > (1ull << 31)) return (plonk::set_last_error("invalid argument", "commit key: table rows * points must be <= 2^31 (31-bit table index of an entry)", __FILE__, __LINE__), PLONK_ERR_ARG);
@@ -1128,7 +1146,10 @@ namespace PLONK_MSM_NS {
 static uint32_t msm_ksl(uint64_t m) {
   static const int forced = [] { const char* e = getenv("PLONK_MSM_KSL"); return e ? atoi(e) : 0; }();   // tuning experiments only
   if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64 || forced == 128) return (uint32_t)forced;
-  if (MSM_NB_BITS > 15) return MSM_KSL;
+  if (MSM_NB_BITS > 15) {   // one slice per bucket: the smallest of 32 / 64 / 128 that holds ~1.3x the expected entries of a bucket
+    const uint64_t expect = 13 * m / MSM_NB;
+    return expect <= 24 ? 32u : (expect <= 49 ? 64u : 128u);
+  }
   uint32_t r = 4;
   while (r < MSM_KSL && (uint64_t)r * MSM_NB < m) r *= 2;   // smallest power of two >= m / 2^15, clamped to [4, 32]
   return r;
@@ -1208,6 +1229,9 @@ __global__ void __launch_bounds__(256) msm_fold_quad_kernel(const G1RSlot* __res
 }
 #endif
 
+#if PLONK_MSM_NB_BITS > 15
+int msm_buckets_bits() { return MSM_NB_BITS; }
+#endif
 // One commitment group through the pipeline: bucket grouping, accumulation, bucket sums, reduction tail.
 // bt arrives filled (scalars, sizes, outputs, table); ksl / wide / heavy_thresh are decided here.
 int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
@@ -1260,9 +1284,11 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     // PLONK_MSM_TAIL=serial: one lane per addition in the heavy-bucket, row/column and bit-sum kernels (A/B, fallback)
     static const bool tail_quad_ = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
     const uint32_t fused = (tail_quad_ || MSM_NB_BITS > 15) ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
-#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3(MSM_NB * G / 128 + fused, count), dim3(128), 0, st, bt, \
+    const bool list_mode = MSM_NB_BITS > 15 && acc_ordered && !acc_lds;   // bucket sums driven by msm_layout_apply's list
+#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3((list_mode ? 256u : MSM_NB * G / 128) + fused, count), dim3(128), 0, st, bt, \
                                    (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (const HeavyItem*)w.heavy_list, \
-                                   (G1RSlot*)w.seg_sum, w.cap_segs, fused, (acc_ordered && !acc_lds) ? 1u : 0u)
+                                   (G1RSlot*)w.seg_sum, w.cap_segs, fused, (acc_ordered && !acc_lds) ? 1u : 0u, \
+                                   list_mode ? (const uint32_t*)w.multi_list : (const uint32_t*)nullptr)
     if (avg_slices <= 4) BSUM(1);
     else if (avg_slices <= 16) BSUM(2);
     else if (avg_slices <= 32) BSUM(4);
@@ -1344,6 +1370,7 @@ int msm_sort_reserve_fixed(Ctx* c) {   // the bucket sort's size-independent buf
   HIP_TRY(hipMalloc((void**)&w.big_cnt, sizeof(uint32_t) * 2 * MSM_NB_MAX * KB));   // bin-wide bucket counts, then the run cursors
   HIP_TRY(hipMalloc((void**)&w.full_off, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
   HIP_TRY(hipMalloc((void**)&w.part_list, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
+  HIP_TRY(hipMalloc((void**)&w.multi_list, sizeof(uint32_t) * MSM_NB_MAX * KB));
   HIP_TRY(hipMalloc((void**)&w.layout, sizeof(uint32_t) * (2 * (MSM_NB_MAX / 1024) + (MSM_NB_MAX / 1024 + 1) * 132) * KB));
   return PLONK_OK;
 }
@@ -1355,14 +1382,14 @@ int msm_reserve(Ctx* c, uint64_t m) {
     // all-or-nothing: a failure half way must not leave some of these set (the next call would skip the block and
     // launch kernels on null pointers) — free whatever exists and start over
     for (void** q : {(void**)&w.offsets, (void**)&w.slice_off, (void**)&w.nheavy, &w.heavy_list, (void**)&w.coarse_cnt, (void**)&w.coarse_off,
-                     (void**)&w.coarse_cur, (void**)&w.big_off, (void**)&w.big_cnt, (void**)&w.full_off, (void**)&w.part_list, (void**)&w.layout, &w.buckets, &w.chunk,
+                     (void**)&w.coarse_cur, (void**)&w.big_off, (void**)&w.big_cnt, (void**)&w.full_off, (void**)&w.part_list, (void**)&w.layout, (void**)&w.multi_list, &w.buckets, &w.chunk,
                      (void**)&w.result}) {
       if (*q) { (void)hipFree(*q); *q = nullptr; }
     }
     if (w.result_host) { (void)hipHostFree(w.result_host); w.result_host = nullptr; }
     HIP_TRY(hipMalloc((void**)&w.offsets, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
     HIP_TRY(hipMalloc((void**)&w.slice_off, sizeof(uint32_t) * (MSM_NB_MAX + 1) * KB));
-    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * 2 * KB));
+    HIP_TRY(hipMalloc((void**)&w.nheavy, sizeof(uint32_t) * 4 * KB));
     HIP_TRY(hipMalloc((void**)&w.heavy_list, sizeof(HeavyItem) * MSM_NB_MAX * KB));
     { const int rc_s = msm_sort_reserve_fixed(c); if (rc_s) return rc_s; }
     HIP_TRY(hipMalloc((void**)&w.buckets, sizeof(G1RSlot) * MSM_NB_MAX * KB));
@@ -1385,7 +1412,7 @@ int msm_reserve(Ctx* c, uint64_t m) {
     HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
     w.cap_slices = msm_slice_cap(cap);
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
-    w.cap_segs = w.cap_slices / 256 + MSM_NB_MAX + 1;   // sum over heavy buckets of ceil(slices / 256)
+    w.cap_segs = w.cap_slices / 128 + MSM_NB_MAX + 1;   // sum over heavy buckets of ceil(slices / HEAVY_SEG)
     HIP_TRY(hipMalloc((void**)&w.seg_sum, sizeof(G1RSlot) * w.cap_segs * KB));
     w.cap_m = cap;
   }
@@ -1438,8 +1465,8 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
   static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
   const bool can19 = table_rows == MSM_ROWS_BITPOS && bit_sums && tail_quad && !acc_lds;
-  const bool use19 = can19 && (buckets_env == 19 || (buckets_env != 15 && mmax > (1ull << 19)));
-  return use19 ? nb19::msm_batch_device_v(c, bt, mmax, bit_sums) : nb15::msm_batch_device_v(c, bt, mmax, bit_sums);
+  const bool use19 = can19 && (buckets_env > 15 || (buckets_env != 15 && mmax > (1ull << 19) + 64));
+  return use19 ? nbl::msm_batch_device_v(c, bt, mmax, bit_sums) : nb15::msm_batch_device_v(c, bt, mmax, bit_sums);
 }
 
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {

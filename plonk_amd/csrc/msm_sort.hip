@@ -165,6 +165,26 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
   return incl - v;
 }
 
+// exclusive prefix of the 2^FINE_BITS counters cnt[] into ex[] (sc: scratch of the same size; *total = their sum); every
+// thread of the workgroup calls it.  The serial loop of one thread it replaces was free for 16 fine buckets and 5-10 us —
+// with a global atomic per bucket in msm_big_scatter, 160 us — for the 256 of the 2^19-bucket variant.
+__device__ __forceinline__ void fine_exclusive_scan(const uint32_t* cnt, uint32_t* ex, uint32_t* sc, uint32_t* total) {
+  constexpr uint32_t NF = 1u << FINE_BITS;
+  const uint32_t t = threadIdx.x;
+  const uint32_t v = t < NF ? cnt[t] : 0u;
+  if (t < NF) sc[t] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < NF; d <<= 1) {
+    const uint32_t x = (t < NF && t >= d) ? sc[t - d] : 0u;
+    __syncthreads();
+    if (t < NF) sc[t] += x;
+    __syncthreads();
+  }
+  if (t < NF) ex[t] = sc[t] - v;
+  *total = sc[NF - 1];
+  __syncthreads();
+}
+
 // ---- level 1b: coarse offsets; also clears the run cursors of the partition pass ------------------
 // Skewed digits (many equal or small scalars: bits, quads, range accumulators of a real witness) put a large share
 // of the entries into a few coarse bins.  A bin above BIG_LIMIT words is not left to one workgroup: it is cut into
@@ -294,7 +314,7 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
                                                           void* __restrict__ tmp_all,
                                                           uint32_t* __restrict__ entries_all,
                                                           uint32_t* __restrict__ offsets_all) {
-  __shared__ uint32_t cnt[1u << FINE_BITS], start[1u << FINE_BITS], cur[1u << FINE_BITS];
+  __shared__ uint32_t cnt[1u << FINE_BITS], start[1u << FINE_BITS], cur[1u << FINE_BITS], scan_tmp[1u << FINE_BITS];
   const int kb = blockIdx.y;
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
@@ -316,16 +336,16 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
     if (beg + t + r * FINE_T < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
   for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) atomicAdd(&cnt[tmp.ld_fine(j)], 1u);
   __syncthreads();
-  if (t == 0) {
-    uint32_t run = beg;
-    for (uint32_t f = 0; f < (1u << FINE_BITS); ++f) {
-      start[f] = run;
-      offsets[(bin << FINE_BITS) + f] = run;
-      run += cnt[f];
+  {
+    uint32_t total;
+    fine_exclusive_scan(cnt, start, scan_tmp, &total);
+    if (t < (1u << FINE_BITS)) {
+      start[t] += beg;
+      offsets[(bin << FINE_BITS) + t] = start[t];
     }
-    if (bin == COARSE - 1) offsets[MSM_NB] = run;
+    if (t == 0 && bin == COARSE - 1) offsets[MSM_NB] = beg + total;
+    __syncthreads();
   }
-  __syncthreads();
   auto place = [&](WordT e) {
     const uint32_t f = SortWord<WordT>::fine(e);
     const uint32_t pos = start[f] + atomicAdd(&cur[f], 1u);
@@ -379,7 +399,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
                                                                 void* __restrict__ tmp_all,
                                                                 const uint32_t* __restrict__ big_cnt_all, uint32_t* __restrict__ big_cur_all,
                                                                 uint32_t* __restrict__ entries_all, uint32_t* __restrict__ offsets_all) {
-  __shared__ uint32_t cnt[1u << FINE_BITS], base[1u << FINE_BITS], cur[1u << FINE_BITS];
+  __shared__ uint32_t cnt[1u << FINE_BITS], base[1u << FINE_BITS], cur[1u << FINE_BITS], bin_cnt[1u << FINE_BITS], scan_tmp[1u << FINE_BITS];
   const int kb = blockIdx.y;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
@@ -401,15 +421,18 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
     if (j < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
   }
   __syncthreads();
-  if (t == 0) {   // bucket starts inside the bin from the bin-wide counts; this chunk's run in every bucket by one atomic each
-    uint32_t run = coff[bin];
+  {   // bucket starts inside the bin from the bin-wide counts; this chunk's run in every bucket by one atomic each
     const bool first = beg == coff[bin];
-    for (uint32_t f = 0; f < (1u << FINE_BITS); ++f) {
-      if (first) offsets[(bin << FINE_BITS) + f] = run;
-      base[f] = run + (cnt[f] ? atomicAdd(&bcur[f], cnt[f]) : 0u);
-      run += bcnt[f];
+    if (t < (1u << FINE_BITS)) bin_cnt[t] = bcnt[t];
+    __syncthreads();
+    uint32_t total;
+    fine_exclusive_scan(bin_cnt, base, scan_tmp, &total);
+    if (t < (1u << FINE_BITS)) {
+      const uint32_t run = coff[bin] + base[t];
+      if (first) offsets[(bin << FINE_BITS) + t] = run;
+      base[t] = run + (cnt[t] ? atomicAdd(&bcur[t], cnt[t]) : 0u);
     }
-    if (first && bin == COARSE - 1) offsets[MSM_NB] = run;
+    if (first && t == 0 && bin == COARSE - 1) offsets[MSM_NB] = coff[bin] + total;
   }
   __syncthreads();
 #pragma unroll
@@ -425,7 +448,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
 // ---- slice offsets: slice_off[b] = sum_{b' < b} ceil(count[b'] / ksl), one workgroup per commitment
 // Also lists the HEAVY buckets (more than heavy_thresh slices: skewed digits) with their 256-slice segments —
 // nheavy[2 kb] buckets, nheavy[2 kb + 1] segments — for the segment workers inside msm_bucket_sum (msm.hip).
-static constexpr uint32_t HEAVY_SEG_SLICES = 256;
+static constexpr uint32_t HEAVY_SEG_SLICES = 128;   // = HEAVY_SEG of msm.hip
 __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __restrict__ offsets_all,
                                                             uint32_t* __restrict__ slice_off_all, uint32_t ksl, uint32_t heavy_thresh,
                                                             uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
@@ -575,7 +598,8 @@ __global__ void __launch_bounds__(SORT_T) msm_layout_scan_kernel(uint32_t* __res
 __global__ void __launch_bounds__(SORT_T) msm_layout_apply_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ slice_off_all,
                                                                   uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ part_list_all,
                                                                   const uint32_t* __restrict__ lay_all, uint32_t ksl, uint32_t heavy_thresh,
-                                                                  uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
+                                                                  uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all,
+                                                                  uint4* __restrict__ buckets_raw, uint32_t* __restrict__ multi_list_all) {
   __shared__ uint32_t rank[LAY_H];
   const int kb = blockIdx.y;
   const uint32_t blk = blockIdx.x, t = threadIdx.x, b = blk * SORT_T + t;
@@ -598,7 +622,23 @@ __global__ void __launch_bounds__(SORT_T) msm_layout_apply_kernel(const uint32_t
     it.seg_base = atomicAdd(&nheavy_all[2 * kb + 1], it.nseg);
     it.pad = 0;
     heavy_list_all[(uint64_t)kb * MSM_NB + atomicAdd(&nheavy_all[2 * kb], 1u)] = it;
+  } else if (ns == 0) {
+    uint4* q = buckets_raw + ((uint64_t)kb * MSM_NB + b) * 16;   // empty bucket: the identity (ZZ = 0) — a 256-B slot of zeros
+#pragma unroll
+    for (int k = 0; k < 16; ++k) q[k] = make_uint4(0u, 0u, 0u, 0u);
   }
+  // with ~24 entries per bucket a bucket is ONE slice and its lane of msm_accumulate_ordered writes the bucket itself; the
+  // few with a second slice are listed so that msm_bucket_sum touches only them (nheavy[2 KB + kb] = their number).  One
+  // global atomic per workgroup: ~26 k single appends on one counter cost 0.2 ms per launch (r03c).
+  __shared__ uint32_t nmul, mbase;
+  if (t == 0) nmul = 0;
+  __syncthreads();
+  const bool multi = ns >= 2 && ns <= heavy_thresh;
+  const uint32_t mrank = multi ? atomicAdd(&nmul, 1u) : 0u;
+  __syncthreads();
+  if (t == 0 && nmul) mbase = atomicAdd(&nheavy_all[2 * MSM_MAX_BATCH + kb], nmul);
+  __syncthreads();
+  if (multi) multi_list_all[(uint64_t)kb * MSM_NB + mbase + mrank] = b;
 }
 #endif
 
@@ -639,13 +679,13 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
     hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp,
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
-  HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 2 * MSM_MAX_BATCH, st));
+  HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 4 * MSM_MAX_BATCH, st));
 #if PLONK_MSM_NB_BITS > 15
   if (bt.ksl > 128) return (set_last_error("msm_group_sort", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
   hipLaunchKernelGGL(msm_layout_count_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.layout, bt.ksl);
   hipLaunchKernelGGL(msm_layout_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.slice_off, w.full_off, w.part_list, w.layout, bt.ksl);
   hipLaunchKernelGGL(msm_layout_apply_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.part_list,
-                     (const uint32_t*)w.layout, bt.ksl, bt.heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list);
+                     (const uint32_t*)w.layout, bt.ksl, bt.heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list, (uint4*)w.buckets, w.multi_list);
 #else
   hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
                      w.nheavy, (HeavyItem*)w.heavy_list);

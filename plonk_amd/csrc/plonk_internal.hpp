@@ -47,18 +47,19 @@ struct NttTables {
 // way a scalar yields at most MSM_W entries.
 //
 // The bucket count is a COMPILE-TIME constant of the MSM kernels (msm.hip, msm_sort.hip), and those two files are compiled
-// twice: PLONK_MSM_NB_BITS = 15 (namespace nb15: 2^15 buckets, both recodings, every size) and 19 (namespace nb19: 2^19
-// buckets for bit-position tables and large MSMs — width-21 NAF digits, 12.1 additions per scalar, one lane per bucket).
+// twice: PLONK_MSM_NB_BITS = 15 (namespace nb15: 2^15 buckets, both recodings, every size) and a LARGE count (namespace
+// nbl: 2^19 — or 2^18 — buckets for bit-position tables and large MSMs: width-21 / -20 NAF digits, 12.1 / 12.6 additions
+// per scalar, one lane per bucket).
 // msm_batch_device (msm.hip, compiled once) picks the variant per call; Ctx / MsmWork are shared and sized for the larger.
 #ifndef PLONK_MSM_NB_BITS
 #define PLONK_MSM_NB_BITS 15
 #endif
 #if PLONK_MSM_NB_BITS == 15
 #define PLONK_MSM_NS nb15
-#elif PLONK_MSM_NB_BITS == 19
-#define PLONK_MSM_NS nb19
+#elif PLONK_MSM_NB_BITS >= 17 && PLONK_MSM_NB_BITS <= 19
+#define PLONK_MSM_NS nbl          /* the "large" variant; 2^18 / 2^19 buckets are both built for A/B (tools/build_variants.sh) */
 #else
-#error "PLONK_MSM_NB_BITS must be 15 or 19"
+#error "PLONK_MSM_NB_BITS must be 15 or 17..19"
 #endif
 static constexpr int MSM_C = 16;                          // window tables: signed 16-bit windows (2^15 buckets only)
 static constexpr int MSM_W = MSM_DIGITS;
@@ -103,11 +104,12 @@ struct MsmWork {   // per-context scratch, grown on demand
   uint32_t* slice_off = nullptr;   // NB + 1
   uint32_t* full_off = nullptr;    // NB + 1: scan of the FULL slices per bucket (PLONK_MSM_ORDER=1: lanes in order of slice length)
   uint32_t* part_list = nullptr;   // NB + 1: buckets with a partial slice, longest first; [NB] = their number
+  uint32_t* multi_list = nullptr;  // 2^19-bucket variant: buckets with 2 .. heavy_thresh slices (the only ones msm_bucket_sum visits)
   uint32_t* layout = nullptr;      // 2^19-bucket variant: block totals / remainder-class counts of the multi-workgroup layout pass
   uint64_t cap_slices = 0;
   void* partial = nullptr;         // slices x 256 B (XYZZ over Fp28, msm.hip)
   void* buckets = nullptr;         // NB
-  uint32_t* nheavy = nullptr;      // per commitment: number of heavy buckets / of their segments in this launch
+  uint32_t* nheavy = nullptr;      // per commitment: number of heavy buckets / of their segments in this launch; [2 KB + k]: listed multi-slice buckets
   void* heavy_list = nullptr;      // NB items per commitment (msm.hip HeavyItem)
   void* seg_sum = nullptr;         // segment sums of the heavy buckets
   uint64_t cap_segs = 0;
@@ -206,7 +208,7 @@ static constexpr int MSM_BIT_SUMS = 12 + 9;          // slots per commitment (th
   bool msm_needs_wide_words(uint32_t rows, uint64_t table_n);                                                            \
   int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums);
 namespace nb15 { PLONK_MSM_VARIANT_DECLS }
-namespace nb19 { PLONK_MSM_VARIANT_DECLS }
+namespace nbl { PLONK_MSM_VARIANT_DECLS int msm_buckets_bits(); }
 // table == nullptr: the context's commit key; otherwise tables built by srs_table_build (same layout, table_rows rows).
 // c->msm.last_rowbits tells the caller how the bit sums of THIS call are laid out (finish_bit_sums).
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,

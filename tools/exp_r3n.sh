@@ -1,10 +1,10 @@
 #!/bin/bash
 # round 3, GPU call 14: 2^19-bucket variant with multi-workgroup layout kernels, direct bucket writes, tail by group size
 set -u
-O=$GRAFT_REPO_ROOT/gpurun_out/r3n
+O=$GRAFT_REPO_ROOT/gpurun_out/r3o
 rm -rf $O; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-T="tests/test_gpu_msm.py tests/test_gpu_prover.py tests/test_golden.py"
+T="tests/test_gpu_msm.py tests/test_gpu_prover.py tests/test_golden.py tests/test_gpu_prove_sizes.py"
 PLONK_MSM_TABLE=bitpos PLONK_MSM_BUCKETS=19 timeout 600 python -m pytest $T -m "gpu and not slow" -x -q > $O/tests_nb19.log 2>&1; echo "nb19 small tests rc=$?"; tail -4 $O/tests_nb19.log
 timeout 600 python -m pytest $T -m "gpu and not slow" -x -q > $O/tests_default.log 2>&1; echo "default tests rc=$?"; tail -3 $O/tests_default.log
 B="python bench.py --no-extras --no-cpu-baseline --steps 8 --warmup 2"
