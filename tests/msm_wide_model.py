@@ -166,11 +166,13 @@ def bitpos_digits(s: int, w: int = NAF_W):
         if ((s >> p) & 1) == carry:           # remaining value even
             p += 1
             continue
-        v = ((s >> p) & ((1 << w) - 1)) + carry
-        d = v - (1 << w) if v >> (w - 1) else v
+        rem = 256 - p                                     # when at most two digits are left they share the remaining bits (+ 1 of headroom)
+        wd = (rem + 1) // 2 if w < rem <= 2 * w else w        # evenly (otherwise the last digit is small with probability ~ 1 / value)
+        v = ((s >> p) & ((1 << wd) - 1)) + carry
+        d = v - (1 << wd) if v >> (wd - 1) else v
         carry = 1 if d < 0 else 0
         out.append((p, d))
-        p += w
+        p += wd
     assert sum(d << p for p, d in out) == s
     return out
 

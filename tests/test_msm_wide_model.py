@@ -78,7 +78,8 @@ def test_bitpos_digits_are_a_width_17_naf():
         assert len(dg) <= 16
         assert all(d & 1 and abs(d) < (1 << 16) for _, d in dg)
         assert all(0 <= p <= 255 for p, _ in dg)
-        assert all(q - p >= 17 for (p, _), (q, _) in zip(dg, dg[1:]))
+        assert all(q - p >= 17 for (p, _), (q, _) in zip(dg[:-2], dg[1:-1]))      # the last two digits share what remains
+        assert all(q - p >= 9 for (p, _), (q, _) in zip(dg, dg[1:]))
     for _ in range(2000):
         total += len(bitpos_digits(r.randrange(E.Q)))
         cnt += 1
@@ -122,3 +123,23 @@ def test_product_recoding_matches_the_models():
         want = {w: d for w, d in enumerate(signed_digits(s, 16)) if d}
         assert got == want, hex(s)
         assert all(out[4 * j] == out[4 * j + 1] for j in range(n))       # window recoding: slot = row
+
+
+def test_top_digits_are_not_skewed():
+    """the last digit alone would be small with probability ~ 1 / value (bucket 0 would hold ~ 1 % of ALL entries); sharing
+    the remaining bits between the last two digits keeps every bucket within a small multiple of the mean"""
+    from collections import Counter
+
+    from msm_wide_model import bitpos_digits
+    r = random.Random(2121)
+    for w, nb in ((21, 1 << 19), (17, 1 << 15)):
+        cnt = Counter()
+        total = 0
+        n = 6000
+        for _ in range(n):
+            for _, d in bitpos_digits(r.randrange(E.Q), w):
+                cnt[abs(d) >> 1] += 1
+                total += 1
+        # without the sharing bucket 0 alone receives ~ n * 2 / w entries
+        assert max(cnt.values()) < max(12, 40 * total / nb) and cnt[0] < n / 50
+        assert all(b < nb for b in cnt)
