@@ -531,14 +531,17 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
   if (multi_list_all) {
     // many buckets: only the listed buckets of 2 .. heavy_thresh slices (every other one is already written), one lane each,
     // over a SMALL grid with a stride loop — 4096 nearly empty workgroups per commitment cost 0.2 ms of dispatch alone (r03c)
+    // A listed bucket has 2 .. heavy_thresh slices, i.e. up to 15 DEPENDENT additions: the kernel lasts as long as its longest
+    // chain (0.27 ms with one lane per bucket), so a quad works on each bucket (g1r_add_quad: ~2.8x lower latency).
     const uint32_t nmulti = nheavy_all[2 * MSM_MAX_BATCH + kb];
     const uint32_t* __restrict__ list = multi_list_all + (uint64_t)kb * MSM_NB;
-    for (uint32_t i = (blockIdx.x - fused) * blockDim.x + threadIdx.x; i < nmulti; i += (gridDim.x - fused) * blockDim.x) {
+    const uint32_t q = threadIdx.x & 3;
+    for (uint32_t i = ((blockIdx.x - fused) * blockDim.x + threadIdx.x) >> 2; i < nmulti; i += ((gridDim.x - fused) * blockDim.x) >> 2) {
       const uint32_t mb = list[i];
       const uint32_t beg = slice_off[mb], end = slice_off[mb + 1];
       G1R acc = ld_g1r(partial + beg);
-      for (uint32_t k = beg + 1; k < end; ++k) acc = acc.add(ld_g1r(partial + k));
-      st_g1r(buckets + mb, acc);
+      for (uint32_t k = beg + 1; k < end; ++k) acc = g1r_add_quad(acc, ld_g1r(partial + k), q);
+      if (q == 0) st_g1r(buckets + mb, acc);
     }
     return;
   }
@@ -1285,7 +1288,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     static const bool tail_quad_ = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
     const uint32_t fused = (tail_quad_ || MSM_NB_BITS > 15) ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
     const bool list_mode = MSM_NB_BITS > 15 && acc_ordered && !acc_lds;   // bucket sums driven by msm_layout_apply's list
-#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3((list_mode ? 256u : MSM_NB * G / 128) + fused, count), dim3(128), 0, st, bt, \
+#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3((list_mode ? 1024u : MSM_NB * G / 128) + fused, count), dim3(128), 0, st, bt, \
                                    (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (const HeavyItem*)w.heavy_list, \
                                    (G1RSlot*)w.seg_sum, w.cap_segs, fused, (acc_ordered && !acc_lds) ? 1u : 0u, \
                                    list_mode ? (const uint32_t*)w.multi_list : (const uint32_t*)nullptr)

@@ -346,15 +346,25 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
     if (t == 0 && bin == COARSE - 1) offsets[MSM_NB] = beg + total;
     __syncthreads();
   }
+  // With 256 fine buckets a bucket's run is ~24 entries (96 B): scattered straight to HBM those are partial cache lines from
+  // 512 lanes at random times.  A bin that fits the register cache (the usual case) is regrouped in LDS and written out
+  // linearly instead; a larger one scatters directly.
+  __shared__ uint32_t sorted[(MSM_NB_BITS > 15 && FINE_CACHE > 0) ? FINE_T * FINE_CACHE : 1];
+  const bool staged = MSM_NB_BITS > 15 && FINE_CACHE > 0 && end - beg <= FINE_T * FINE_CACHE;
   auto place = [&](WordT e) {
     const uint32_t f = SortWord<WordT>::fine(e);
     const uint32_t pos = start[f] + atomicAdd(&cur[f], 1u);
-    entries[pos] = SortWord<WordT>::entry(e);   // accumulate's format: index | sign << 31
+    if (staged) sorted[pos - beg] = SortWord<WordT>::entry(e);
+    else entries[pos] = SortWord<WordT>::entry(e);   // accumulate's format: index | sign << 31
   };
 #pragma unroll
   for (uint32_t r = 0; r < FINE_CACHE; ++r)
     if (beg + t + r * FINE_T < end) place(cache[r]);
   for (uint32_t j = beg + t + FINE_CACHE * FINE_T; j < end; j += FINE_T) place(tmp.ld(j));
+  if (staged) {
+    __syncthreads();
+    for (uint32_t j = t; j < end - beg; j += FINE_T) entries[beg + j] = sorted[j];
+  }
 }
 
 // ---- level 2 for oversized bins: one workgroup per BIG_CHUNK words --------------------------------
