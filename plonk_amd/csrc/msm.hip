@@ -472,15 +472,16 @@ msm_accumulate_lds_kernel(const G1AffineR* __restrict__ table, MsmBatch bt, cons
 // per bucket (strided partial sums + one LDS step) keep the SIMDs busy without idling lanes in a
 // deep tree.  Lanes per bucket follow the expected slice count: 1 (sparse), 2 (m ~ 2^20: 16 slices), 4, 8 (m >= 2^22).
 // A bucket with more than `heavy_thresh` slices is "heavy" (skewed digits: equal or small scalars — the bits, quads and
-// range accumulators of a real witness).  Its lanes here skip it; lane 0 cuts it into segments of HEAVY_SEG slices and
-// appends (bucket, first segment, segment count) to a list.  msm_heavy_seg_kernel sums one segment per workgroup
-// (one slice per lane + an 8-step LDS tree), msm_heavy_bucket_kernel the segment sums of one bucket per workgroup:
-// ~14 dependent additions for a bucket of any size, and the heavy buckets — which sit next to each other at the
-// small bucket indices — are spread over the whole chip.
+// range accumulators of a real witness).  Its lanes here skip it; it is summed in segments of HEAVY_SEG slices (workers
+// below), and msm_heavy_bucket adds the segment sums of a bucket of more than one segment: ~14 dependent additions for a
+// bucket of any size, and the heavy buckets — which sit next to each other at the small bucket indices — are spread over
+// the whole chip.
+// With MANY buckets (2^19) the kernel has a third mode: a bucket is one slice whose lane wrote the bucket itself
+// (`direct`), and only the listed buckets of 2 .. heavy_thresh slices are visited, a quad each (`multi_list_all`).
 static constexpr uint32_t HEAVY_SEG = 128;
 // (HeavyItem: plonk_internal.hpp.)  The list of heavy buckets is written by msm_slices_kernel (msm_sort.hip), i.e. BEFORE
 // the accumulation, so that the segment sums do not need a kernel of their own: the first `fused` workgroups of
-// msm_bucket_sum are segment workers (32 quads: 8 slices per quad + a 5-step tree of quad additions, g1r_add_quad below)
+// msm_bucket_sum are segment workers (32 quads: 4 slices per quad + a 5-step tree of quad additions, g1r_add_quad below)
 // and run beside the ordinary bucket sums — r03: as separate launches the two heavy kernels cost 0.2 ms per commitment
 // group whenever a witness (or the leftover top digit of the bit-position recoding) makes a few buckets heavy.  A bucket
 // of one segment goes straight to its bucket slot; longer ones leave segment sums for msm_heavy_bucket.

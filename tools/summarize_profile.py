@@ -37,8 +37,8 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(list)
     for r in rows:
         name = r["Kernel_Name"].split("(")[0][:70]
-        if name.startswith("plonk::msm_accumulate"):
-            name = "plonk::msm_accumulate_kernel"       # the ordered-lane variant is the default from 2^19 terms: one row
+        if "msm_accumulate" in name:
+            name = "plonk::msm_accumulate_kernel"       # one row for every variant (ordered lanes, nb15 / nbl namespaces)
         agg[name].append(float(r["Counter_Value"]))
     pm[C] = agg
     out.append(f"\n## {C} per launch (raw counter value, KiB)\n\n| kernel | launches | avg per launch |\n|---|---|---|")
@@ -50,7 +50,7 @@ try:
     cnt = collections.Counter()
     for r in rows:
         k = r["Kernel_Name"].split("(")[0][:50]
-        if k.startswith("plonk::msm_accumulate"):
+        if "msm_accumulate" in k:
             k = "plonk::msm_accumulate_kernel"
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     out.append("\n## SQ counters (summed over launches of 1 proof + setup)\n\n| kernel | SQ_WAVES | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAIT_INST_ANY | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES |\n|---|---|---|---|---|---|---|")
@@ -68,7 +68,7 @@ if acc in pm["FETCH_SIZE"]:
                f"+ written {wa * 1024 / 1e9:.2f} GB = **{(2 * fa + wa) * 1024 / 1e9:.2f} GB per launch** (upper bound — the gather pattern here is 4 x 16 B per lane "
                f"from random 128-B table entries, for which the guide gives no calibration; uncorrected it is {(fa + wa) * 1024 / 1e9:.2f} GB).")
     out.append("* algorithmic bytes per launch (bench.py): (32 b + 96) m averaged over the groups = 0.193 GB.  The excess is by design: one precomputed "
-               "table row per digit position is gathered (~14.7 x 128 B per term with bit-position tables, 16 x 128 B with window tables) so that all digits "
+               "table row per digit position is gathered (~12.1 x 128 B per term with bit-position tables and 2^19 buckets, 14.7 with 2^15 buckets, 16 x 128 B with window tables) so that all digits "
                "share one bucket set; the kernel is integer-VALU bound, not HBM bound.")
     import json
     valu = None
