@@ -157,6 +157,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
     (void)hipFree(t->w512); (void)hipFree(t->g_lo); (void)hipFree(t->g_hi);
     (void)hipFree(t->tw_lo29); (void)hipFree(t->tw_hi29); (void)hipFree(t->tw_lo_scaled29);
     (void)hipFree(t->w512_29); (void)hipFree(t->g_lo29); (void)hipFree(t->g_hi29);
+    (void)hipFree(t->tw_a29); (void)hipFree(t->tw_b29);
     delete t;
   }
   (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_buf2); (void)hipFree(c.ntt_buf3); (void)hipFree(c.ntt_tmp);

@@ -33,6 +33,8 @@
 // checked against the oracle on CPU.
 #include "plonk_internal.hpp"
 #include "fr29.cuh"
+#include <type_traits>
+#include <utility>
 
 namespace plonk {
 
@@ -40,6 +42,7 @@ static constexpr int TILE_LOG = 11;
 static constexpr int NTT_THREADS = 256;
 static constexpr int TWLO_BITS = 13;
 static constexpr int GLO_BITS = 10;
+static constexpr int NTT_DIRECT_MAX_LOG = 25;
 
 struct NttPass {
   const Fr* src;
@@ -55,6 +58,9 @@ struct NttPass {
   uint32_t tw_shr;
   const Fr29Slot* tw_lo;
   const Fr29Slot* tw_hi;
+  // when set: the twiddle is read whole from tw_direct[e >> tw_shr] (pass A: w_N^e for every e < N; pass B: the N / R1
+  // multiples of R1 that its exponents can take) instead of the two-level product — one Fr product less per element
+  const Fr29Slot* tw_direct;
   // first pass: zero beyond in_len, optional coset scale g^i
   uint64_t in_len;
   int pre_coset;
@@ -192,6 +198,15 @@ __device__ __forceinline__ Fr29 two_level(const Fr29Slot* lo, const Fr29Slot* hi
   if (use_hi) w = Fr29::mul(w, ld_tw(hi + (e >> lobits)));
   return w;
 }
+// compile-time loop over the 8 elements of a lane: f(std::integral_constant<int, e>) for e = 0 .. 7
+template <typename F, int... Is>
+__device__ __forceinline__ void for_e8_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <typename F>
+__device__ __forceinline__ void for_e8(F&& f) {
+  for_e8_impl(static_cast<F&&>(f), std::make_integer_sequence<int, 8>{});
+}
 
 template <int RLOG, bool TRANSPOSE>
 __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
@@ -204,64 +219,104 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
   const int t = threadIdx.x;
   const uint64_t cg0 = (uint64_t)blockIdx.x * C;
 
-  // ---- load round 0 operands straight from HBM
+  // ---- load round 0 operands straight from HBM.  All eight loads of a lane are issued back to back in one branch-free
+  // block (index clamped to 0 beyond in_len, the value masked to zero afterwards): with a branch per element the
+  // compiler waited for each load before issuing the next — eight exposed HBM latencies per wave at two waves per SIMD
+  // (r03e: the passes ran at 5.7-6.4 cycles per VALU instruction against 4.7 in msm_accumulate).
+  // for_e8 is a compile-time loop: `#pragma unroll` gives up on bodies of this size (a Montgomery product is ~600
+  // instructions) and a rolled loop would index the arrays in scratch memory.
   using G0 = RoundGeom<RLOG, 0>;
   Fr29 v[8];
+  {
+    Fr raw[8];
+    uint64_t gis[8];
+    for_e8([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      const int idx = elem_index<G0::POS, G0::RB>(t, e);
+      const uint64_t row = idx >> CLOG;
+      const uint64_t cg = cg0 + (idx & (C - 1));
+      gis[e] = row * p.in_rs + (cg >> p.in_hshift) * p.in_hs + (cg & ((1ull << p.in_hshift) - 1));
+      raw[e] = ld_fr(p.src + (gis[e] < p.in_len ? gis[e] : 0));   // in_len >= 1 (ntt_device)
+    });
+    for_e8([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      const uint32_t keep = gis[e] < p.in_len ? 0xffffffffu : 0u;
+      const Fr29 x = Fr29::from_fr(raw[e]);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int idx = elem_index<G0::POS, G0::RB>(t, e);
-    const uint64_t row = idx >> CLOG;
-    const uint64_t cg = cg0 + (idx & (C - 1));
-    const uint64_t gi = row * p.in_rs + (cg >> p.in_hshift) * p.in_hs + (cg & ((1ull << p.in_hshift) - 1));
-    if (gi < p.in_len) {
-      Fr29 x = Fr29::from_fr(ld_fr(p.src + gi));
-      if (p.pre_coset) x = Fr29::mul(x, two_level(p.g_lo, p.g_hi, gi, GLO_BITS, true));
-      v[e] = x;
-    } else {
-      v[e] = Fr29::zero();
+      for (int l = 0; l < Fr29::N; ++l) v[e].l[l] = x.l[l] & keep;
+    });
+    if (p.pre_coset) {   // coset scale g^i of the valid coefficients (n + 3 of 4n in the prover: whole rows are skipped)
+      for_e8([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        if (gis[e] < p.in_len) v[e] = Fr29::mul(v[e], two_level(p.g_lo, p.g_hi, gis[e], GLO_BITS, true));
+      });
     }
   }
   Rounds<RLOG, 0, NR>::run(v, t, data, wtab);
 
-  // ---- epilogue: inter-pass twiddle / scaling, then store
+  // ---- epilogue: inter-pass twiddle / scaling, then store.  The pass-wide modes are tested OUTSIDE the element loops so
+  // that each loop is one basic block: the eight twiddle loads (HBM gathers with the direct table of pass A) go out
+  // together and the multiplications follow.
   using GL = RoundGeom<RLOG, NR - 1>;
   const uint64_t nmask = (1ull << p.logN) - 1;
   const bool use_hi = p.logN > TWLO_BITS;
-  if constexpr (!TRANSPOSE) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = elem_index<GL::POS, GL::RB>(t, e);
-      const uint32_t prow = idx >> CLOG;
-      const uint64_t k = __brev(prow) >> (32 - RLOG);
-      const uint64_t cg = cg0 + (idx & (C - 1));
-      Fr29 x = v[e];
-      if (p.tw_mode) {
-        const uint64_t twcol = (cg >> p.tw_shr) << p.tw_shr;
-        x = Fr29::mul(x, two_level(p.tw_lo, p.tw_hi, (k * twcol) & nmask, TWLO_BITS, use_hi));
-      }
-      const uint64_t o = k * p.out_rs + (cg >> p.out_hshift) * p.out_hs +
-                         (cg & ((1ull << p.out_hshift) - 1)) * p.out_ls;
-      if (p.post_mode == 1) x = Fr29::mul(x, p.scale);
-      else if (p.post_mode == 2) x = Fr29::mul(x, two_level(p.g_lo, p.g_hi, o, GLO_BITS, true));
-      st_fr(p.dst + o, x.to_fr());
+  uint32_t ks[8];
+  uint64_t cgs[8];
+  for_e8([&](auto ec) __attribute__((always_inline)) {
+    constexpr int e = decltype(ec)::value;
+    const int idx = elem_index<GL::POS, GL::RB>(t, e);
+    const uint32_t prow = idx >> CLOG;
+    ks[e] = __brev(prow) >> (32 - RLOG);
+    cgs[e] = cg0 + (idx & (C - 1));
+  });
+  if (p.tw_mode) {
+    if (p.tw_direct) {
+      Fr29 tw[8];
+      for_e8([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        const uint64_t twcol = (cgs[e] >> p.tw_shr) << p.tw_shr;
+        tw[e] = ld_tw(p.tw_direct + ((((uint64_t)ks[e] * twcol) & nmask) >> p.tw_shr));   // tests/ntt_model.py: direct_index
+      });
+      for_e8([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        v[e] = Fr29::mul(v[e], tw[e]);
+      });
+    } else {
+      for_e8([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        const uint64_t twcol = (cgs[e] >> p.tw_shr) << p.tw_shr;
+        v[e] = Fr29::mul(v[e], two_level(p.tw_lo, p.tw_hi, ((uint64_t)ks[e] * twcol) & nmask, TWLO_BITS, use_hi));
+      });
     }
+  }
+  if constexpr (!TRANSPOSE) {
+    uint64_t os[8];
+    for_e8([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      os[e] = (uint64_t)ks[e] * p.out_rs + (cgs[e] >> p.out_hshift) * p.out_hs + (cgs[e] & ((1ull << p.out_hshift) - 1)) * p.out_ls;
+    });
+    if (p.post_mode == 1) {
+      for_e8([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        v[e] = Fr29::mul(v[e], p.scale);
+      });
+    } else if (p.post_mode == 2) {
+      for_e8([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        v[e] = Fr29::mul(v[e], two_level(p.g_lo, p.g_hi, os[e], GLO_BITS, true));
+      });
+    }
+    for_e8([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      st_fr(p.dst + os[e], v[e].to_fr());
+    });
   } else {
     constexpr int R = 1 << RLOG;
     __syncthreads();   // everyone finished reading `data` for the last round
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int idx = elem_index<GL::POS, GL::RB>(t, e);
-      const uint32_t prow = idx >> CLOG;
-      const uint32_t k = __brev(prow) >> (32 - RLOG);
-      const int col = idx & (C - 1);
-      const uint64_t cg = cg0 + col;
-      Fr29 x = v[e];
-      if (p.tw_mode) {
-        const uint64_t twcol = (cg >> p.tw_shr) << p.tw_shr;
-        x = Fr29::mul(x, two_level(p.tw_lo, p.tw_hi, ((uint64_t)k * twcol) & nmask, TWLO_BITS, use_hi));
-      }
-      lds_put(data, 1 << TILE_LOG, col * R + (int)k, x);
-    }
+    for_e8([&](auto ec) __attribute__((always_inline)) {
+      constexpr int e = decltype(ec)::value;
+      lds_put(data, 1 << TILE_LOG, (int)(cgs[e] - cg0) * R + (int)ks[e], v[e]);
+    });
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -421,6 +476,28 @@ int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
   if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->w512_29, host_omega(9, inverse), Fr::one(), 256))) return rc;
   if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->g_lo29, g, Fr::one(), 1u << GLO_BITS))) return rc;
   if ((rc = build_pow_table29(c, (Fr29Slot**)&tb->g_hi29, g.pow_u64(1ull << GLO_BITS), Fr::one(), ghi_n))) return rc;
+  // Direct inter-pass twiddles (one Fr product less per element in passes A and B, ~15 % of a transform's multiplications):
+  // N + N / R1 slots of 48 B — 0.2 GB at 2^22, 0.8 GB at 2^24 per direction.  PLONK_NTT_DIRECT=0 keeps the two-level tables
+  // (A/B runs); above 2^NTT_DIRECT_MAX_LOG, or when the tables would take more than 1/8 of the free memory, likewise.
+  static const bool direct_on = [] { const char* e = getenv("PLONK_NTT_DIRECT"); return !(e && e[0] == '0'); }();
+  if (direct_on && L > 10 && L <= (uint32_t)NTT_DIRECT_MAX_LOG) {
+    int r[3], np;
+    ntt_plan(L, r, &np);
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const uint64_t N = 1ull << L;
+    if ((N + (N >> r[0])) * sizeof(Fr29Slot) <= free_b / 8) {
+      // optional: on any failure the passes keep the two-level product
+      if (build_pow_table29(c, (Fr29Slot**)&tb->tw_a29, w, inverse ? n_inv : Fr::one(), (uint32_t)N) != PLONK_OK) {
+        (void)hipGetLastError();
+        tb->tw_a29 = nullptr;
+      }
+      if (np == 3 && build_pow_table29(c, (Fr29Slot**)&tb->tw_b29, w.pow_u64(1ull << r[0]), Fr::one(), (uint32_t)(N >> r[0])) != PLONK_OK) {
+        (void)hipGetLastError();
+        tb->tw_b29 = nullptr;
+      }
+    }
+  }
   tb->n_inv = n_inv;
   c->ntt_tables[key] = tb;
   *out = tb;
@@ -460,6 +537,10 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
   if (L >= 28) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // 3 passes of <= 2^9; reference limit is 2^32 (domain.rs:132)
   const uint64_t N = 1ull << L;
   if (in_len > N) in_len = N;          // Vec::resize truncation, domain.rs:174
+  if (in_len == 0) {                   // transform of the zero vector (every variant is linear); the pass kernels read src[0]
+    HIP_TRY(hipMemsetAsync(dst, 0, sizeof(Fr) * N, c->stream));
+    return PLONK_OK;
+  }
   NttTables* tb;
   int rc = ntt_tables(c, L, inverse, &tb);
   if (rc) return rc;
@@ -492,6 +573,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.tw_mode = 1; p.tw_shr = 0;
     p.tw_lo = (const Fr29Slot*)(inverse ? tb->tw_lo_scaled29 : tb->tw_lo29);   // n^-1 folded into pass A's twiddles
     p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
+    p.tw_direct = (const Fr29Slot*)tb->tw_a29;
     p.in_len = in_len; p.pre_coset = (coset && !inverse) ? 1 : 0;
     p.post_mode = 0; p.g_lo = g_lo29; p.g_hi = g_hi29;
     p.w512 = (const Fr29Slot*)tb->w512_29;
@@ -506,6 +588,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.out_rs = R1; p.out_hshift = (uint32_t)r[0]; p.out_hs = R1 << r[1]; p.out_ls = 1;
     p.tw_mode = 1; p.tw_shr = (uint32_t)r[0];
     p.tw_lo = (const Fr29Slot*)tb->tw_lo29; p.tw_hi = (const Fr29Slot*)tb->tw_hi29;
+    p.tw_direct = (const Fr29Slot*)tb->tw_b29;
     p.in_len = N; p.pre_coset = 0; p.post_mode = 0; p.w512 = (const Fr29Slot*)tb->w512_29;
     p.g_lo = g_lo29; p.g_hi = g_hi29;
     const uint32_t nb = (uint32_t)((N >> r[1]) >> (TILE_LOG - r[1]));

@@ -39,6 +39,10 @@ struct NttTables {
   void* w512_29 = nullptr;
   void* g_lo29 = nullptr;
   void* g_hi29 = nullptr;
+  // whole inter-pass twiddle tables of the multi-pass plans (ntt.hip: NttPass::tw_direct), built for L <= NTT_DIRECT_MAX_LOG
+  // when memory allows: pass A  first * w_N^e, e < N (first = n^-1 for the inverse);  pass B  w_N^(R1 j), j < N / R1
+  void* tw_a29 = nullptr;
+  void* tw_b29 = nullptr;
   Fr n_inv;
 };
 

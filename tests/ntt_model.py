@@ -89,8 +89,16 @@ def tile_dif(vals, RLOG, w512):
     return lds
 
 
-def ntt_model(a, L, inverse=False, coset=False, in_len=None, radices=None):
-    """Full transform as the GPU executes it (natural in, natural out)."""
+def direct_index(e, tw_shr):
+    """ntt.hip pass_twiddle: slot of w_N^e in a pass's direct table (pass A: tw_shr = 0, every e; pass B: the table
+    holds the multiples of R1 = 2^tw_shr only, and e must be one of them)."""
+    assert e & ((1 << tw_shr) - 1) == 0
+    return e >> tw_shr
+
+
+def ntt_model(a, L, inverse=False, coset=False, in_len=None, radices=None, direct=True):
+    """Full transform as the GPU executes it (natural in, natural out).  direct: inter-pass twiddles read from the
+    whole tables tw_a (w^e, e < N) / tw_b (w^(R1 j), j < N / R1) through direct_index, else computed from the exponent."""
     N = 1 << L
     in_len = N if in_len is None else in_len
     w = omega(L, inverse)
@@ -125,6 +133,13 @@ def ntt_model(a, L, inverse=False, coset=False, in_len=None, radices=None):
         S = N >> r1
         CLOG = TILE_LOG - r1
         C = 1 << CLOG
+        tw_a = tw_b = None
+        if direct:
+            tw_a = [1] * N
+            for e in range(1, N):
+                tw_a[e] = tw_a[e - 1] * w % Q
+            if P == 3:
+                tw_b = tw_a[::R1]                     # w^(R1 j), j < N / R1
         dst = [None] * N
         for blk in range(S // C):
             cg0 = blk * C
@@ -134,7 +149,8 @@ def ntt_model(a, L, inverse=False, coset=False, in_len=None, radices=None):
                 p, col = idx >> CLOG, idx & (C - 1)
                 k = bitrev(p, r1)
                 cg = cg0 + col
-                val = tile[idx] * pow(w, (k * cg) & (N - 1), Q) % Q
+                ex = (k * cg) & (N - 1)
+                val = tile[idx] * (tw_a[direct_index(ex, 0)] if direct else pow(w, ex, Q)) % Q
                 lo_, hi_ = cg & (R3 - 1), cg >> r3
                 dst[lo_ * (N >> r3) + hi_ * R1 + k] = val
         buf = dst
@@ -156,7 +172,8 @@ def ntt_model(a, L, inverse=False, coset=False, in_len=None, radices=None):
                     k = bitrev(p, r2)
                     cg = cg0 + col
                     twcol = (cg >> r1) << r1
-                    val = tile[idx] * pow(w, (k * twcol) & (N - 1), Q) % Q
+                    ex = (k * twcol) & (N - 1)
+                    val = tile[idx] * (tw_b[direct_index(ex, r1)] if direct else pow(w, ex, Q)) % Q
                     nxt[addr(k, cg)] = val
             buf = nxt
         # ---- pass C: rows (stride N / R3), cols contiguous, no twiddle

@@ -194,3 +194,26 @@ def test_concurrent_callers_share_one_context(ctx):
     assert got == expected
     d = EvaluationDomain(1 << jobs[0][0])
     assert expected[0][0] == d.fft(jobs[0][1])
+
+
+@pytest.mark.parametrize("L", [5, 12, 19])
+def test_empty_input_is_the_zero_polynomial(ctx, L):
+    """Vec::resize pads an empty coefficient vector with zeros (domain.rs:174): every variant returns zeros (ntt.hip
+    answers in_len == 0 with a memset, the pass kernels always read element 0)."""
+    z = [0] * (1 << L)
+    assert ctx.ntt([], L) == z
+    assert ctx.ntt([], L, coset=True) == z
+
+
+def test_two_level_twiddle_fallback_matches_the_oracle():
+    """PLONK_NTT_DIRECT=0: the inter-pass twiddles as TWLO x TWHI products (the path taken above 2^25 or when memory is
+    short) — the same transforms, in a child process because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_ntt.py", "-x", "-q", "-m", "gpu", "-k",
+                        "two_pass or three_pass or batch_of_five"], cwd=root, env=dict(os.environ, PLONK_NTT_DIRECT="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
