@@ -320,17 +320,21 @@ int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
  *   PLONK_PP_RAW_UNCHECKED  PublicParameters::from_slice_unchecked (srs.rs:131-146): the commit-key points are trusted; like
  *                           CommitKey::from_slice_unchecked (key.rs:243-258) it takes min(count, whole 97-byte chunks present) points;
  *   PLONK_PP_RAW            CommitKey::from_raw_var_bytes (key.rs:263-300): count != 0 (PLONK_ERR_DATA), exact length
- *                           (PLONK_ERR_BYTES), every kept point is_on_curve & is_torsion_free (PLONK_ERR_POINT; on the GPU);
+ *                           (PLONK_ERR_BYTES), EVERY point of the file is_on_curve & is_torsion_free (PLONK_ERR_POINT; on the
+ *                           GPU) — also the ones a trim drops afterwards, as in the reference;
  *   PLONK_PP_COMPRESSED     PublicParameters::from_slice (srs.rs:164-178) = one G1Affine::from_slice per 48-byte chunk
  *                           (key.rs:319-326): compression flag, x < p, x^3 + 4 a square, torsion-free — any failure, a short
- *                           last chunk included, is a dusk_bytes error (PLONK_ERR_DATA).  Decompression (one square root per
- *                           point, g1codec.cuh) and the subgroup test run on the GPU.
- *   All modes: the opening key's g must be a valid compressed G1 point (PLONK_ERR_DATA, OpeningKey::from_slice); h and x_h are
- *   G2 points — the prover never touches them, they are checked for the compression flag only and handed back as bytes.
+ *                           last chunk included, is a dusk_bytes error (PLONK_ERR_DATA), wherever in the file.  Decompression
+ *                           (one square root per point, g1codec.cuh) and the subgroup test run on the GPU.
+ *   All modes: OpeningKey::from_slice (key.rs:455-490) in full — g a valid compressed G1 point, h and x_h valid compressed G2
+ *   points (flags, canonical coordinates, on the twist curve, of order q; hostg2.hpp, on the host) — PLONK_ERR_DATA otherwise.
+ *   The prover never uses them; they are handed back as the 240 bytes they came as.
  *   truncated_degree > 0: PublicParameters::trim (srs.rs:188-196) = CommitKey::truncate(truncated_degree + 6)
- *   (key.rs:336-355): PLONK_ERR_DEGREE when the key is shorter (Error::TruncatedDegreeTooLarge); 0 keeps every point; points
- *   beyond the trim are never decoded.  An identity among the kept points is refused (PLONK_ERR_POINT): a commit key never
- *   holds one and the window tables cannot represent it.  At most 240 bytes: PLONK_ERR_BYTES (Error::NotEnoughBytes, srs.rs:165-167).
+ *   (key.rs:336-355): PLONK_ERR_DEGREE when the key is shorter (Error::TruncatedDegreeTooLarge); 0 keeps every point.  The
+ *   unchecked mode never reads beyond the trim.  At most 240 bytes: PLONK_ERR_BYTES (Error::NotEnoughBytes, srs.rs:165-167).
+ *   ONE deliberate divergence: an identity point in the commit key (flag byte 1 / the 0xC0 encoding) is refused with
+ *   PLONK_ERR_POINT in every mode, although G1Affine::from_bytes and is_on_curve & is_torsion_free accept it: no SRS
+ *   [tau^i] G holds one and the precomputed table rows cannot represent it (tests/test_public_parameters.py names this case).
  * plonk_public_parameters_check is the host-side part (no GPU): structure, opening key, trim, flags and coordinate ranges.
  * plonk_srs_load_public_parameters = check + the per-point work on the GPU + window tables of the kept points. */
 enum { PLONK_PP_RAW_UNCHECKED = 0, PLONK_PP_RAW = 1, PLONK_PP_COMPRESSED = 2 };

@@ -26,7 +26,7 @@
 
 #include "../../include/plonk_hip.h"
 #include "plonk_internal.hpp"
-#include "hostg1.hpp"
+#include "hostg2.hpp"
 #include "g1codec.cuh"
 
 namespace plonk {
@@ -244,8 +244,9 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
   if (len <= OPENING_KEY_BYTES) FAIL(PLONK_ERR_BYTES, "public parameters shorter than an opening key");   // srs.rs:165-167
   // OpeningKey::from_slice (key.rs:455-490): three compressed points; g is checked like every G1 encoding
   if (!g1_compressed_valid(bytes)) FAIL(PLONK_ERR_DATA, "opening key: g is not a valid compressed G1 point");
-  for (uint64_t off : {(uint64_t)48, (uint64_t)144})
-    if (!(bytes[off] & 0x80)) FAIL(PLONK_ERR_DATA, "opening key: G2 point without the compression flag");
+  // h and x_h: G2Affine::from_bytes in full (flags, canonical coordinates, on the twist curve, order q) — hostg2.hpp
+  if (!g2_compressed_valid(bytes + 48)) FAIL(PLONK_ERR_DATA, "opening key: h is not a valid compressed G2 point");
+  if (!g2_compressed_valid(bytes + 144)) FAIL(PLONK_ERR_DATA, "opening key: x_h is not a valid compressed G2 point");
   info->opening_key_off = 0;
   const uint8_t* ck = bytes + OPENING_KEY_BYTES;
   const uint64_t ck_len = len - OPENING_KEY_BYTES;
@@ -279,7 +280,11 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
     keep = d + 1;
   }
   info->points_kept = keep;
-  for (uint64_t i = 0; i < keep; ++i) {
+  // The validating decoders look at EVERY point of the file before trim() drops the tail (key.rs:263-300, :319-326): a bad
+  // point beyond the kept prefix refuses the file there, so it does here.  from_slice_unchecked looks at none; the kept
+  // prefix is still scanned for identities (which no table row can hold — see plonk_hip.h, a documented divergence).
+  const uint64_t scan = mode == PLONK_PP_RAW_UNCHECKED ? keep : npts;
+  for (uint64_t i = 0; i < scan; ++i) {
     const uint8_t* r = bytes + info->points_off + info->point_stride * i;
     if (mode == PLONK_PP_COMPRESSED) {   // the flag and range half of G1Affine::from_bytes; the square root is the GPU's
       if (!(r[0] & 0x80)) FAIL(PLONK_ERR_DATA, "commit key point without the compression flag");
@@ -350,7 +355,7 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
     uint8_t* in = nullptr;
     G1Affine* pts = nullptr;
     int* flag = nullptr;
-    const uint64_t n = info.points_kept;
+    const uint64_t n = info.points_total;   // every chunk is decoded and tested, the kept prefix is loaded
     hipError_t e = hipMalloc((void**)&in, COMPRESSED_POINT * n);
     if (e == hipSuccess) e = hipMalloc((void**)&pts, sizeof(G1Affine) * n);
     if (e == hipSuccess) e = hipMalloc((void**)&flag, 2 * sizeof(int));
@@ -375,7 +380,7 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
       set_last_error("InvalidData", "commit key point outside the prime-order subgroup", __FILE__, __LINE__);
       rc = PLONK_ERR_DATA;
     }
-    if (rc == PLONK_OK) rc = srs_load_device(&c, pts, n);
+    if (rc == PLONK_OK) rc = srs_load_device(&c, pts, info.points_kept);
     (void)hipStreamSynchronize(c.stream);
     (void)hipFree(in);
     (void)hipFree(pts);
@@ -383,11 +388,13 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
     if (e != hipSuccess) set_last_error("plonk_srs_load_public_parameters", hipGetErrorString(e), __FILE__, __LINE__);
     if (rc) return rc;
   } else {
-    // 97-byte raw points -> x || y; the trimmed prefix only (the rest of the file is never touched)
-    std::vector<uint8_t> xy((size_t)info.points_kept * 96);
-    for (uint64_t i = 0; i < info.points_kept; ++i) memcpy(&xy[96 * i], bytes + info.points_off + RAW_POINT * i, 96);
-    if (mode == PLONK_PP_RAW) {   // is_on_curve & is_torsion_free for every point, on the GPU (key.rs:287-293)
-      rc = plonk_srs_validate(ctx, xy.data(), info.points_kept);
+    // 97-byte raw points -> x || y.  PLONK_PP_RAW: is_on_curve & is_torsion_free for every point OF THE FILE, on the GPU
+    // (key.rs:287-293), then the trimmed prefix is loaded; unchecked: the prefix only, the rest is never touched.
+    const uint64_t nval = mode == PLONK_PP_RAW ? info.points_total : info.points_kept;
+    std::vector<uint8_t> xy((size_t)nval * 96);
+    for (uint64_t i = 0; i < nval; ++i) memcpy(&xy[96 * i], bytes + info.points_off + RAW_POINT * i, 96);
+    if (mode == PLONK_PP_RAW) {
+      rc = plonk_srs_validate(ctx, xy.data(), nval);
       if (rc) return rc;
     }
     rc = plonk_srs_load(ctx, xy.data(), info.points_kept);

@@ -262,3 +262,8 @@ extern "C" void h_fr_inv_gcd(const uint32_t* a, uint32_t* o) {
   Fr r = Fr29::mul(inv_t, Fr29::from_fr(Fr::one())).to_fr();              // * R / 2^261 = x^-1 R
   memcpy(o, &r, 32);
 }
+
+// ---- hostg2.hpp: validity of a compressed G2 encoding (OpeningKey::from_slice's test of h and x_h) ----
+#include "../../plonk_amd/csrc/hostg2.hpp"
+extern "C" int h_g2_compressed_valid(const uint8_t in[96]) { return plonk::g2_compressed_valid(in) ? 1 : 0; }
+extern "C" int h_g1_compressed_valid(const uint8_t in[48]) { return plonk::g1_compressed_valid(in) ? 1 : 0; }

@@ -20,7 +20,7 @@ def build_host_lib():
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
     hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
             for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp", "g1codec.cuh",
-                      "msm_recode.cuh", "fp_safegcd.cuh")]
+                      "msm_recode.cuh", "fp_safegcd.cuh", "hostg2.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -358,3 +358,77 @@ def test_safegcd_inverse_in_fr_matches_the_oracle(lib):
     for a in edge_values(Q, rnd, 200) + [Q - (1 << 30), (Q + 1) // 2, 7, pow(7, (Q - 1) >> 32, Q)]:
         lib.h_fr_inv_gcd(fr_limbs(a), out)
         assert fr_val(out) == (pow(a, -1, Q) if a else 0), hex(a)
+
+
+def test_g2_reference_generator_is_the_standard_one():
+    """tests/g2_ref.py (the checker of the next test): generator on E'(Fp2), of order q, and its well-known encoding"""
+    import g2_ref as G
+    from oracle.bls12_381 import Q as ORDER
+    assert G.on_curve(G.G2_GEN) and G.g2_mul(G.G2_GEN, ORDER) is None
+    assert G.g2_compress(G.G2_GEN).hex().startswith("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049")
+    assert G.g2_decompress(G.g2_compress(G.G2_GEN)) == G.G2_GEN
+
+
+def test_g2_compressed_validity_matches_the_reference_decoder(lib):
+    """hostg2.hpp g2_compressed_valid == "G2Affine::from_bytes succeeds" (key.rs:455-490 through dusk-bls12_381): multiples of
+    the generator with either sign flag, the identity, and every way an encoding can be wrong — flag bits, a non-canonical
+    coordinate, x off the curve, a curve point outside the order-q subgroup."""
+    import g2_ref as G
+    r = random.Random(77)
+
+    def valid(b):
+        return bool(lib.h_g2_compressed_valid(bytes(b)))
+
+    def ref(b):
+        try:
+            G.g2_decompress(bytes(b))
+            return True
+        except ValueError:
+            return False
+
+    good = [G.g2_compress(G.g2_mul(G.G2_GEN, k)) for k in (1, 2, 3, r.randrange(1, 1 << 255), r.randrange(1, 1 << 255))]
+    for enc in good:
+        assert ref(enc) and valid(enc)
+        flipped = bytearray(enc)
+        flipped[0] ^= 0x20                                     # the other root: still a point of the subgroup
+        assert ref(flipped) and valid(flipped)
+        no_flag = bytearray(enc)
+        no_flag[0] &= 0x7F
+        assert not valid(no_flag)
+        inf_flag = bytearray(enc)
+        inf_flag[0] |= 0x40                                    # infinity flag on a finite x
+        assert not ref(inf_flag) and not valid(inf_flag)
+    identity = bytes([0xC0]) + bytes(95)
+    assert ref(identity) and valid(identity)
+    assert not valid(bytes([0xE0]) + bytes(95))               # identity with the sign flag
+    assert not valid(bytes([0xC0]) + bytes(94) + b"\x01")     # identity with a stray bit
+    # non-canonical: c0 = p (zero + p), c1 = p + small
+    from oracle.bls12_381 import P as MODP
+    enc = bytearray(good[0])
+    enc[48:] = MODP.to_bytes(48, "big")
+    assert not ref(enc) and not valid(enc)
+    # x values by trial: off the curve, and on the curve but outside the subgroup (cofactor of E'(Fp2) is huge)
+    seen_off = seen_outside = 0
+    x1 = 1
+    while seen_off < 3 or seen_outside < 3:
+        x1 += 1
+        x = (r.randrange(MODP), x1)
+        b = bytearray(x[1].to_bytes(48, "big") + x[0].to_bytes(48, "big"))
+        b[0] |= 0x80
+        y = G.f2_sqrt(G.f2_add(G.f2_mul(G.f2_sqr(x), x), G.B2))
+        if y is None:
+            seen_off += 1
+            assert not valid(b)
+        else:
+            assert G.g2_mul((x, y), 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001) is not None
+            seen_outside += 1
+            assert not ref(b) and not valid(b)
+
+
+def test_g1_compressed_validity_on_host(lib):
+    from oracle import bls12_381 as E
+    assert lib.h_g1_compressed_valid(E.g1_compress(E.G1_GEN)) == 1
+    assert lib.h_g1_compressed_valid(bytes([0xC0]) + bytes(47)) == 1
+    bad = bytearray(E.g1_compress(E.G1_GEN))
+    bad[0] &= 0x7F
+    assert lib.h_g1_compressed_valid(bytes(bad)) == 0

@@ -13,9 +13,10 @@ from oracle.serialize import public_parameters_to_raw_var_bytes, public_paramete
 
 
 def opening_key_bytes():
-    # g = the G1 generator (compressed); h, x_h: 96-byte compressed G2 encodings — only their flag bit is looked at
-    g2 = bytes([0x80 | 0x13]) + bytes(range(1, 96))
-    return E.g1_compress(E.G1_GEN) + g2 + g2
+    # OpeningKey::to_bytes (key.rs:436-452): g (G1 generator), h (G2 generator), x_h = [x] h — real points: the loader decodes
+    # all three like OpeningKey::from_slice (tests/g2_ref.py is the Python G2 used to make them)
+    import g2_ref
+    return E.g1_compress(E.G1_GEN) + g2_ref.g2_compress(g2_ref.G2_GEN) + g2_ref.g2_compress(g2_ref.g2_mul(g2_ref.G2_GEN, 0x1234567))
 
 
 @pytest.fixture(scope="module")
@@ -82,6 +83,33 @@ def test_invalid_data(pp):
         plonk_amd.public_parameters_check(bad_h)
 
 
+def test_opening_key_g2_points_are_decoded_like_the_reference(pp):
+    """OpeningKey::from_slice (key.rs:455-490) runs G2Affine::from_bytes on h and x_h: an encoding the reference refuses is
+    refused here (they used to be checked for the compression flag only)."""
+    import g2_ref
+    data, _ = pp
+    for off in (48, 144):                                                        # h, x_h
+        enc = data[off:off + 96]
+        assert g2_ref.g2_decompress(enc) is not None
+        # x + 1 in c0: off the twist curve or outside the order-q subgroup — invalid either way
+        bumped = bytearray(enc)
+        bumped[95] ^= 1
+        with pytest.raises(ValueError):
+            g2_ref.g2_decompress(bytes(bumped))
+        with pytest.raises(plonk_amd.InvalidData):
+            plonk_amd.public_parameters_check(data[:off] + bytes(bumped) + data[off + 96:])
+        # non-canonical coordinate (c0 = p)
+        noncanon = enc[:48] + E.P.to_bytes(48, "big")
+        with pytest.raises(plonk_amd.InvalidData):
+            plonk_amd.public_parameters_check(data[:off] + noncanon + data[off + 96:])
+        # the other root is the negated point: still a valid key
+        neg = bytes([enc[0] ^ 0x20]) + enc[1:]
+        assert plonk_amd.public_parameters_check(data[:off] + neg + data[off + 96:])["points_total"] == 23
+        # the identity decodes (G2Affine::from_bytes accepts it)
+        ident = bytes([0xC0]) + bytes(95)
+        assert plonk_amd.public_parameters_check(data[:off] + ident + data[off + 96:])["points_total"] == 23
+
+
 def test_point_malformed(pp):
     data, _ = pp
     inf = bytearray(data)
@@ -92,10 +120,29 @@ def test_point_malformed(pp):
     big[248 + 97 * 5 + 47] = 0xFF                                                # x limb 11 >= p's: not reduced
     with pytest.raises(plonk_amd.PointMalformed):
         plonk_amd.public_parameters_check(bytes(big))
-    # a point beyond the trim is never looked at
+    # CommitKey::from_raw_var_bytes tests every point BEFORE the trim (key.rs:263-300, srs.rs:188-196): a bad point beyond
+    # the kept prefix refuses the file; from_slice_unchecked never looks there
     far = bytearray(data)
-    far[248 + 97 * 20 + 96] = 1
-    assert plonk_amd.public_parameters_check(bytes(far), truncated_degree=8)["points_kept"] == 15
+    far[248 + 97 * 20 + 47] = 0xFF
+    with pytest.raises(plonk_amd.PointMalformed):
+        plonk_amd.public_parameters_check(bytes(far), truncated_degree=8)
+    assert plonk_amd.public_parameters_check(bytes(far), truncated_degree=8, validate=False)["points_kept"] == 15
+
+
+def test_divergence_identity_in_the_commit_key_is_refused(pp):
+    """DIVERGENCE from the reference, on purpose (include/plonk_hip.h): G1Affine::from_bytes and is_on_curve & is_torsion_free
+    accept the identity, so dusk-plonk loads a commit key holding one; this library answers PLONK_ERR_POINT in every mode —
+    no SRS [tau^i] G contains the identity and the precomputed table rows cannot represent it."""
+    data, ck = pp
+    raw = bytearray(data)
+    raw[248 + 97 * 3:248 + 97 * 4] = bytes(96) + b"\x01"
+    for validate in (True, False):
+        with pytest.raises(plonk_amd.PointMalformed):
+            plonk_amd.public_parameters_check(bytes(raw), validate=validate)
+    comp = public_parameters_to_var_bytes(opening_key_bytes(), ck)
+    comp = comp[:240 + 48 * 3] + bytes([0xC0]) + bytes(47) + comp[240 + 48 * 4:]
+    with pytest.raises(plonk_amd.PointMalformed):
+        plonk_amd.public_parameters_check(comp, compressed=True)
 
 
 def test_compressed_form_layout_and_host_side_refusals(pp):
@@ -172,4 +219,27 @@ def test_loaded_key_commits_like_the_points_loaded_directly(pp):
     bad[248 + 97 * 2 + 48] ^= 1                                                  # y of point 2
     with pytest.raises(plonk_amd.PointMalformed):
         ctx.srs_load_public_parameters(bytes(bad))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_validated_modes_test_every_point_of_the_file_before_the_trim(pp):
+    """key.rs:263-300 / :319-326 decode and test the whole commit key, PublicParameters::trim cuts afterwards: a point off the
+    curve BEYOND the kept prefix refuses the file in the validating modes (only the prefix used to be tested) and
+    is never seen by from_slice_unchecked."""
+    data, ck = pp
+    ctx = plonk_amd.Context(0)
+    bad = bytearray(data)
+    bad[248 + 97 * 20 + 48] ^= 1                                                 # y of point 20; trim(8) keeps 15 points
+    with pytest.raises(plonk_amd.PointMalformed):
+        ctx.srs_load_public_parameters(bytes(bad), truncated_degree=8)
+    ctx.srs_load_public_parameters(bytes(bad), truncated_degree=8, validate=False)
+    assert ctx.srs_points == 15
+    comp = public_parameters_to_var_bytes(opening_key_bytes(), ck)
+    x = next(v for v in range(2, 50) if pow((v ** 3 + 4) % E.P, (E.P - 1) // 2, E.P) != 1)
+    badc = comp[:240 + 48 * 20] + bytes([0x80]) + x.to_bytes(47, "big") + comp[240 + 48 * 21:]
+    with pytest.raises(plonk_amd.InvalidData):
+        ctx.srs_load_public_parameters(badc, truncated_degree=8, compressed=True)
+    ctx.srs_load_public_parameters(comp, truncated_degree=8, compressed=True)
+    assert ctx.srs_points == 15
     ctx.close()
