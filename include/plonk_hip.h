@@ -262,7 +262,12 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  * PLONK_COMM_TIMEOUT_MS (default 120000) the communicator is aborted (ncclCommAbort) and the call returns
  * PLONK_ERR_STATE on every surviving rank — the context then has no communicator and must be given a new one
  * (plonk_comm_init) before the next sharded proof.  The host program should still tear the job down when one rank
- * reports an error (bench.py does: the launcher kills the remaining ranks). */
+ * reports an error (bench.py does: the launcher kills the remaining ranks).
+ *
+ * Measurement aid, never for production: with PLONK_COMM_LOOPBACK=1 in the environment every collective of a sharded prover
+ * returns the rank's own contribution in its peers' places (local copies, no transport), so that one rank of a W-rank job can
+ * be timed alone on one GPU (tools/rank_alone.py).  Proofs made that way are wrong by construction: plonk_prover_prove*
+ * returns PLONK_ERR_UNSAT from its final identity check. */
 int plonk_comm_unique_id(uint8_t out[128]);
 int plonk_comm_init(plonk_ctx* ctx, const uint8_t unique_id[128], int rank, int world);
 int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world);

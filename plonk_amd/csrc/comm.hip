@@ -111,8 +111,21 @@ int comm_sync(Ctx* c, hipStream_t st) {
 
 // All-gather of `bytes` host bytes per rank; recv is rank-major.  RCCL when the context has a
 // communicator (staged through device buffers on the main stream), else the host callback.
+// PLONK_COMM_LOOPBACK=1 — MEASUREMENT ONLY (tools/rank_alone.py): every collective hands a rank its own contribution back in
+// place of its peers', with local copies and no transport, so that ONE rank of a W-rank job can be timed alone on one GPU
+// (its kernels, its share of the points and coefficients, the same host sequence).  The values exchanged are wrong by
+// construction: prove() ends in PLONK_ERR_UNSAT at its final identity check, after all of its work.
+static bool comm_loopback() {
+  static const bool on = [] { const char* e = getenv("PLONK_COMM_LOOPBACK"); return e && e[0] == '1'; }();
+  return on;
+}
+
 int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes) {
   if (l.world <= 1) { memcpy(recv, send, bytes); return PLONK_OK; }
+  if (comm_loopback()) {
+    for (int r = 0; r < l.world; ++r) memcpy((uint8_t*)recv + bytes * (size_t)r, send, bytes);
+    return PLONK_OK;
+  }
   if (c->nccl_comm) {
     RcclApi* api = rccl_api();
     if (!api || bytes > COMM_STAGE) return (set_last_error("comm_allgather_host", "message too large / no rccl", __FILE__, __LINE__), PLONK_ERR_ARG);
@@ -132,6 +145,12 @@ int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv,
 int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* recv_dev, size_t bytes_per_peer) {
   if (l.world <= 1) {
     HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, bytes_per_peer, hipMemcpyDeviceToDevice, c->main_stream));
+    return PLONK_OK;
+  }
+  if (comm_loopback()) {
+    for (int src = 0; src < l.world; ++src)
+      HIP_TRY(hipMemcpyAsync((uint8_t*)recv_dev + bytes_per_peer * (size_t)src, (const uint8_t*)send_dev + bytes_per_peer * (size_t)l.rank,
+                             bytes_per_peer, hipMemcpyDeviceToDevice, c->main_stream));
     return PLONK_OK;
   }
   if (c->nccl_comm) {

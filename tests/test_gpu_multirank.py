@@ -146,3 +146,20 @@ def test_comm_api_misuse_is_refused():
     with pytest.raises(plonk_amd.PlonkError):
         plonk_amd.Prover(ctx, 64, b"x", {}, None, 0, 2, 71, None)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_rank_alone_measurement_tool_runs_and_ends_in_the_identity_check():
+    """tools/rank_alone.py (PLONK_COMM_LOOPBACK=1: a rank's own contribution in its peers' places) — the per-rank times of
+    DESIGN.md section 5 come from it.  Every sharded proof made that way must fail at the FINAL quotient-identity check
+    (PLONK_ERR_UNSAT), i.e. after all of the rank's work; the tool asserts that and never calls the transport callback."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rank_alone.py"), "12", "2", "2,8"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [json.loads(x) for x in r.stdout.strip().splitlines()]
+    assert [x["world"] for x in lines] == [2, 8]
+    assert all(x["callback_calls"] == 0 and x["prove_ms_rank_alone"] > 0 for x in lines)
+    assert lines[0]["points"] == (4096 + 7 + 1) // 2
