@@ -1317,7 +1317,16 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     G1RSlot* rc1 = (G1RSlot*)w.chunk;
     G1RSlot* rc2 = rc1 + (size_t)TP_RC1 * MSM_MAX_BATCH;
 #define TPK(LPS) hipLaunchKernelGGL(msm_rowcol_tp_kernel<LPS>, dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1)
-    if (count >= 3) TPK(8); else if (count == 2) TPK(16); else TPK(32);
+    // lanes per sum of 128 buckets: the chip holds 2^17 lanes at two waves per SIMD and a commitment has 2^13 sums; fewer
+    // lanes per sum waste less of the tree steps (useful additions per lane-step: LPS 4: 96 %, 8: 88 %, 16: 72 %, 32: 50 %)
+    // but lengthen the serial chain.  Measured (profiles/r03e section 7): 8 / 8 / 16 for groups of >= 3 / 2 / 1 commitments
+    // (until then 8 / 16 / 32: the small groups over-subscribed the chip two-fold for the sake of depth); 4 for the large
+    // groups gains nothing at 2^20 and loses 0.5 ms at 2^22, where the kernel shares the chip with longer transforms.
+    static const int lps_env = [] { const char* e = getenv("PLONK_MSM_LPS"); return e ? atoi(e) : 0; }();   // A/B runs
+    int lps = count >= 2 ? 8 : 16;
+    if (lps_env == 4 || lps_env == 8 || lps_env == 16 || lps_env == 32) lps = lps_env;
+    else if (lps_env == 1) lps = count >= 3 ? 8 : (count == 2 ? 16 : 32);   // the old rule
+    if (lps == 4) TPK(4); else if (lps == 8) TPK(8); else if (lps == 16) TPK(16); else TPK(32);
 #undef TPK
     hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + (1u << TP_E) + 128, count), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
     hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
