@@ -35,7 +35,7 @@
 namespace plonk {
 
 
-static constexpr uint32_t MSM_KSL = 32;   // entries per slice for m >= 2^20 (msm_ksl: shorter slices keep ~2^19 lanes busy for smaller m)
+static constexpr uint32_t MSM_KSL = 32;   // entries per slice from 2^18 terms on (msm_ksl: shorter slices, 3-6 per bucket, for smaller m)
 static constexpr uint32_t MSM_CHUNK = 16; // buckets per chunk in the weighted reduction
 
 __device__ __forceinline__ Fr ld_fr_g(const Fr* p) {
@@ -1175,8 +1175,9 @@ static constexpr uint32_t TP_E = MSM_NB_BITS - 15;
 static constexpr uint32_t TP_ROWS = MSM_NB / 128, TP_PARTS = TP_ROWS / 128;
 static constexpr uint32_t TP_RC1 = 2 * TP_ROWS;                  // stage-1 sums per commitment
 static constexpr uint32_t TP_RC2 = RCQ_SUMS + (1u << TP_E);      // stage-1.5 sums per commitment: the 2^15 layout + H_r
-// LPS lanes per sum of 128 buckets: a lane adds 128 / LPS buckets serially, then a log2(LPS)-step tree.  8 for groups of 3-4
-// commitments (throughput: 15 + 3 additions per lane, 88 % useful), 16 / 32 for groups of 2 / 1 (depth 11 / 9: latency).
+// LPS lanes per sum of 128 buckets: a lane adds 128 / LPS buckets serially, then a log2(LPS)-step tree.  8 for groups of 2-4
+// commitments (15 + 3 additions per lane, 88 % of the lane-steps useful), 16 for a single commitment (7 + 4, 72 %): the rule
+// and its measurements are at the launch (msm_batch_device_v).
 template <int LPS>
 __global__ void __launch_bounds__(128) msm_rowcol_tp_kernel(const G1RSlot* __restrict__ buckets_all, G1RSlot* __restrict__ rc1_all) {
   constexpr uint32_t PER = 128 / LPS;          // buckets per lane = sums per workgroup
