@@ -5,7 +5,7 @@
 #pragma once
 #include <cstring>
 
-#include "curve.cuh"
+#include "curve28.cuh"   // curve.cuh + the constant-time safegcd inverse (fp_safegcd.cuh)
 
 namespace plonk {
 
@@ -89,7 +89,7 @@ static inline Fp64 fp64_mul(const Fp64& a, const Fp64& b) {
   }
   return (t6 || !borrow) ? d : r;
 }
-static Fp64 fp64_inv(const Fp64& a) {   // a^(p-2), fixed 4-bit windows: 380 squarings + <= 95 + 14 products
+static Fp64 fp64_inv_fermat(const Fp64& a) {   // a^(p-2), fixed 4-bit windows: 380 squarings + <= 95 + 14 products (the cross-check of fp64_inv)
   Fp64 e = fp64_mod();
   e.l[0] -= 2;   // p is odd and p mod 2^64 > 2: no borrow
   Fp64 tab[16];  // tab[k] = a^k, k >= 1
@@ -108,6 +108,30 @@ static Fp64 fp64_inv(const Fp64& a) {   // a^(p-2), fixed 4-bit windows: 380 squ
       if (nib) acc = fp64_mul(acc, tab[nib]);
     }
   return acc;
+}
+// a R -> a^-1 R with the Bernstein-Yang divstep inverse of fp_safegcd.cuh (the same code the kernels use, run on the host):
+// ~5 us instead of the ~27 us of the Fermat chain, once per commitment group between two GPU phases.  The plain inverse of
+// the integer a R is a^-1 R^-1; one Montgomery product with R^3 gives a^-1 R.  0 -> 0 like the Fermat chain.
+static Fp64 fp64_inv(const Fp64& a) {
+  static const Fp64 R3 = [] {
+    Fp r2;
+    for (int i = 0; i < 12; ++i) r2.l[i] = FpP::R2[i];
+    Fp64 x;
+    memcpy(x.l, r2.l, 48);
+    return fp64_mul(x, x);   // R^2 R^2 / R
+  }();
+  uint32_t w[12];
+  memcpy(w, a.l, 48);
+  const safegcd::Signed30<13> d = safegcd::inverse<safegcd::FpMod>(safegcd::to30<13, 32>(w));
+  Fp64 y;
+  memset(&y, 0, sizeof y);
+  for (int i = 0; i < 13; ++i) {   // 13 x 30 bits -> 6 x 64 (the value is < p < 2^381)
+    const int bit = 30 * i, q = bit >> 6, sh = bit & 63;
+    const uint64_t v = (uint64_t)(uint32_t)d.v[i];
+    y.l[q] |= v << sh;
+    if (sh > 34 && q + 1 < 6) y.l[q + 1] |= v >> (64 - sh);
+  }
+  return fp64_mul(y, R3);
 }
 static Fp64 fp64_add(const Fp64& a, const Fp64& b) {
   static const Fp64 M = fp64_mod();

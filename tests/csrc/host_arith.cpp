@@ -267,3 +267,11 @@ extern "C" void h_fr_inv_gcd(const uint32_t* a, uint32_t* o) {
 #include "../../plonk_amd/csrc/hostg2.hpp"
 extern "C" int h_g2_compressed_valid(const uint8_t in[96]) { return plonk::g2_compressed_valid(in) ? 1 : 0; }
 extern "C" int h_g1_compressed_valid(const uint8_t in[48]) { return plonk::g1_compressed_valid(in) ? 1 : 0; }
+
+// ---- hostg1.hpp: the host-side Fp inverse (Montgomery in, Montgomery out): safegcd (mode 0) and the Fermat chain (mode 1) ----
+extern "C" void h_fp64_inv(const uint8_t in[48], int fermat, uint8_t out[48]) {
+  plonk::Fp64 a;
+  memcpy(a.l, in, 48);
+  const plonk::Fp64 r = fermat ? plonk::fp64_inv_fermat(a) : plonk::fp64_inv(a);
+  memcpy(out, r.l, 48);
+}

@@ -432,3 +432,18 @@ def test_g1_compressed_validity_on_host(lib):
     bad = bytearray(E.g1_compress(E.G1_GEN))
     bad[0] &= 0x7F
     assert lib.h_g1_compressed_valid(bytes(bad)) == 0
+
+
+def test_host_fp_inverse_safegcd_equals_fermat_and_the_oracle(lib):
+    """hostg1.hpp fp64_inv (the shared inversion of a commitment group's affine normalisation, on the host between two GPU
+    phases): Bernstein-Yang divsteps instead of the a^(p-2) chain — Montgomery form in and out, 0 -> 0."""
+    r = random.Random(91)
+    R = 1 << 384
+    vals = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, 1 << 380, (1 << 381) % P] + [r.randrange(P) for _ in range(200)]
+    out = ctypes.create_string_buffer(48)
+    for v in vals:
+        mont = (v * R % P).to_bytes(48, "little")
+        expect = (pow(v, -1, P) * R % P) if v else 0
+        for fermat in (0, 1):
+            lib.h_fp64_inv(mont, fermat, out)
+            assert int.from_bytes(out.raw, "little") == expect, (v, fermat)
