@@ -236,4 +236,25 @@ HD Fr29 fr29_inv_gcd_tw(const Fr29& a) {
   return Fr29::mul(y, c);
 }
 
+// Montgomery form in, Montgomery form out for the 8 x 32-bit Fr of field.cuh (x R -> x^-1 R, R = 2^256); 0 -> 0.  The host
+// driver's per-proof inversions (1 / (z (z - 1)) in round 5, the public-input denominators) use it instead of the a^(q-2)
+// chain: ~3 us instead of ~45 us between two GPU phases.
+HD Fr fr_inv_gcd(const Fr& a) {
+  Fr r2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r2.l[i] = FrP::R2[i];
+  const Fr r3 = r2 * r2;                                    // stored R^2 R^2 / R = R^3
+  const safegcd::Signed30<9> d = safegcd::inverse<safegcd::FrMod>(safegcd::to30<9, 32>(a.l));
+  Fr y;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                             // 9 x 30 bits -> 8 x 32
+    const int bit = 32 * i, w = bit / 30, sh = bit % 30;
+    uint64_t v = (uint64_t)(uint32_t)d.v[w] >> sh;
+    if (w + 1 < 9) v |= (uint64_t)(uint32_t)d.v[w + 1] << (30 - sh);
+    if (w + 2 < 9) v |= (uint64_t)(uint32_t)d.v[w + 2] << (60 - sh);
+    y.l[i] = (uint32_t)v;
+  }
+  return y * r3;                                            // x^-1 R^-1 R^3 / R
+}
+
 }  // namespace plonk

@@ -680,7 +680,7 @@ static Fr public_input_eval(const Prover* p, const uint64_t* pi_idx, const Fr* p
     pre[i] = run;
     if (!pi_val[i].is_zero() && !den[i].is_zero()) run = run * den[i];
   }
-  Fr inv = run.inv(), acc = Fr::zero();
+  Fr inv = fr_inv_gcd(run), acc = Fr::zero();
   for (uint64_t i = pi_count; i-- > 0;) {
     if (pi_val[i].is_zero() || den[i].is_zero()) continue;
     acc = acc + inv * pre[i] * pi_val[i];
@@ -997,7 +997,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   {
     const Fr zm1 = z_ch - one;
     const Fr a = z_zero ? one : z_ch, b = zm1.is_zero() ? one : zm1;
-    const Fr iab = (a * b).inv();
+    const Fr iab = fr_inv_gcd(a * b);
     inv_z = iab * b;
     inv_zm1 = iab * a;
   }
@@ -1351,7 +1351,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   const Fr n_inv = p->n_inv;
   if (z_ch.is_zero() || zw.is_zero()) return PLONK_ERR_STATE;   // probability 2^-255
   const Fr zm1 = z_ch - one;
-  const Fr iab = (z_ch * (zm1.is_zero() ? one : zm1)).inv();
+  const Fr iab = fr_inv_gcd(z_ch * (zm1.is_zero() ? one : zm1));
   const Fr inv_z = iab * (zm1.is_zero() ? one : zm1), inv_zm1 = iab * z_ch;
   const Fr pi_eval = public_input_eval(p, pi_idx, pi_val, pi_count, z_ch, zh);
   const Fr bz = beta * z_ch;

@@ -275,3 +275,9 @@ extern "C" void h_fp64_inv(const uint8_t in[48], int fermat, uint8_t out[48]) {
   const plonk::Fp64 r = fermat ? plonk::fp64_inv_fermat(a) : plonk::fp64_inv(a);
   memcpy(out, r.l, 48);
 }
+// the Montgomery-in / Montgomery-out Fr inverse the host driver uses per proof (fp_safegcd.cuh fr_inv_gcd)
+extern "C" void h_fr_inv_gcd_mont(const uint32_t* a, uint32_t* o) {
+  Fr x; memcpy(&x, a, 32);
+  const Fr r = fr_inv_gcd(x);
+  memcpy(o, &r, 32);
+}

@@ -447,3 +447,13 @@ def test_host_fp_inverse_safegcd_equals_fermat_and_the_oracle(lib):
         for fermat in (0, 1):
             lib.h_fp64_inv(mont, fermat, out)
             assert int.from_bytes(out.raw, "little") == expect, (v, fermat)
+
+
+def test_host_fr_inverse_safegcd_montgomery_form(lib):
+    """fp_safegcd.cuh fr_inv_gcd: x R -> x^-1 R on the 8 x 32-bit Fr — the per-proof host inversions of prover.hip
+    (1 / (z (z - 1)), the public-input denominators); 0 -> 0 like Fr::inv."""
+    r = random.Random(92)
+    out = (ctypes.c_uint32 * 8)()
+    for v in [0, 1, 2, Q - 1, Q - 2, (Q - 1) // 2, 1 << 254] + [r.randrange(Q) for _ in range(300)]:
+        lib.h_fr_inv_gcd_mont(fr_limbs(v), out)
+        assert fr_val(out) == (pow(v, -1, Q) if v else 0), v
