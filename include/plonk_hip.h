@@ -331,8 +331,9 @@ int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints);
  *                           (key.rs:319-326): compression flag, x < p, x^3 + 4 a square, torsion-free — any failure, a short
  *                           last chunk included, is a dusk_bytes error (PLONK_ERR_DATA), wherever in the file.  Decompression
  *                           (one square root per point, g1codec.cuh) and the subgroup test run on the GPU.
- *   All modes: OpeningKey::from_slice (key.rs:455-490) in full — g a valid compressed G1 point, h and x_h valid compressed G2
- *   points (flags, canonical coordinates, on the twist curve, of order q; hostg2.hpp, on the host) — PLONK_ERR_DATA otherwise.
+ *   All modes: OpeningKey::from_bytes + try_new (key.rs:596-648) — g a valid compressed G1 point, h and x_h valid compressed G2
+ *   points (flags, canonical coordinates, on the twist curve, of order q; hostg2.hpp, on the host) and NONE of the three the
+ *   identity (try_new refuses a degenerate key: the pairing check would be trivially satisfiable) — PLONK_ERR_DATA otherwise.
  *   The prover never uses them; they are handed back as the 240 bytes they came as.
  *   truncated_degree > 0: PublicParameters::trim (srs.rs:188-196) = CommitKey::truncate(truncated_degree + 6)
  *   (key.rs:336-355): PLONK_ERR_DEGREE when the key is shorter (Error::TruncatedDegreeTooLarge); 0 keeps every point.  The

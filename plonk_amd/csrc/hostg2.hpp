@@ -1,9 +1,10 @@
-// Host-side validity test of a compressed G2 encoding: what OpeningKey::from_slice (reference src/commitment_scheme/
-// kzg10/key.rs:455-490) asks of `h` and `x_h` through G2Affine::from_bytes of the dusk-bls12_381 dependency (zkcrypto
+// Host-side validity test of a compressed G2 encoding: what OpeningKey::from_bytes (reference src/commitment_scheme/
+// kzg10/key.rs:596-615) asks of `h` and `x_h` through G2Affine::from_bytes of the dusk-bls12_381 dependency (zkcrypto
 // layout: 96 bytes, x.c1 then x.c0 big-endian, flag bits 0x80 compressed / 0x40 infinity / 0x20 sign of y in the first
 // byte).  An encoding is accepted iff
 //   * the compression flag is set;
-//   * infinity flag set:  the sign flag is clear and every other bit is zero  (the identity decodes);
+//   * infinity flag set:  the sign flag is clear and every other bit is zero  (the identity decodes HERE; OpeningKey::try_new,
+//     key.rs:617-648, then refuses an identity g, h or x_h — serial.hip public_parameters_check does that before calling this);
 //   * otherwise: both coordinates of x are canonical (< p), x^3 + 4 (1 + u) is a square in Fp2 (either root is a point;
 //     the sign flag only picks one of them), and the point has order r  ([r] P = O, is_torsion_free).
 // No G2 arithmetic exists anywhere else in the library (the prover never touches the opening key): this runs once per

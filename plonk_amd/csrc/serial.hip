@@ -242,7 +242,10 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
   memset(info, 0, sizeof *info);
   if (mode != PLONK_PP_RAW_UNCHECKED && mode != PLONK_PP_RAW && mode != PLONK_PP_COMPRESSED) FAIL(PLONK_ERR_ARG, "unknown public-parameters mode");
   if (len <= OPENING_KEY_BYTES) FAIL(PLONK_ERR_BYTES, "public parameters shorter than an opening key");   // srs.rs:165-167
-  // OpeningKey::from_slice (key.rs:455-490): three compressed points; g is checked like every G1 encoding
+  // OpeningKey::from_bytes (key.rs:596-615) -> OpeningKey::try_new (key.rs:617-648): three compressed points, each on its
+  // curve, torsion-free AND not the identity — a degenerate opening key makes the pairing check trivially satisfiable.
+  // (G1Affine / G2Affine::from_bytes alone accept the 0xC0 encoding; verifier-key commitments above keep accepting it.)
+  if ((bytes[0] & 0x40) || (bytes[48] & 0x40) || (bytes[144] & 0x40)) FAIL(PLONK_ERR_DATA, "opening key: g, h and x_h must not be the identity");
   if (!g1_compressed_valid(bytes)) FAIL(PLONK_ERR_DATA, "opening key: g is not a valid compressed G1 point");
   // h and x_h: G2Affine::from_bytes in full (flags, canonical coordinates, on the twist curve, order q) — hostg2.hpp
   if (!g2_compressed_valid(bytes + 48)) FAIL(PLONK_ERR_DATA, "opening key: h is not a valid compressed G2 point");

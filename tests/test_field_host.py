@@ -370,7 +370,7 @@ def test_g2_reference_generator_is_the_standard_one():
 
 
 def test_g2_compressed_validity_matches_the_reference_decoder(lib):
-    """hostg2.hpp g2_compressed_valid == "G2Affine::from_bytes succeeds" (key.rs:455-490 through dusk-bls12_381): multiples of
+    """hostg2.hpp g2_compressed_valid == "G2Affine::from_bytes succeeds" (key.rs:596-648 through dusk-bls12_381): multiples of
     the generator with either sign flag, the identity, and every way an encoding can be wrong — flag bits, a non-canonical
     coordinate, x off the curve, a curve point outside the order-q subgroup."""
     import g2_ref as G

@@ -84,7 +84,7 @@ def test_invalid_data(pp):
 
 
 def test_opening_key_g2_points_are_decoded_like_the_reference(pp):
-    """OpeningKey::from_slice (key.rs:455-490) runs G2Affine::from_bytes on h and x_h: an encoding the reference refuses is
+    """OpeningKey::from_bytes (key.rs:596-615, then try_new :617-648) runs G2Affine::from_bytes on h and x_h: an encoding the reference refuses is
     refused here (they used to be checked for the compression flag only)."""
     import g2_ref
     data, _ = pp
@@ -105,9 +105,13 @@ def test_opening_key_g2_points_are_decoded_like_the_reference(pp):
         # the other root is the negated point: still a valid key
         neg = bytes([enc[0] ^ 0x20]) + enc[1:]
         assert plonk_amd.public_parameters_check(data[:off] + neg + data[off + 96:])["points_total"] == 23
-        # the identity decodes (G2Affine::from_bytes accepts it)
+        # the identity is a valid G2Affine encoding but OpeningKey::try_new (key.rs:617-648) refuses it: InvalidData
         ident = bytes([0xC0]) + bytes(95)
-        assert plonk_amd.public_parameters_check(data[:off] + ident + data[off + 96:])["points_total"] == 23
+        with pytest.raises(plonk_amd.InvalidData):
+            plonk_amd.public_parameters_check(data[:off] + ident + data[off + 96:])
+    # the same for g (a valid compressed G1 identity)
+    with pytest.raises(plonk_amd.InvalidData):
+        plonk_amd.public_parameters_check(bytes([0xC0]) + bytes(47) + data[48:])
 
 
 def test_point_malformed(pp):
