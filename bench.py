@@ -131,10 +131,12 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
     return prover, wbuf, srs_total
 
 
-def time_profile(ctx, log_n, profile, steps, blinders):
-    """ms per prove() of another workload on this (single) GPU"""
+def time_profile(ctx, log_n, profile, steps, blinders, digest=None):
+    """ms per prove() of another workload on this (single) GPU; digest: a dict that receives the proof's blake2b"""
     prover, wbuf, _ = build_prover(ctx, log_n, 0, 1, None, profile)
-    prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+    proof = prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+    if digest is not None:
+        digest["proof_blake2b"] = hashlib.blake2b(proof).hexdigest()[:32]
     ctx.sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -237,6 +239,15 @@ def leaf_costs(ctx, log_n):
     return out
 
 
+VALU_PEAK_GWIPS = 1024 * 2.4 / 4          # G wave-instructions/s: 1024 SIMDs x 2.4 GHz, one VALU wave-instruction per 4 cycles
+
+
+def valu_issue(wave_instructions, ms):
+    """the bound that holds for every kernel on this path: integer-VALU issue"""
+    ach = wave_instructions / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"achieved": round(ach, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GWIPS, 4)}
+
+
 def quotient_roofline(prover, n, qmul, has_pi, profile, ms_per_launch):
     nz = getattr(build_prover, "selectors_nonzero", 5)
     """Algorithmic bytes of the point-wise quotient pass: every array the kernel reads once per point + the one it writes,
@@ -247,9 +258,15 @@ def quotient_roofline(prover, n, qmul, has_pi, profile, ms_per_launch):
     bytes_per_point = 32 * (arrays + 1)
     pts = qmul * n
     ach = bytes_per_point * pts / (ms_per_launch * 1e-3) / 1e9 if ms_per_launch > 0 else 0.0
-    return {"bound": "hbm", "kernel": "quotient_kernel", "points": pts, "algorithmic_bytes_per_point": bytes_per_point,
-            "arrays_read": arrays, "avg_launch_ms": round(ms_per_launch, 4), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+    # what binds it (profiles/r03e section 6): ~7 000 VALU instructions per point without custom gates (28 Fr29 products + 20
+    # limb conversions), ~32 000 with every widget — issue-bound at a third of the HBM peak
+    instr = 32000 if profile == "widgets" else 7000
+    issue = valu_issue(pts * instr / 64, ms_per_launch)
+    return {"bound": "valu-int-issue", "kernel": "quotient_kernel", "points": pts, "instructions_per_point": instr,
+            "achieved": issue["achieved"], "peak": issue["peak"], "unit": issue["unit"], "frac": issue["frac"],
+            "algorithmic_bytes_per_point": bytes_per_point, "arrays_read": arrays, "avg_launch_ms": round(ms_per_launch, 4),
+            "hbm": {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)},
+            "hbm_frac": round(ach / HBM_PEAK_GBS, 4),
             "note": "hipEvent pair around the launch inside the timed region (slot 3)"}
 
 
@@ -276,10 +293,16 @@ def ntt_roofline(ctx, log_n, qd8):
         ms = (time.perf_counter() - t0) * 1e3 / iters
         for b in (src, dst, tmp):
             b.free()
+        # N/2 log2 N butterflies of ~290 VALU instructions (fr29.cuh) + one inter-pass twiddle product per
+        # element and pass boundary (~150): the issue-rate figure that bounds the passes
+        npass = 1 if L <= 10 else (2 if L <= 18 else 3)
+        issue = valu_issue((N // 2 * L * 290 + N * (npass - 1) * 150) / 64, ms)
         out[name] = {"log_size": L, "ms": round(ms, 4), "melem_per_s": round(N / ms / 1e3, 1),
-                     "achieved": round(64 * N / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)}
-    return {"bound": "hbm", "kernel": "ntt_pass_kernel (2-3 passes per transform)", "algorithmic_bytes": "64 N per transform",
+                     "achieved": issue["achieved"], "peak": issue["peak"], "unit": issue["unit"], "frac": issue["frac"],
+                     "hbm": {"achieved": round(64 * N / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)},
+                     "hbm_frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    return {"bound": "valu-int-issue", "kernel": "ntt_pass_kernel (2-3 passes per transform)", "algorithmic_bytes": "64 N per transform",
             "note": "timed standalone with wall clock around 10 back-to-back launches; integer-VALU bound (Fr29 butterflies), "
                     "a k-pass plan moves k x 64 N actual bytes", "transforms": out}
 
@@ -386,6 +409,7 @@ def main():
     ap.add_argument("--log-gates", type=int, default=20)
     ap.add_argument("--profile", default="dense", choices=["dense", "bench-like", "widgets"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-2p22", action="store_true", help="skip the 2^22-gate extra of the default line (about half a minute of setup)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads / leaf costs of the N=1 line")
     ap.add_argument("--from-circuit", action="store_true",
                     help="build the prover with plonk_compile from gate columns (Compiler::preprocess on the device) instead of "
@@ -537,6 +561,8 @@ def main():
             digits_per_scalar = 16.0 - 0.5
         elif m_local > (1 << 19) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":
             digits_per_scalar = round(254.86 / 22 + 0.5 - (1 << 19) / max(m_local, 1), 2)
+        elif m_local > (1 << 18) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":   # w = 19 over 2^17 buckets
+            digits_per_scalar = round(254.86 / 20 + 0.5 - (1 << 17) / max(m_local, 1), 2)
         else:
             digits_per_scalar = 14.67 - 0.5
         npoly = 6 if pi else 5
@@ -567,20 +593,24 @@ def main():
             # whole-job MSM rate: all 11 x (n + 6) terms of a proof over the time rank 0 spends in its (sharded) MSM kernels
             "msm_mscalar_per_s": round(11 * (n + 6) / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),
             "proof_blake2b": hashlib.blake2b(proof).hexdigest()[:32],
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
-                         # wave-instructions (additions / 64 lanes x instructions per addition) x 4 cycles / (time x 1024 SIMDs x 2.4 GHz): how close the
-                         # kernel runs to one VALU instruction per 4 cycles per SIMD (mixed addition: 4850 instructions,
-                         # profiles/r02c/accumulate_isa.md; additions = non-zero digits of the 11 commitments' scalars)
-                         "valu_issue_fraction": round(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850 * 4 /
-                                                      max(acc_ms_per_prove * 1e-3 * 1024 * 2.4e9, 1e-9), 3),
-                         "additions_per_scalar": digits_per_scalar, "table_rows": table_rows,
-                         "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
-                         "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
-                         "launch_groups_per_prove": list(groups),
-                         "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; see DESIGN.md"},
-            # the one HBM-bound pass of a proof: quotient_kernel over the quotient-domain points
+            # the dominant kernel is bound by integer-VALU issue, not by HBM: `frac` is the issue-rate fraction —
+            # wave-instructions (additions / 64 lanes x 4850 instructions per mixed addition, profiles/r02c/accumulate_isa.md;
+            # additions = non-zero digits of the 11 commitments' scalars) over one VALU wave-instruction per 4 cycles per SIMD.  The
+            # HBM figure the contract asks for (algorithmic (32 b + 96) m bytes per group launch over the launch time) is `hbm`.
+            "roofline": dict(
+                {"bound": "valu-int-issue", "kernel": "msm_accumulate_kernel"},
+                **valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove),
+                **{"traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
+                   "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
+                   "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
+                   "valu_issue_fraction": valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"],
+                   "additions_per_scalar": digits_per_scalar, "instructions_per_addition": 4850, "table_rows": table_rows,
+                   "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
+                   "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
+                   "launch_groups_per_prove": list(groups),
+                   "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; `traffic` (PMC, HBM bytes per launch) is one "
+                           "128-B table gather per non-zero digit by design; see DESIGN.md"}),
+            # the pass of a proof that comes closest to HBM: quotient_kernel over the quotient-domain points
             "roofline_quotient": quotient_roofline(prover, n, 8 if qd8 else 4, bool(pi), args.profile, q_ms / max(q_n, 1)),
             "kernel_ms_per_prove": {"msm_accumulate": round(acc_ms / args.steps, 3),
                                     "msm_other": round(oth_ms / args.steps, 3),
@@ -621,13 +651,30 @@ def main():
                 k = max(2, min(args.steps, 5))
                 out["prove_ms_bench_like"] = time_profile(ctx, log_n, "bench-like", k, blinders)
                 out["prove_ms_all_widgets_pi"] = time_profile(ctx, log_n, "widgets", k, blinders)
-                if log_n != 16:
-                    out["prove_ms_2p16"] = time_profile(ctx, 16, "dense", 2 * k, blinders)
+                # north_star: prove-time at 2^16 .. 2^22 (and BASELINE config 1's 2^12) on the driver's clock, each with its digest
+                for lg, reps in ((12, 6 * k), (16, 4 * k)):
+                    if log_n != lg:
+                        dg = {}
+                        out["prove_ms_2p%d" % lg] = time_profile(ctx, lg, "dense", reps, blinders, dg)
+                        out["proof_blake2b_2p%d" % lg] = dg.get("proof_blake2b")
                 out["compile"] = compile_costs(ctx, log_n if log_n <= 20 else 20, blinders)
                 if log_n <= 20:   # same circuit, key and blinders as the timed run, built the other way
                     out["compile"]["proof_matches_timed_run"] = bool(out["compile"]["proof_blake2b"] == out["proof_blake2b"])
             except Exception as e:   # noqa: BLE001
                 out["extras_error"] = repr(e)
+        if world == 1 and not args.no_extras and args.profile == "dense" and log_n == 20 and not args.no_2p22:
+            try:   # BASELINE config 5's size on one GPU (commit key streamed from pinned host memory): after everything else, own guard
+                t22 = time.perf_counter()
+                dg = {}
+                out["prove_ms_2p22"] = time_profile(ctx, 22, "dense", 3, blinders, dg)
+                out["proof_blake2b_2p22"] = dg.get("proof_blake2b")
+                out["prove_2p22_setup_and_run_s"] = round(time.perf_counter() - t22, 1)
+            except Exception as e:   # noqa: BLE001
+                out["prove_2p22_error"] = repr(e)
+            try:   # give the 137 GB of bit-position rows back before the CPU leg
+                ctx.srs_load([])
+            except Exception:   # noqa: BLE001
+                pass
         if world == 1 and not args.no_cpu_baseline and args.profile == "dense":
             try:
                 out["cpu_baseline"], cpu_proof = cpu_baseline(log_n, vk48)

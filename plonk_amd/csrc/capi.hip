@@ -35,7 +35,7 @@ struct ProfState {
   std::vector<hipEvent_t> pool;
   size_t used = 0;
   std::vector<ProfRec> recs;
-  hipEvent_t open[8] = {nullptr};
+  hipEvent_t open[Ctx::PROF_SLOTS] = {nullptr};
 };
 static std::map<Ctx*, ProfState*> g_prof;
 static std::mutex g_prof_mu;
@@ -503,7 +503,7 @@ int plonk_profile_enable(plonk_ctx* ctx, int on) {
   return PLONK_OK;
 }
 int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches) {
-  if (!ctx || slot < 0 || slot >= 8) return PLONK_ERR_ARG;
+  if (!ctx || slot < 0 || slot >= plonk::Ctx::PROF_SLOTS) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   int rc = prof_collect(&ctx->c);
   if (rc) return rc;
@@ -515,7 +515,7 @@ int plonk_profile_reset(plonk_ctx* ctx) {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   int rc = prof_collect(&ctx->c);
-  for (int i = 0; i < 8; ++i) { ctx->c.acc_ms[i] = 0; ctx->c.acc_n[i] = 0; }
+  for (int i = 0; i < plonk::Ctx::PROF_SLOTS; ++i) { ctx->c.acc_ms[i] = 0; ctx->c.acc_n[i] = 0; }
   return rc;
 }
 

@@ -493,7 +493,7 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
                                                              G1RSlot* __restrict__ buckets_all, uint32_t heavy_thresh,
                                                              const uint32_t* __restrict__ nheavy_all, const HeavyItem* __restrict__ heavy_list_all,
                                                              G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused, uint32_t direct,
-                                                             const uint32_t* __restrict__ multi_list_all) {
+                                                             const uint32_t* __restrict__ multi_list_all, uint32_t dense_quad) {
   const int kb = blockIdx.y;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -529,17 +529,25 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
     }
     return;
   }
-  if (multi_list_all) {
+  if (multi_list_all || dense_quad) {
     // many buckets: only the listed buckets of 2 .. heavy_thresh slices (every other one is already written), one lane each,
     // over a SMALL grid with a stride loop — 4096 nearly empty workgroups per commitment cost 0.2 ms of dispatch alone (r03c)
     // A listed bucket has 2 .. heavy_thresh slices, i.e. up to 15 DEPENDENT additions: the kernel lasts as long as its longest
     // chain (0.27 ms with one lane per bucket), so a quad works on each bucket (g1r_add_quad: ~2.8x lower latency).
-    const uint32_t nmulti = nheavy_all[2 * MSM_MAX_BATCH + kb];
+    // dense_quad (r04, few slices per bucket — small MSMs): the same quad walk over EVERY bucket instead of a list.  With 3-6
+    // slices per bucket the one-lane-per-bucket kernel below is 2^15 lanes (half a wave per SIMD) running 3-5 dependent full
+    // additions at a lone wave's ~10 cycles per instruction: 200 us for ONE 2^16-term commitment, 400 for a group of four —
+    // as long as the accumulation it follows (profiles/r04a).  A quad per bucket is 2^17 lanes and ns - 1 quad additions.
+    const uint32_t nmulti = dense_quad ? MSM_NB : nheavy_all[2 * MSM_MAX_BATCH + kb];
     const uint32_t* __restrict__ list = multi_list_all + (uint64_t)kb * MSM_NB;
     const uint32_t q = threadIdx.x & 3;
     for (uint32_t i = ((blockIdx.x - fused) * blockDim.x + threadIdx.x) >> 2; i < nmulti; i += ((gridDim.x - fused) * blockDim.x) >> 2) {
-      const uint32_t mb = list[i];
+      const uint32_t mb = dense_quad ? i : list[i];
       const uint32_t beg = slice_off[mb], end = slice_off[mb + 1];
+      if (dense_quad) {
+        if (end - beg > heavy_thresh || (direct && end - beg == 1)) continue;   // heavy: the segment workers; one slice: written by its lane
+        if (end == beg) { if (q == 0) st_g1r(buckets + mb, G1R::identity()); continue; }
+      }
       G1R acc = ld_g1r(partial + beg);
       for (uint32_t k = beg + 1; k < end; ++k) acc = g1r_add_quad(acc, ld_g1r(partial + k), q);
       if (q == 0) st_g1r(buckets + mb, acc);
@@ -941,7 +949,8 @@ uint32_t msm_table_rows(uint64_t n) {
   // layout — a reduction over 16x the buckets (same-box pairs, window rows vs bit-position rows: 2^16 gates 5.33 / 5.59 ms,
   // 2^18 11.16 / 11.37, 2^19 20.23 / 20.43; 2^20 37.8 / 34.9, 2^21 71.9* / 64.4, 2^22 147.0 / 131.8; * = 2^15 buckets).
   // profiles/r03c/sizes_2p18_to_2p22.txt
-  if (n <= (1ull << 19) + 64) return MSM_ROWS_WINDOW;
+  // round 4: keys of 2^18 .. 2^19 points take bit-position rows too (2^19 buckets win from 2^19 terms on, see msm_batch_device)
+  if (n <= (1ull << 18) + 64) return MSM_ROWS_WINDOW;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MSM_ROWS_WINDOW;
   const uint64_t need = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_BITPOS * n + sizeof(Fp28Slot) * 3 * (MSM_ROWS_BITPOS - 1) * (1ull << 16);
@@ -1150,6 +1159,11 @@ namespace PLONK_MSM_NS {
 static uint32_t msm_ksl(uint64_t m) {
   static const int forced = [] { const char* e = getenv("PLONK_MSM_KSL"); return e ? atoi(e) : 0; }();   // tuning experiments only
   if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64 || forced == 128) return (uint32_t)forced;
+  // 2^17 buckets (r04): 32-entry slices although a bucket holds ~53 entries at 2^19 terms.  One lane per bucket (128-entry
+  // slices) is a single round of 2^17 lanes per commitment whose longest buckets set the kernel's time: accumulate ran at
+  // 83 % of its rate (13.4 ms per 2^19-gate proof against 11.2 with 32-entry slices, profiles/r04f); the second slice of
+  // every bucket costs 0.9 ms of bucket sums.
+  if (MSM_NB_BITS == 17) return 32u;
   if (MSM_NB_BITS > 15) {   // one slice per bucket: the smallest of 32 / 64 / 128 that holds ~1.3x the expected entries of a bucket
     const uint64_t expect = 13 * m / MSM_NB;
     return expect <= 24 ? 32u : (expect <= 49 ? 64u : 128u);
@@ -1255,13 +1269,23 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     // heavy = well above the expected slice count (skewed digits): twice the uniform average, at least 16 slices
     bt.heavy_thresh = (uint32_t)(2 * avg_slices > 16 ? 2 * avg_slices : 16);
   }
+  // PLONK_PROF_FINE=1: every phase of the group on its own slot (16 + phase for groups of >= 3 commitments, 24 + phase below;
+  // phases: 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums (+ fold), 5 bit sums) —
+  // hipEvents between the launches, i.e. kernel times WITHOUT a profiler attached (tools/msm_phases.py)
+  static const bool fine = [] { const char* e = getenv("PLONK_PROF_FINE"); return e && e[0] == '1'; }();
+  const int fbase = count >= 3 ? 16 : 24;
+#define FINE_BEGIN(ph) do { if (fine) prof_begin(c, fbase + (ph)); } while (0)
+#define FINE_END(ph) do { if (fine) prof_end(c, fbase + (ph)); } while (0)
   prof_begin(c, 2);
+  FINE_BEGIN(0);
   rc = msm_group_sort(c, bt, mmax);
+  FINE_END(0);
   prof_end(c, 2);
   if (rc) return rc;
   // upper bound on slices known on the host: no device->host sync on the path
   const uint64_t max_slices = (MSM_W * mmax) / bt.ksl + MSM_NB + 1;
   prof_begin(c, 1);
+  FINE_BEGIN(1);
   // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
   // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
   static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
@@ -1282,9 +1306,11 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   else
     hipLaunchKernelGGL(msm_accumulate_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
                        (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, (G1RSlot*)w.partial);
+  FINE_END(1);
   prof_end(c, 1);
   if (c->acc_done) HIP_TRY(hipEventRecord(c->acc_done, st));
   prof_begin(c, 2);
+  FINE_BEGIN(2);
   {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
     const uint32_t heavy_thresh = bt.heavy_thresh;                  // the list of heavy buckets was written by msm_slices_kernel
@@ -1292,16 +1318,23 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     static const bool tail_quad_ = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
     const uint32_t fused = (tail_quad_ || MSM_NB_BITS > 15) ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
     const bool list_mode = MSM_NB_BITS > 15 && acc_ordered && !acc_lds;   // bucket sums driven by msm_layout_apply's list
-#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3((list_mode ? 1024u : MSM_NB * G / 128) + fused, count), dim3(128), 0, st, bt, \
+    // few slices per bucket (small MSMs over 2^15 buckets): a quad per bucket (dense_quad above); PLONK_MSM_BSUM=lane restores
+    // the one-lane-per-bucket kernels for A/B
+    static const bool bsum_lane = [] { const char* e = getenv("PLONK_MSM_BSUM"); return e && e[0] == 'l'; }();
+    const bool dense_quad = !list_mode && tail_quad_ && !bsum_lane && avg_slices <= 8;
+#define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3((list_mode ? 1024u : (dense_quad ? MSM_NB * 4 / 128 : MSM_NB * G / 128)) + fused, count), dim3(128), 0, st, bt, \
                                    (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (const HeavyItem*)w.heavy_list, \
                                    (G1RSlot*)w.seg_sum, w.cap_segs, fused, (acc_ordered && !acc_lds) ? 1u : 0u, \
-                                   list_mode ? (const uint32_t*)w.multi_list : (const uint32_t*)nullptr)
-    if (avg_slices <= 4) BSUM(1);
+                                   list_mode ? (const uint32_t*)w.multi_list : (const uint32_t*)nullptr, dense_quad ? 1u : 0u)
+    if (dense_quad) BSUM(1);
+    else if (avg_slices <= 4) BSUM(1);
     else if (avg_slices <= 16) BSUM(2);
     else if (avg_slices <= 32) BSUM(4);
     else BSUM(8);
 #undef BSUM
   }
+  FINE_END(2);
+  FINE_BEGIN(3);
   static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
   if (tail_quad || MSM_NB_BITS > 15) {
     hipLaunchKernelGGL(msm_heavy_bucket_quad_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
@@ -1312,6 +1345,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
                        (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
   }
+  FINE_END(3);
   c->msm.last_rowbits = 8 + (MSM_NB_BITS - 15);
 #if PLONK_MSM_NB_BITS > 15
   {   // many buckets: throughput row / column sums, the fold to the 2^15 shapes, then the same bit sums (outputs shifted by E)
@@ -1325,12 +1359,19 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     // groups gains nothing at 2^20 and loses 0.5 ms at 2^22, where the kernel shares the chip with longer transforms.
     static const int lps_env = [] { const char* e = getenv("PLONK_MSM_LPS"); return e ? atoi(e) : 0; }();   // A/B runs
     int lps = count >= 2 ? 8 : 16;
+    // 2^17 buckets (r04): a quarter of the sums — 8 lanes per sum left half of the chip idle behind 18 dependent additions
+    // (0.64 ms per group of four, profiles/r04d); lanes per sum so that a launch has about the chip's 2^17 lane slots
+    if (MSM_NB_BITS == 17) lps = count >= 3 ? 16 : 32;
     if (lps_env == 4 || lps_env == 8 || lps_env == 16 || lps_env == 32) lps = lps_env;
     else if (lps_env == 1) lps = count >= 3 ? 8 : (count == 2 ? 16 : 32);   // the old rule
+    FINE_BEGIN(4);
     if (lps == 4) TPK(4); else if (lps == 8) TPK(8); else if (lps == 16) TPK(16); else TPK(32);
 #undef TPK
     hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + (1u << TP_E) + 128, count), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
+    FINE_END(4);
+    FINE_BEGIN(5);
     hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
+    FINE_END(5);
     prof_end(c, 2);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
@@ -1338,10 +1379,14 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
 #else
   if (bit_sums && tail_quad) {
     // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
+    FINE_BEGIN(4);
     if (count >= 3) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     else if (count == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     else hipLaunchKernelGGL(msm_rowcol_quad_kernel<4>, dim3(RCQ_SUMS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    FINE_END(4);
+    FINE_BEGIN(5);
     hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17, count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk, (uint32_t)RCQ_SUMS, 0u);
+    FINE_END(5);
     prof_end(c, 2);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
@@ -1359,6 +1404,8 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 #endif
+#undef FINE_BEGIN
+#undef FINE_END
 }
 
 
@@ -1480,9 +1527,24 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   static const int buckets_env = [] { const char* e = getenv("PLONK_MSM_BUCKETS"); return e ? atoi(e) : 0; }();
   static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
   static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
-  const bool can19 = table_rows == MSM_ROWS_BITPOS && bit_sums && tail_quad && !acc_lds;
-  const bool use19 = can19 && (buckets_env > 15 || (buckets_env != 15 && mmax > (1ull << 19) + 64));
-  return use19 ? nbl::msm_batch_device_v(c, bt, mmax, bit_sums) : nb15::msm_batch_device_v(c, bt, mmax, bit_sums);
+  // bucket count by the number of terms: more than 2^18 terms 2^19 buckets, else 2^15.  Round 4 moved the crossover down from
+  // 2^19 (same box, 2^19 gates: window rows 19.94 ms, bit-position rows over 2^15 / 2^17 / 2^19 buckets 21.31 / 19.99 / 19.20;
+  // 2^18 gates: 10.94 / 10.92 / 11.01 / 11.44 — profiles/r04h) — a rank of a 2-GPU job at 2^20 gates or of an 8-GPU job at
+  // 2^22 holds 2^19 points.  PLONK_MSM_BUCKETS=15 / 19 forces one (17: the opt-in A/B build with the 2^17-bucket variant)
+  const bool can_large = table_rows == MSM_ROWS_BITPOS && bit_sums && tail_quad && !acc_lds;
+  int nb_bits = 15;
+  if (can_large) {
+    if (buckets_env == 17 || buckets_env == 19) nb_bits = buckets_env;
+    else if (buckets_env > 15) nb_bits = 19;
+    else if (buckets_env != 15) nb_bits = mmax > (1ull << 18) + 64 ? 19 : 15;
+  }
+  if (nb_bits == 19) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums);
+#ifdef PLONK_MSM_WITH_MEDIUM
+  if (nb_bits == 17) return nbm::msm_batch_device_v(c, bt, mmax, bit_sums);
+#else
+  if (nb_bits == 17) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums);
+#endif
+  return nb15::msm_batch_device_v(c, bt, mmax, bit_sums);
 }
 
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {

@@ -393,15 +393,20 @@ __global__ void __launch_bounds__(BIG_T) msm_big_hist_kernel(MsmBatch bt, const 
   const int kb = blockIdx.y;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
-  uint32_t bin, beg, end;
-  if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
   const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
   const uint32_t t = threadIdx.x;
-  if (t < (1u << FINE_BITS)) cnt[t] = 0;
-  __syncthreads();
-  for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[tmp.ld_fine(j)], 1u);
-  __syncthreads();
-  if (t < (1u << FINE_BITS) && cnt[t]) atomicAdd(&big_cnt_all[(uint64_t)kb * MSM_NB + (bin << FINE_BITS) + t], cnt[t]);
+  // a SMALL grid walks the chunk list (r04): the list is empty unless the digits are skewed, and one workgroup per POSSIBLE
+  // chunk (1 281 x 4 at 2^20 terms) cost 30-45 us of dispatch per launch for nothing
+  for (uint32_t item = blockIdx.x;; item += gridDim.x) {
+    uint32_t bin, beg, end;
+    if (!big_item(big, coff, item, &bin, &beg, &end)) return;   // uniform per workgroup
+    if (t < (1u << FINE_BITS)) cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t j = beg + t; j < end; j += BIG_T) atomicAdd(&cnt[tmp.ld_fine(j)], 1u);
+    __syncthreads();
+    if (t < (1u << FINE_BITS) && cnt[t]) atomicAdd(&big_cnt_all[(uint64_t)kb * MSM_NB + (bin << FINE_BITS) + t], cnt[t]);
+    __syncthreads();
+  }
 }
 template <class WordT>
 __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, const uint32_t* __restrict__ coarse_off_all,
@@ -413,45 +418,48 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
   const int kb = blockIdx.y;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
-  uint32_t bin, beg, end;
-  if (!big_item(big, coff, blockIdx.x, &bin, &beg, &end)) return;
   const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
   uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
-  const uint32_t* __restrict__ bcnt = big_cnt_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
-  uint32_t* __restrict__ bcur = big_cur_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
   const uint32_t t = threadIdx.x;
-  if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
-  __syncthreads();
-  WordT cache[BIG_PER];
-#pragma unroll
-  for (uint32_t r = 0; r < BIG_PER; ++r) {
-    const uint32_t j = beg + t + r * BIG_T;
-    cache[r] = j < end ? tmp.ld(j) : (WordT)0;
-    if (j < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
-  }
-  __syncthreads();
-  {   // bucket starts inside the bin from the bin-wide counts; this chunk's run in every bucket by one atomic each
-    const bool first = beg == coff[bin];
-    if (t < (1u << FINE_BITS)) bin_cnt[t] = bcnt[t];
+  for (uint32_t item = blockIdx.x;; item += gridDim.x) {   // small grid over the chunk list, see msm_big_hist_kernel
+    uint32_t bin, beg, end;
+    if (!big_item(big, coff, item, &bin, &beg, &end)) return;
+    const uint32_t* __restrict__ bcnt = big_cnt_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
+    uint32_t* __restrict__ bcur = big_cur_all + (uint64_t)kb * MSM_NB + (bin << FINE_BITS);
+    if (t < (1u << FINE_BITS)) { cnt[t] = 0; cur[t] = 0; }
     __syncthreads();
-    uint32_t total;
-    fine_exclusive_scan(bin_cnt, base, scan_tmp, &total);
-    if (t < (1u << FINE_BITS)) {
-      const uint32_t run = coff[bin] + base[t];
-      if (first) offsets[(bin << FINE_BITS) + t] = run;
-      base[t] = run + (cnt[t] ? atomicAdd(&bcur[t], cnt[t]) : 0u);
-    }
-    if (first && t == 0 && bin == COARSE - 1) offsets[MSM_NB] = coff[bin] + total;
-  }
-  __syncthreads();
+    WordT cache[BIG_PER];
 #pragma unroll
-  for (uint32_t r = 0; r < BIG_PER; ++r) {
-    if (beg + t + r * BIG_T < end) {
-      const WordT e = cache[r];
-      const uint32_t f = SortWord<WordT>::fine(e);
-      entries[base[f] + atomicAdd(&cur[f], 1u)] = SortWord<WordT>::entry(e);
+    for (uint32_t r = 0; r < BIG_PER; ++r) {
+      const uint32_t j = beg + t + r * BIG_T;
+      cache[r] = j < end ? tmp.ld(j) : (WordT)0;
+      if (j < end) atomicAdd(&cnt[SortWord<WordT>::fine(cache[r])], 1u);
     }
+    __syncthreads();
+    {   // bucket starts inside the bin from the bin-wide counts; this chunk's run in every bucket by one atomic each
+      const bool first = beg == coff[bin];
+      if (t < (1u << FINE_BITS)) bin_cnt[t] = bcnt[t];
+      __syncthreads();
+      uint32_t total;
+      fine_exclusive_scan(bin_cnt, base, scan_tmp, &total);
+      if (t < (1u << FINE_BITS)) {
+        const uint32_t run = coff[bin] + base[t];
+        if (first) offsets[(bin << FINE_BITS) + t] = run;
+        base[t] = run + (cnt[t] ? atomicAdd(&bcur[t], cnt[t]) : 0u);
+      }
+      if (first && t == 0 && bin == COARSE - 1) offsets[MSM_NB] = coff[bin] + total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < BIG_PER; ++r) {
+      if (beg + t + r * BIG_T < end) {
+        const WordT e = cache[r];
+        const uint32_t f = SortWord<WordT>::fine(e);
+        entries[base[f] + atomicAdd(&cur[f], 1u)] = SortWord<WordT>::entry(e);
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -469,17 +477,21 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
   HeavyItem* __restrict__ heavy_list = heavy_list_all + (uint64_t)blockIdx.x * MSM_NB;
   constexpr uint32_t PER = MSM_NB / SORT_T;
   const uint32_t t = threadIdx.x;
+  // the thread's PER + 1 bucket offsets in ONE batch of independent loads (r04: the two loops of dependent reads this
+  // replaces made the kernel 50 us of pure load latency — a third of the whole bucket sort of a 2^16-term group)
+  uint32_t o[PER + 1];
+#pragma unroll
+  for (uint32_t k = 0; k <= PER; ++k) o[k] = offsets[t * PER + k];
+  const uint32_t sh_ksl = 31u - (uint32_t)__builtin_clz(ksl);   // ksl is a power of two (msm_ksl)
   uint32_t mine = 0;
-  for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
-    mine += (c + ksl - 1) / ksl;
-  }
+#pragma unroll
+  for (uint32_t k = 0; k < PER; ++k) mine += (o[k + 1] - o[k] + ksl - 1) >> sh_ksl;
   uint32_t total;
   uint32_t run = block_exclusive_scan(mine, sh, &total);
+#pragma unroll
   for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
     slice_off[t * PER + k] = run;
-    const uint32_t ns = (c + ksl - 1) / ksl;
+    const uint32_t ns = (o[k + 1] - o[k] + ksl - 1) >> sh_ksl;
     run += ns;
     if (ns > heavy_thresh) {
       HeavyItem it;
@@ -683,7 +695,8 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
                      w.entries, w.offsets);
   {   // oversized bins (skewed digits): upper bound of the chunk count known on the host, surplus workgroups exit at once
     const uint64_t words = (uint64_t)MSM_W * mmax;
-    const uint32_t big_wgs = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
+    const uint32_t most = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
+    const uint32_t big_wgs = most < 512u ? most : 512u;   // the kernels stride over the chunk list
     HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
     hipLaunchKernelGGL(msm_big_hist_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp, w.big_cnt);
     hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp,

@@ -53,14 +53,18 @@ struct NttTables {
 // The bucket count is a COMPILE-TIME constant of the MSM kernels (msm.hip, msm_sort.hip), and those two files are compiled
 // twice: PLONK_MSM_NB_BITS = 15 (namespace nb15: 2^15 buckets, both recodings, every size) and a LARGE count (namespace
 // nbl: 2^19 — or 2^18 — buckets for bit-position tables and large MSMs: width-21 / -20 NAF digits, 12.1 / 12.6 additions
-// per scalar, one lane per bucket).
+// per scalar, one lane per bucket).  Round 4 built and measured a MEDIUM count too (namespace nbm: 2^17 buckets, width-19
+// digits, 13.2 additions per scalar; opt-in A/B build): at 2^19 terms it loses to 2^19 buckets and at 2^18 to 2^15.
 // msm_batch_device (msm.hip, compiled once) picks the variant per call; Ctx / MsmWork are shared and sized for the larger.
 #ifndef PLONK_MSM_NB_BITS
 #define PLONK_MSM_NB_BITS 15
 #endif
 #if PLONK_MSM_NB_BITS == 15
 #define PLONK_MSM_NS nb15
-#elif PLONK_MSM_NB_BITS >= 17 && PLONK_MSM_NB_BITS <= 19
+#elif PLONK_MSM_NB_BITS == 17
+#define PLONK_MSM_NS nbm          /* round 4 A/B build only (PLONK_BUILD_MSM_MEDIUM=1): 2^17 buckets, width-19 NAF digits (13.2 additions per
+                                     scalar).  Measured at 2^19 terms against 2^15 / 2^19 buckets: no size where it wins (profiles/r04*) */
+#elif PLONK_MSM_NB_BITS >= 18 && PLONK_MSM_NB_BITS <= 19
 #define PLONK_MSM_NS nbl          /* the "large" variant; 2^18 / 2^19 buckets are both built for A/B (tools/build_variants.sh) */
 #else
 #error "PLONK_MSM_NB_BITS must be 15 or 17..19"
@@ -159,8 +163,9 @@ struct Ctx {
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double acc_ms[8] = {0};
-  uint64_t acc_n[8] = {0};
+  static constexpr int PROF_SLOTS = 32;   // 0-7: the bench line's slots; 16-21 / 24-29: MSM phases of groups of >= 3 / <= 2 commitments (PLONK_PROF_FINE=1)
+  double acc_ms[PROF_SLOTS] = {0};
+  uint64_t acc_n[PROF_SLOTS] = {0};
 };
 
 // ntt.hip
@@ -212,6 +217,9 @@ static constexpr int MSM_BIT_SUMS = 12 + 9;          // slots per commitment (th
   bool msm_needs_wide_words(uint32_t rows, uint64_t table_n);                                                            \
   int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums);
 namespace nb15 { PLONK_MSM_VARIANT_DECLS }
+#ifdef PLONK_MSM_WITH_MEDIUM
+namespace nbm { PLONK_MSM_VARIANT_DECLS int msm_buckets_bits(); }
+#endif
 namespace nbl { PLONK_MSM_VARIANT_DECLS int msm_buckets_bits(); }
 // table == nullptr: the context's commit key; otherwise tables built by srs_table_build (same layout, table_rows rows).
 // c->msm.last_rowbits tells the caller how the bit sums of THIS call are laid out (finish_bit_sums).

@@ -1118,27 +1118,43 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
 
   uint8_t comm[11][48];
   // ---- round 1 (replicated polynomials, sharded commitments)
-  prof_begin(c, 4);   // slot 4: replicated polynomial work (rounds 1-2)
-  for (int k = 0; k < 4; ++k) {
-    Fr* wp = p->wpoly + k * np;
-    if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
-    PTRY(ntt_device(c, wires_dev + k * n, wp, p->tmp8, L, true, false, n));
-    BlindArgs ba;
-    ba.count = 2;
-    ba.b[0] = bl[2 * k];
-    ba.b[1] = bl[2 * k + 1];
-    PTRY(poly_fill_zero(c, wp + n, np - n));
-    PTRY(poly_blind(c, wp, n, ba));
-  }
-  prof_end(c, 4);
+  const bool lag = p->lag_on;
+  // iNTT + blinding of the four columns and their lowest coefficients (quotient_low), on the CURRENT stream
+  auto wire_polynomials = [&](Fr* ntt_tmp) -> int {
+    prof_begin(c, 4);   // slot 4: replicated polynomial work (rounds 1-2)
+    for (int k = 0; k < 4; ++k) {
+      Fr* wp = p->wpoly + k * np;
+      if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
+      PTRY(ntt_device(c, wires_dev + k * n, wp, ntt_tmp, L, true, false, n));
+      BlindArgs ba;
+      ba.count = 2;
+      ba.b[0] = bl[2 * k];
+      ba.b[1] = bl[2 * k + 1];
+      PTRY(poly_fill_zero(c, wp + n, np - n));
+      PTRY(poly_blind(c, wp, n, ba));
+    }
+    prof_end(c, 4);
+    for (int k = 0; k < 4; ++k)
+      HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    return PLONK_OK;
+  };
+  // Round 4 (r04): the schedule of the single-GPU path for a RANK.  With the Lagrange-basis slice the wire commitments read
+  // the wire VALUES, so the replicated wire polynomials (needed from round 3 on) ride on the side stream under the
+  // commitment pipeline — a rank's MSM over 1/W of the points leaves most of the chip idle in its latency-bound sort and
+  // reduction tail (W = 8 at 2^20: 1.4 of the rank's 7.7 ms were these transforms in front of the commitment).  The side
+  // work starts after the group's accumulation (side_defer) while the rank's share is small; PLONK_SHARD_SIDE=0 restores
+  // the round-3 order.
+  static const bool shard_side_env = [] { const char* e = getenv("PLONK_SHARD_SIDE"); return !(e && e[0] == '0'); }();
+  const uint64_t rank_pts = hi - lo;
+  const bool polys_on_side = lag && shard_side_env && rank_pts <= (1ull << 18) + 64;   // (2^19 points per rank: 19.2 -> 19.4 ms, the accumulation owns the VALU)
+  const bool side_defer = shard_side_env && rank_pts <= (1ull << 18) + 64;
+  if (!polys_on_side) PTRY(wire_polynomials(p->tmp8));
   SideJoin side_join{c};
   uint64_t pi_len = 0;
-  for (int k = 0; k < 4; ++k)
-    HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   Fr* fold_side = p->fold + n;
-  {
+  auto side_round1 = [&]() -> int {
     // class evaluations of a, b, c, d, PI on the side stream: fold mod (X^n - x^n|class), size-n coset transform
-    SideScope side(c, p->ev_ready);
+    if (polys_on_side) PTRY(wire_polynomials(p->tmp8b));
     for (uint32_t k = 0; k < cpr; ++k)
       for (int w = 0; w < 4; ++w) {
         PTRY(poly_fold(c, p->wpoly + w * np, fold_side, n, 2, p->sigma_j[p->cls[k]]));
@@ -1154,27 +1170,41 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     if (pi_len)
       for (uint32_t k = 0; k < cpr; ++k)
         PTRY(ntt_device(c, p->pipoly, p->cos + 5 * qn + k * n, p->tmp8b, L, false, true, n, &p->cs_fwd[k]));
+    return PLONK_OK;
+  };
+  if (!side_defer) {
+    SideScope side(c, p->ev_ready);
+    PTRY(side_round1());
   }
-  if (p->lag_on) {
-    // wire commitments from the wire VALUES over this rank's slice of the Lagrange-basis key (see prover_prove): values
-    // [lo_L, hi_L) of each column in place, the column's two blinders for the slice that reaches indices n, n + 1
-    const uint64_t lo_l = p->shard_lo, hi_l = p->shard_lo + p->lag_n;       // hi_l <= n + 2
-    HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
-    const Fr* sc[4];
-    const Fr* tl[4];
-    uint64_t ms[4], sp[4];
-    for (int k = 0; k < 4; ++k) {
-      sc[k] = wires_dev + (uint64_t)k * n + (lo_l < n ? lo_l : 0);
-      sp[k] = lo_l < n ? n - lo_l : 0;                                      // scalars of the slice below index n
-      if (sp[k] > p->lag_n) sp[k] = p->lag_n;
-      tl[k] = p->wscal + 2 * k + (lo_l > n ? lo_l - n : 0);                 // blinder b_(index - n)
-      ms[k] = hi_l - lo_l;
+  {
+    AccMark mark(c, side_defer ? p->ev_acc : nullptr);
+    if (lag) {
+      // wire commitments from the wire VALUES over this rank's slice of the Lagrange-basis key (see prover_prove): values
+      // [lo_L, hi_L) of each column in place, the column's two blinders for the slice that reaches indices n, n + 1
+      const uint64_t lo_l = p->shard_lo, hi_l = p->shard_lo + p->lag_n;       // hi_l <= n + 2
+      for (int k = 0; k < 4; ++k)
+        if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));
+      HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+      const Fr* sc[4];
+      const Fr* tl[4];
+      uint64_t ms[4], sp[4];
+      for (int k = 0; k < 4; ++k) {
+        sc[k] = wires_dev + (uint64_t)k * n + (lo_l < n ? lo_l : 0);
+        sp[k] = lo_l < n ? n - lo_l : 0;                                      // scalars of the slice below index n
+        if (sp[k] > p->lag_n) sp[k] = p->lag_n;
+        tl[k] = p->wscal + 2 * k + (lo_l > n ? lo_l - n : 0);                 // blinder b_(index - n)
+        ms[k] = hi_l - lo_l;
+      }
+      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp));
+    } else {
+      const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
+      const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
+      PTRY(msm_group(p, sc, ms, 4, 0));
     }
-    PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp));
-  } else {
-    const Fr* sc[4] = {p->wpoly, p->wpoly + np, p->wpoly + 2 * np, p->wpoly + 3 * np};
-    const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
-    PTRY(msm_group(p, sc, ms, 4, 0));
+  }
+  if (side_defer) {
+    SideScopeAfter side(c, p->ev_acc);
+    PTRY(side_round1());
   }
   PTRY(fetch_commitments(p, 0, 4, comm));
   tr.append_commitment("a_comm", comm[0]);
@@ -1209,15 +1239,26 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     prof_end(c, 4);
   }
   HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-  {
-    SideScope side(c, p->ev_ready);
+  auto side_round2 = [&]() -> int {
     for (uint32_t k = 0; k < cpr; ++k) {
       PTRY(poly_fold(c, p->zpoly, fold_side, n, 3, p->sigma_j[p->cls[k]]));
       PTRY(ntt_device(c, fold_side, p->cos + k * n, p->tmp8b, L, false, true, n, &p->cs_fwd[k]));
     }
     HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+    return PLONK_OK;
+  };
+  if (!side_defer) {
+    SideScope side(c, p->ev_ready);
+    PTRY(side_round2());
   }
-  PTRY(msm_to(p, p->zpoly, n + 3, 4));
+  {
+    AccMark mark(c, side_defer ? p->ev_acc : nullptr);
+    PTRY(msm_to(p, p->zpoly, n + 3, 4));
+  }
+  if (side_defer) {
+    SideScopeAfter side(c, p->ev_acc);
+    PTRY(side_round2());
+  }
   PTRY(fetch_commitments(p, 4, 1, comm + 4));
   tr.append_commitment("z_comm", comm[4]);
 

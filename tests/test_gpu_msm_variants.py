@@ -25,6 +25,7 @@ def run_variant(env_extra, select=SELECT, marker="gpu", target="tests/test_gpu_m
     {"PLONK_MSM_TABLE": "bitpos"},                               # a table row per bit position, width-17 NAF digits, 2^15 buckets
     {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"},    # width-21 NAF digits over 2^19 buckets (the default above 2^19 terms)
     {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_ORDER": "0"},
+    {"PLONK_MSM_BSUM": "lane"},    # one lane per bucket in msm_bucket_sum instead of a quad (small MSMs)
 ], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_variant_matches_the_oracle_on_the_edge_cases(variant):
     r = run_variant(variant)

@@ -67,6 +67,18 @@ def test_sharded_prove_matches_single_gpu_at_2p20(ranks):
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
+@pytest.mark.slow
+def test_sharded_prove_matches_single_gpu_at_2p22():
+    """BASELINE config 5's shape: 2^22 gates over W = 8 ranks (Q = 8 classes; 2^19 + 1 commit-key points per rank, each rank
+    streaming only its own range from pinned host memory).  The eight ranks share this box's one GPU; the sharded proof must
+    be the single-GPU proof byte for byte — whose bytes tests/test_gpu_fullsize.py compares with the C oracle."""
+    s = single(22, "dense")
+    m = _run([sys.executable, "bench.py", "--gpus", "8", "--log-gates", "22", "--steps", "1", "--warmup", "0", "--no-extras"],
+             {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1"})
+    assert m["n_gpus"] == 8 and m["config"]["collective"] == "gloo"
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
 def test_self_launcher_starts_the_ranks_on_the_gpu_path():
     """`python bench.py --gpus 2` with no launcher in front of it (how the driver starts the bench): two ranks, the
     single-GPU proof"""
