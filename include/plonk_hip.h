@@ -254,8 +254,9 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  *
  * Environment: this platform's driver only supports dmabuf IPC, so RCCL between processes needs
  * HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment before the HSA runtime starts (the first HIP call of the process).
- * The library sets it when it is LOADED unless the host program already chose a value; a host that initialises HIP
- * before loading libplonk_hip.so must export it itself.
+ * The HOST PROGRAM exports it before its first HIP call (bench.py and the Python binding do); the library does not touch the
+ * process environment.  plonk_comm_init names the variable in its error text when the communicator cannot be created
+ * without it.
  *
  * Failure of a peer: a sharded proof is a sequence of collectives, and a rank that fails (or never arrives) would
  * leave the others waiting inside one.  Every wait that follows a collective polls the stream instead of blocking; after
@@ -264,10 +265,11 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  * (plonk_comm_init) before the next sharded proof.  The host program should still tear the job down when one rank
  * reports an error (bench.py does: the launcher kills the remaining ranks).
  *
- * Measurement aid, never for production: with PLONK_COMM_LOOPBACK=1 in the environment every collective of a sharded prover
- * returns the rank's own contribution in its peers' places (local copies, no transport), so that one rank of a W-rank job can
- * be timed alone on one GPU (tools/rank_alone.py).  Proofs made that way are wrong by construction: plonk_prover_prove*
- * returns PLONK_ERR_UNSAT from its final identity check. */
+ * Measurement aid, never for production: after plonk_comm_measure_loopback(ctx, 1) every collective of a sharded prover on
+ * THIS context returns the rank's own contribution in its peers' places (local copies, no transport), so that one rank of a
+ * W-rank job can be timed alone on one GPU (tools/rank_alone.py).  Proofs made that way are wrong by construction:
+ * plonk_prover_prove* returns PLONK_ERR_UNSAT from its final identity check.  Nothing in the environment switches it on. */
+int plonk_comm_measure_loopback(plonk_ctx* ctx, int on);
 int plonk_comm_unique_id(uint8_t out[128]);
 int plonk_comm_init(plonk_ctx* ctx, const uint8_t unique_id[128], int rank, int world);
 int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world);

@@ -17,6 +17,10 @@ import ctypes
 import os
 from typing import Iterable, Sequence
 
+# dmabuf IPC: RCCL between processes needs it on this platform's driver, and it must be in the environment before the
+# first HIP call of the process — the host program's job (include/plonk_hip.h, "Multi-GPU"); this binding is that host
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PLONK_HIP_LIB") or os.path.join(_HERE, "lib", "libplonk_hip.so")   # override: A/B builds
 
@@ -47,6 +51,7 @@ EXPORTS = [
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_info", "plonk_comm_selftest", "plonk_comm_destroy",
+    "plonk_comm_measure_loopback",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
     "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
     "plonk_public_parameters_check", "plonk_srs_load_public_parameters",
@@ -188,6 +193,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_comm_selftest.argtypes = [vp]
     lib.plonk_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.plonk_comm_destroy.argtypes = [vp]
+    lib.plonk_comm_measure_loopback.argtypes = [vp, ci]
     _lib = lib
     return lib
 
@@ -487,6 +493,10 @@ class Context:
 
     def comm_destroy(self):
         self._check(self.lib.plonk_comm_destroy(self.handle))
+
+    def comm_measure_loopback(self, on: bool = True):
+        """MEASUREMENT ONLY (tools/rank_alone.py): collectives of this context return the rank's own contribution."""
+        self._check(self.lib.plonk_comm_measure_loopback(self.handle, int(on)))
 
     def profile(self, on: bool):
         self._check(self.lib.plonk_profile_enable(self.handle, int(on)))

@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include <string>
+
 #include "plonk_internal.hpp"
 
 namespace plonk {
@@ -78,9 +80,9 @@ static constexpr size_t COMM_STAGE = 16384;   // bytes per rank of a small (host
 // The host driver of this platform only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment
 // BEFORE the HSA runtime starts, RCCL's device-memory exchange between processes fails (hipIpcGetMemHandle: invalid
 // argument).  The variable is read when the runtime initialises — normally the first HIP call of the process — so it is
-// set when this library is loaded; a value the host program has already chosen is left alone.  A host that initialises
-// HIP before loading libplonk_hip.so has to export it itself (include/plonk_hip.h, "Multi-GPU").
-__attribute__((constructor)) static void comm_default_ipc_mode() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
+// the HOST PROGRAM has to export it before its first HIP call (bench.py and the Python binding do; include/plonk_hip.h,
+// "Multi-GPU").  The library no longer touches the process environment when it is loaded (round 3 did, from a
+// constructor): plonk_comm_init only REPORTS a missing variable when the communicator cannot be created.
 
 // Wait for the main stream after a collective was queued on it.  A rank that failed (or never arrived) leaves its peers
 // inside the collective for ever, and a plain hipStreamSynchronize would hang with them: with a communicator the stream
@@ -103,6 +105,9 @@ int comm_sync(Ctx* c, hipStream_t st) {
       RcclApi* api = rccl_api();
       if (api && api->CommAbort) (void)api->CommAbort((ncclComm_t)c->nccl_comm);
       c->nccl_comm = nullptr;   // aborted: the context falls back to "no communicator" and every later sharded call fails loudly
+      // the abort releases the collective's kernel; what was queued BEHIND it on this stream (copies into caller-owned host
+      // buffers) must not still be running when the error reaches the caller
+      (void)hipStreamSynchronize(st);
       set_last_error("comm_sync", "collective timed out (a peer rank failed or never joined): communicator aborted", __FILE__, __LINE__);
       return PLONK_ERR_STATE;
     }
@@ -111,18 +116,17 @@ int comm_sync(Ctx* c, hipStream_t st) {
 
 // All-gather of `bytes` host bytes per rank; recv is rank-major.  RCCL when the context has a
 // communicator (staged through device buffers on the main stream), else the host callback.
-// PLONK_COMM_LOOPBACK=1 — MEASUREMENT ONLY (tools/rank_alone.py): every collective hands a rank its own contribution back in
-// place of its peers', with local copies and no transport, so that ONE rank of a W-rank job can be timed alone on one GPU
-// (its kernels, its share of the points and coefficients, the same host sequence).  The values exchanged are wrong by
-// construction: prove() ends in PLONK_ERR_UNSAT at its final identity check, after all of its work.
-static bool comm_loopback() {
-  static const bool on = [] { const char* e = getenv("PLONK_COMM_LOOPBACK"); return e && e[0] == '1'; }();
-  return on;
-}
+// Loop-back — MEASUREMENT ONLY (tools/rank_alone.py): every collective hands a rank its own contribution back in place of
+// its peers', with local copies and no transport, so that ONE rank of a W-rank job can be timed alone on one GPU (its
+// kernels, its share of the points and coefficients, the same host sequence).  The values exchanged are wrong by
+// construction: prove() ends in PLONK_ERR_UNSAT at its final identity check, after all of its work.  Enabled per context by
+// an explicit call (plonk_comm_measure_loopback); an environment variable alone no longer switches it on (round 3's
+// PLONK_COMM_LOOPBACK made every collective of a production process silently local).
+static bool comm_loopback(const Ctx* c) { return c->comm_loopback; }
 
 int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes) {
   if (l.world <= 1) { memcpy(recv, send, bytes); return PLONK_OK; }
-  if (comm_loopback()) {
+  if (comm_loopback(c)) {
     for (int r = 0; r < l.world; ++r) memcpy((uint8_t*)recv + bytes * (size_t)r, send, bytes);
     return PLONK_OK;
   }
@@ -147,7 +151,7 @@ int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* rec
     HIP_TRY(hipMemcpyAsync(recv_dev, send_dev, bytes_per_peer, hipMemcpyDeviceToDevice, c->main_stream));
     return PLONK_OK;
   }
-  if (comm_loopback()) {
+  if (comm_loopback(c)) {
     for (int src = 0; src < l.world; ++src)
       HIP_TRY(hipMemcpyAsync((uint8_t*)recv_dev + bytes_per_peer * (size_t)src, (const uint8_t*)send_dev + bytes_per_peer * (size_t)l.rank,
                              bytes_per_peer, hipMemcpyDeviceToDevice, c->main_stream));
@@ -178,6 +182,13 @@ using namespace plonk;
 
 extern "C" {
 
+int plonk_comm_measure_loopback(plonk_ctx* ctx, int on) {
+  if (!ctx) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  ctx->c.comm_loopback = on != 0;
+  return PLONK_OK;
+}
+
 int plonk_comm_unique_id(uint8_t out[128]) {
   if (!out) return PLONK_ERR_ARG;
   RcclApi* api = rccl_api();
@@ -200,7 +211,17 @@ int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int worl
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclComm_t comm = nullptr;
-  RCCL_TRY(api, api->CommInitRank(&comm, world, id, rank));
+  {
+    const ncclResult_t r = api->CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) {
+      const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+      std::string msg = api->GetErrorString ? api->GetErrorString(r) : "rccl error";
+      if (world > 1 && !(ipc && ipc[0] == '0'))
+        msg += " (HSA_ENABLE_IPC_MODE_LEGACY=0 is not in the environment: on a dmabuf-only driver the host program must export it before its first HIP call)";
+      set_last_error("ncclCommInitRank", msg.c_str(), __FILE__, __LINE__);
+      return PLONK_ERR_HIP;
+    }
+  }
   hipError_t e = hipMalloc((void**)&c.comm_send, COMM_STAGE);
   if (e == hipSuccess) e = hipMalloc((void**)&c.comm_recv, COMM_STAGE * (size_t)world);
   if (e != hipSuccess) {

@@ -160,6 +160,7 @@ struct Ctx {
   uint8_t* comm_send = nullptr;
   uint8_t* comm_recv = nullptr;
   int comm_rank = 0, comm_world = 1;
+  bool comm_loopback = false;      // measurement only: collectives return the rank's own contribution (plonk_comm_measure_loopback)
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -9,6 +9,7 @@
 // the padded wire columns and the 11 blinding scalars in the reference's draw order.
 #include <cstdlib>
 #include <cstring>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -206,22 +207,26 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
 // way the wire commitments use it: for pseudo-random values r_0 .. r_{n+1},
 //     sum_{i<n} r_i [L_i(tau)] G + r_n ([tau^n] G - G) + r_{n+1} ([tau^(n+1)] G - [tau] G)   (an MSM over the supplied key)
 // must be the commitment of interpolate(r_0 .. r_{n-1}) + (r_n + r_{n+1} X)(X^n - 1) over the context's key — one inverse
-// transform and two MSMs, once per prover.  A wrong point survives with probability ~2^-64 (the r_i are 64-bit).
-__device__ __host__ static inline uint64_t lag_check_mix(uint64_t i) {
-  uint64_t x = (i + 1) * 0x9e3779b97f4a7c15ull;
+// transform and two MSMs, once per prover.  The r_i are 64-bit values derived from the index AND a per-check seed drawn
+// from the operating system's entropy source (std::random_device) — with a fixed public mix (round 3) a crafted key could
+// cancel its errors against known coefficients; with the seed a wrong point survives with probability ~2^-64.
+__device__ __host__ static inline uint64_t lag_check_mix(uint64_t i, uint64_t seed) {
+  uint64_t x = (i + 1) * 0x9e3779b97f4a7c15ull ^ seed;
   x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
   return x | 1ull;
 }
-__global__ void lag_check_fill_kernel(Fr* r, uint64_t count) {
+__global__ void lag_check_fill_kernel(Fr* r, uint64_t count, uint64_t seed) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) r[i] = Fr::from_u64(lag_check_mix(i));
+  if (i < count) r[i] = Fr::from_u64(lag_check_mix(i, seed));
 }
 static int check_lagrange_key(Prover* p, uint32_t L) {
   Ctx* c = p->c;
   const uint64_t n = 1ull << L;
   Fr* r = p->agg;        // n + 2 values
   Fr* coef = p->wit;     // n + 2 coefficients
-  hipLaunchKernelGGL(lag_check_fill_kernel, dim3((uint32_t)((n + 2 + 255) / 256)), dim3(256), 0, c->stream, r, n + 2);
+  std::random_device rd;
+  const uint64_t seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)rd() << 17);
+  hipLaunchKernelGGL(lag_check_fill_kernel, dim3((uint32_t)((n + 2 + 255) / 256)), dim3(256), 0, c->stream, r, n + 2, seed);
   HIP_TRY(hipGetLastError());
   uint64_t m = n + 2;
   const Fr* sc = r;
@@ -229,8 +234,8 @@ static int check_lagrange_key(Prover* p, uint32_t L) {
   PTRY(ntt_device(c, r, coef, p->wit2, L, true, false, n));
   BlindArgs ba;
   ba.count = 2;
-  ba.b[0] = Fr::from_u64(lag_check_mix(n));
-  ba.b[1] = Fr::from_u64(lag_check_mix(n + 1));
+  ba.b[0] = Fr::from_u64(lag_check_mix(n, seed));
+  ba.b[1] = Fr::from_u64(lag_check_mix(n + 1, seed));
   ba.b[2] = Fr::zero();
   PTRY(poly_blind(c, coef, n, ba));     // coef -= (b0 + b1 X), coef[n], coef[n + 1] = b0, b1: + (b0 + b1 X)(X^n - 1)
   PTRY(msm_to(p, coef, n + 2, 1));
@@ -247,7 +252,10 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
   Ctx* c = p->c;
   HIP_TRY(hipMemcpyAsync(p->res_host + RES_STRIDE * first, p->res + RES_STRIDE * first, RES_STRIDE * (size_t)count,
                          hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // a sharded proof queues collectives on this stream (the quotient's all-to-all precedes the t commitments): never a
+  // blocking wait behind one — comm_sync polls and aborts the communicator on time-out (a dead peer must not hang the rest)
+  if (p->world > 1) PTRY(comm_sync(c, c->stream));
+  else HIP_TRY(hipStreamSynchronize(c->stream));
   std::vector<G1> sums(count);
   for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)), p->res_rowbits[first + i], p->res_bitpos[first + i]);
   if (p->world > 1) {

@@ -162,7 +162,7 @@ def test_comm_api_misuse_is_refused():
 
 @pytest.mark.gpu
 def test_rank_alone_measurement_tool_runs_and_ends_in_the_identity_check():
-    """tools/rank_alone.py (PLONK_COMM_LOOPBACK=1: a rank's own contribution in its peers' places) — the per-rank times of
+    """tools/rank_alone.py (plonk_comm_measure_loopback: a rank's own contribution in its peers' places) — the per-rank times of
     DESIGN.md section 5 come from it.  Every sharded proof made that way must fail at the FINAL quotient-identity check
     (PLONK_ERR_UNSAT), i.e. after all of the rank's work; the tool asserts that and never calls the transport callback."""
     import json

@@ -1,5 +1,5 @@
 """ONE rank of a W-rank sharded proof timed alone on one GPU (measure the per-rank critical path instead of
-modelling it).  PLONK_COMM_LOOPBACK=1 makes every collective return the rank's own contribution in its peers' places with
+modelling it).  plonk_comm_measure_loopback(ctx, 1) makes every collective return the rank's own contribution in its peers' places with
 local copies, so the rank runs exactly its kernels over its share of the points and coefficients and the same host sequence;
 what is NOT in the number is the transport itself (6 small all-gathers + one all-to-all per proof over xGMI) and waiting for
 slower peers.  The proofs are wrong by construction: prove() must end in PLONK_ERR_UNSAT at its final identity check.
@@ -10,7 +10,6 @@ import os
 import sys
 import time
 
-os.environ["PLONK_COMM_LOOPBACK"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
@@ -20,6 +19,7 @@ from oracle.bls12_381 import Q  # noqa: E402
 
 def run(log_n, world, rank, steps):
     ctx = plonk_amd.Context(0)
+    ctx.comm_measure_loopback(True)
     blinders = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
     calls = [0]
 
