@@ -559,6 +559,8 @@ def main():
         # of ~24 entries per bucket), w = 17 over 2^15 buckets below
         if table_rows == 16:
             digits_per_scalar = 16.0 - 0.5
+        elif table_rows == 128:   # even-position digits (a row for every second bit position), w = 20 over 2^19 buckets above 2^18 terms
+            digits_per_scalar = round(254.86 / (20 + 2 / 3) + 0.5 - (1 << 19) / max(m_local, 1), 2) if m_local > (1 << 18) + 64 else 15.8 - 0.5
         elif m_local > (1 << 19) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":
             digits_per_scalar = round(254.86 / 22 + 0.5 - (1 << 19) / max(m_local, 1), 2)
         elif m_local > (1 << 18) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":   # w = 19 over 2^17 buckets

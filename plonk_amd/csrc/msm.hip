@@ -129,7 +129,7 @@ __device__ __forceinline__ G1R g1r_neg(const G1R& p) {   // -P: Y -> 16p - Y (Y 
 // timed region.  `pts` holds points [first, first + count) of the key (a chunk of the stream in plonk_srs_load); row r
 // starts at r * n.  scratch: [(rows - 1) * 3][count] slots.
 static uint64_t srs_table_chunk_points(uint32_t rows) {   // points per launch: bounds the scratch (720 MiB / 3.1 GiB)
-  return rows == MSM_ROWS_BITPOS ? 1ull << 16 : 1ull << 18;
+  return rows == MSM_ROWS_WINDOW ? 1ull << 18 : 1ull << 16;
 }
 __global__ void srs_table_kernel(const G1Affine* __restrict__ pts, G1AffineR* __restrict__ table, uint64_t n,
                                  uint64_t first, uint64_t count, Fp28Slot* __restrict__ scratch, uint32_t rows, uint32_t step) {
@@ -943,6 +943,7 @@ uint32_t msm_table_rows(uint64_t n) {
   if (const char* e = getenv("PLONK_MSM_TABLE")) {
     if (e[0] == 'w') return MSM_ROWS_WINDOW;
     if (e[0] == 'b') return (uint64_t)MSM_ROWS_BITPOS * n <= (1ull << 31) ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
+    if (e[0] == 'h') return MSM_ROWS_HALFPOS;   // a row for every second bit position (round 4)
   }
   if ((uint64_t)MSM_ROWS_BITPOS * n > (1ull << 31)) return MSM_ROWS_WINDOW;   // 31-bit table index of an entry
   // small keys: the saved additions do not pay for the longer recoding, the skewed top digit and — with the 2^19-bucket
@@ -953,8 +954,15 @@ uint32_t msm_table_rows(uint64_t n) {
   if (n <= (1ull << 18) + 64) return MSM_ROWS_WINDOW;
   size_t fr = 0, tot = 0;
   if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MSM_ROWS_WINDOW;
-  const uint64_t need = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_BITPOS * n + sizeof(Fp28Slot) * 3 * (MSM_ROWS_BITPOS - 1) * (1ull << 16);
-  return need <= fr / 2 ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
+  const uint64_t scratch = sizeof(Fp28Slot) * 3 * (MSM_ROWS_BITPOS - 1) * (1ull << 16);
+  const uint64_t need = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_BITPOS * n + scratch;
+  if (need <= fr / 2) return MSM_ROWS_BITPOS;
+  // no room for a row per bit (the Lagrange-basis key of a 2^22-gate circuit beside the commit key's 137 GB): a row for
+  // every SECOND bit position is half the memory and 12.8 instead of 16 additions per scalar (round 4, msm_recode.cuh
+  // for_each_digit_even).  It may take most of what is left: the key is built last (prover.hip) and nothing else grows.
+  const uint64_t need_half = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_HALFPOS * n + scratch / 2;
+  if (need_half <= fr / 10 * 7) return MSM_ROWS_HALFPOS;
+  return MSM_ROWS_WINDOW;
 }
 static int table_index_check(uint32_t rows, uint64_t n) {
   if ((uint64_t)rows * n > (1ull << 31)) return (plonk::set_last_error("invalid argument", "commit key: table rows * points must be <= 2^31 (31-bit table index of an entry)", __FILE__, __LINE__), PLONK_ERR_ARG);
@@ -988,7 +996,7 @@ void srs_table_scratch_free(Ctx* c) {   // after the stream that ran the table k
 // stream: the launches share one scratch array and rely on stream order)
 static int srs_table_launch(Ctx* c, const G1Affine* pts_dev, G1AffineR* table, uint32_t rows, uint64_t n, uint64_t first, uint64_t count, hipStream_t st) {
   const uint64_t chunk = srs_table_chunk_points(rows);
-  const uint32_t step = rows == MSM_ROWS_BITPOS ? 1u : (uint32_t)MSM_C;
+  const uint32_t step = rows == MSM_ROWS_BITPOS ? 1u : (rows == MSM_ROWS_HALFPOS ? 2u : (uint32_t)MSM_C);
   for (uint64_t off = 0; off < count; off += chunk) {
     const uint64_t cnt = count - off < chunk ? count - off : chunk;
     const int rc = srs_table_scratch(c, 3ull * (rows - 1) * cnt);
@@ -1493,7 +1501,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   if (count <= 0) return PLONK_OK;
   if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   if (!table) { table = c->srs_table; table_n = c->srs_n; table_rows = c->srs_rows; }
-  if (table && table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_BITPOS) return (plonk::set_last_error("invalid argument", "msm: table rows", __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (table && table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_BITPOS && table_rows != MSM_ROWS_HALFPOS) return (plonk::set_last_error("invalid argument", "msm: table rows", __FILE__, __LINE__), PLONK_ERR_ARG);
   uint64_t mmax = 0;
   for (int k = 0; k < count; ++k) {
     if (m[k] > table_n) return PLONK_ERR_DEGREE;
@@ -1531,7 +1539,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   // 2^19 (same box, 2^19 gates: window rows 19.94 ms, bit-position rows over 2^15 / 2^17 / 2^19 buckets 21.31 / 19.99 / 19.20;
   // 2^18 gates: 10.94 / 10.92 / 11.01 / 11.44 — profiles/r04h) — a rank of a 2-GPU job at 2^20 gates or of an 8-GPU job at
   // 2^22 holds 2^19 points.  PLONK_MSM_BUCKETS=15 / 19 forces one (17: the opt-in A/B build with the 2^17-bucket variant)
-  const bool can_large = table_rows == MSM_ROWS_BITPOS && bit_sums && tail_quad && !acc_lds;
+  const bool can_large = (table_rows == MSM_ROWS_BITPOS || table_rows == MSM_ROWS_HALFPOS) && bit_sums && tail_quad && !acc_lds;
   int nb_bits = 15;
   if (can_large) {
     if (buckets_env == 17 || buckets_env == 19) nb_bits = buckets_env;

@@ -21,7 +21,7 @@
 namespace plonk {
 
 static constexpr int MSM_DIGITS = 16;          // most non-zero digits of a scalar under either recoding (= MSM_W)
-static constexpr uint32_t MSM_ROWS_WINDOW = 16, MSM_ROWS_BITPOS = 256;
+static constexpr uint32_t MSM_ROWS_WINDOW = 16, MSM_ROWS_BITPOS = 256, MSM_ROWS_HALFPOS = 128;
 static constexpr uint32_t MSM_NAF_W = 17;      // digit width of the bit-position recoding over 2^15 buckets: odd |d| < 2^16
 
 // Signed 16-bit windows, least significant first (carry into the next window when the value exceeds 2^15).
@@ -101,9 +101,44 @@ HD void for_each_digit_naf(const S& s, F&& f) {
 template <class S, class F>
 HD void for_each_digit_bitpos(const S& s, F&& f) { for_each_digit_naf<MSM_NAF_W>(s, f); }
 
+// Half-density tables (round 4): a row for every EVEN bit position, T[r][i] = 2^(2 r) * P_i, r < 128 — half the memory of
+// the bit-position tables (16 KiB per point), for keys whose 256 rows do not fit beside everything else (the Lagrange-basis
+// key of a 2^22-gate circuit next to the commit key's 137 GB).  A digit may start at even positions only: it is taken where
+// the remaining value (s >> p) + carry is NOT a multiple of 4, W bits wide (W even), signed: d in [-2^(W-1), 2^(W-1)],
+// d != 0 mod 4, so digits are odd or 2 * odd and the bucket is |d| - 1 with weight bucket + 1 — the WINDOW convention (no
+// "2 W - S").  After a digit the next W bits are consumed and the run of 2-bit groups equal to the carry that follows has
+// mean length 1/3: 254.9 / (W + 2/3) + 1/2 digits per scalar — 12.8 for W = 20 over 2^19 buckets (a row per bit: 12.1;
+// window rows: 16), 15.8 for W = 16 over 2^15.  The remaining value is a multiple of 4 exactly where the 2-bit group at p
+// equals (carry, carry).  As in the NAF above the last two digits share the remaining bits (even widths), and no digit
+// starts above bit 254: a digit at p >= 256 - W has no bit above 254 to read (s < 2^255), is positive and leaves no carry.
+template <uint32_t W, class S, class F>
+HD void for_each_digit_even(const S& s, F&& f) {
+  static_assert(W % 2 == 0 && W >= 4 && W <= 22, "even digit width");
+  uint32_t p = 0, carry = 0;
+#pragma unroll
+  for (int j = 0; j < MSM_DIGITS; ++j) {
+    const uint32_t flip = 0u - carry;
+    while (p < 256) {                                  // next 2-bit group that differs from (carry, carry)
+      const uint32_t x = bits32_at(s, p) ^ flip;
+      if (x) { p += (uint32_t)__builtin_ctz(x) & ~1u; break; }
+      p += 32;
+    }
+    if (p >= 256) break;
+    const uint32_t rem = 256u - p;
+    const uint32_t w = (rem > W && rem <= 2 * W) ? ((rem / 2 + 1) & ~1u) : W;     // even, >= rem / 2
+    const uint32_t v = (bits32_at(s, p) & ((1u << w) - 1u)) + carry;   // in [1, 2^w), not a multiple of 4
+    const uint32_t neg = v > (1u << (w - 1)) ? 1u : 0u;                // the digit is v - 2^w
+    const uint32_t mag = neg ? (1u << w) - v : v;                      // in [1, 2^(w-1)]
+    f(j, p >> 1, mag - 1u, neg);
+    carry = neg;
+    p += w;
+  }
+}
+
 template <class S, class F>
 HD void for_each_digit(const S& s, uint32_t rows, F&& f) {
   if (rows == MSM_ROWS_BITPOS) for_each_digit_bitpos(s, f);
+  else if (rows == MSM_ROWS_HALFPOS) for_each_digit_even<16>(s, f);
   else for_each_digit_window(s, f);
 }
 

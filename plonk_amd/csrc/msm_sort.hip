@@ -106,8 +106,12 @@ __device__ __forceinline__ Fr scalar_canonical(const Fr& mont) {
 }
 
 // ---- level 1a: coarse histogram -------------------------------------------------------------------
-template <bool BITPOS>
+// MODE: how the scalars are recoded (msm_recode.cuh) — 0 signed 16-bit windows (window tables, 2^15 buckets only), 1 width-w NAF
+// (a table row per bit position), 2 even-position digits (a row for every second bit position, round 4)
+static constexpr uint32_t MSM_EVEN_WIDTH = (MSM_NB_BITS + 1) & ~1u;   // even-position digits: |d| <= 2^(width - 1) <= 2^NB_BITS, bucket = |d| - 1
+template <int MODE>
 __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t* __restrict__ coarse_cnt_all) {
+  constexpr bool BITPOS = MODE != 0;                   // the scalar is parked in LDS for the run-time bit positions of modes 1 and 2
   __shared__ uint32_t hist[COARSE];
   __shared__ uint32_t park[BITPOS ? 9 * SORT_T : 1];   // bit-position recoding: the canonical scalar, limb-major, + a zero limb (StridedLimbs)
   const int kb = blockIdx.y;
@@ -134,7 +138,8 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
 #pragma unroll
         for (int j = 0; j < 8; ++j) park[j * SORT_T + t] = s.l[j];   // read back by this lane only: no barrier
         park[8 * SORT_T + t] = 0;
-        for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, SORT_T}, count);
+        if (MODE == 2) for_each_digit_even<MSM_EVEN_WIDTH>(StridedLimbs{park + t, SORT_T}, count);
+        else for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, SORT_T}, count);
       } else if constexpr (MSM_NB_BITS == 15) {
         for_each_digit_window(s, count);
       }
@@ -223,11 +228,12 @@ __global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t*
 // dynamic LDS: stage[TILE * MSM_W] words, then hist / loff / gbase [COARSE] each
 static constexpr size_t PARTITION_LDS = ((size_t)TILE * MSM_W + 3 * COARSE) * sizeof(uint32_t);
 
-template <bool BITPOS, class WordT>
+template <int MODE, class WordT>
 __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint64_t srs_n,
                                                                const uint32_t* __restrict__ coarse_off_all,
                                                                uint32_t* __restrict__ coarse_cur_all,
                                                                void* __restrict__ tmp_all) {
+  constexpr bool BITPOS = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   uint32_t* stage = lds;                          // TILE * MSM_W
   uint32_t* hist = lds + TILE * MSM_W;            // COARSE: entries of this tile per bin
@@ -262,7 +268,8 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
 #pragma unroll
         for (int j = 0; j < 8; ++j) park[j * SORT_T + t] = s.l[j];
         park[8 * SORT_T + t] = 0;
-        for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, SORT_T}, put);
+        if (MODE == 2) for_each_digit_even<MSM_EVEN_WIDTH>(StridedLimbs{park + t, SORT_T}, put);
+        else for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, SORT_T}, put);
       } else if constexpr (MSM_NB_BITS == 15) {
         for_each_digit_window(s, put);
       }
@@ -678,7 +685,7 @@ int msm_order_slices(Ctx* c, const MsmBatch& bt) {
 }
 
 // Host side: everything between the scalars and msm_accumulate for one commitment group.
-template <bool BITPOS, class WordT>
+template <int MODE, class WordT>
 static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   MsmWork& w = c->msm;
   hipStream_t st = c->stream;
@@ -686,10 +693,10 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
   void* tmp = (void*)w.tmp_words;
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
-  hipLaunchKernelGGL(msm_hist_kernel<BITPOS>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
+  hipLaunchKernelGGL(msm_hist_kernel<MODE>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
-  smem_opt_in(c, (const void*)msm_partition_kernel<BITPOS, WordT>, PARTITION_LDS);
-  hipLaunchKernelGGL((msm_partition_kernel<BITPOS, WordT>), dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
+  smem_opt_in(c, (const void*)msm_partition_kernel<MODE, WordT>, PARTITION_LDS);
+  hipLaunchKernelGGL((msm_partition_kernel<MODE, WordT>), dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
                      w.coarse_off, w.coarse_cur, tmp);
   hipLaunchKernelGGL(msm_fine_kernel<WordT>, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, tmp,
                      w.entries, w.offsets);
@@ -720,9 +727,10 @@ int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   // final entries: sign << 31 | 31-bit table index
   if ((uint64_t)bt.rows * bt.table_n > (1ull << 31))
     return (set_last_error("commit key too large for the bucket sort", "table rows * points must be <= 2^31", __FILE__, __LINE__), PLONK_ERR_ARG);
-  if (bt.rows == MSM_ROWS_BITPOS) return bt.wide ? msm_group_sort_t<true, uint64_t>(c, bt, mmax) : msm_group_sort_t<true, uint32_t>(c, bt, mmax);
+  if (bt.rows == MSM_ROWS_BITPOS) return bt.wide ? msm_group_sort_t<1, uint64_t>(c, bt, mmax) : msm_group_sort_t<1, uint32_t>(c, bt, mmax);
+  if (bt.rows == MSM_ROWS_HALFPOS) return bt.wide ? msm_group_sort_t<2, uint64_t>(c, bt, mmax) : msm_group_sort_t<2, uint32_t>(c, bt, mmax);
 #if PLONK_MSM_NB_BITS == 15
-  return bt.wide ? msm_group_sort_t<false, uint64_t>(c, bt, mmax) : msm_group_sort_t<false, uint32_t>(c, bt, mmax);
+  return bt.wide ? msm_group_sort_t<0, uint64_t>(c, bt, mmax) : msm_group_sort_t<0, uint32_t>(c, bt, mmax);
 #else
   return (set_last_error("msm_group_sort", "window tables need the 2^15-bucket variant", __FILE__, __LINE__), PLONK_ERR_ARG);
 #endif

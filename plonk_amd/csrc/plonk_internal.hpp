@@ -87,7 +87,7 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   uint64_t cap_m, cap_slices;
   const void* table;   // tables the entries index: the context's commit key, or a prover's Lagrange-basis key
   uint64_t table_n;    // points per row of `table`
-  uint32_t rows;       // MSM_ROWS_WINDOW (16) or MSM_ROWS_BITPOS (256): which recoding the entries come from
+  uint32_t rows;       // MSM_ROWS_WINDOW (16), MSM_ROWS_BITPOS (256) or MSM_ROWS_HALFPOS (128): which recoding the entries come from
   uint32_t wide;       // the coarse-partitioned words are 64-bit (rows * table_n above 2^27)
   uint32_t heavy_thresh;   // a bucket with more slices than this is "heavy" (msm_slices_kernel lists it, msm.hip sums it by segments)
   // scalars of commitment k: scalars[k][i] for i < split[k], tail[k][i - split[k]] above (a wire column in place + its
@@ -148,7 +148,7 @@ struct Ctx {
   Fr* ntt_tmp = nullptr;
   uint64_t ntt_cap = 0;
   // SRS
-  void* srs_table = nullptr;       // [srs_rows][npoints] 128-B affine entries (Fp28): 2^(16 w) * P_i (16 rows) or 2^r * P_i (256 rows)
+  void* srs_table = nullptr;       // [srs_rows][npoints] 128-B affine entries (Fp28): 2^(16 w) * P_i (16 rows), 2^r * P_i (256 rows) or 4^r * P_i (128 rows)
   uint32_t srs_rows = 0;
   void* table_scratch = nullptr;   // srs_table_kernel's per-window ZZ / ZZZ / running products, alive during a key load
   uint64_t table_scratch_pts = 0;

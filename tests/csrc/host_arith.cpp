@@ -226,6 +226,14 @@ extern "C" int h_msm_recode(const uint32_t* scalar, int bitpos, uint32_t* out) {
     out[4 * n] = (uint32_t)slot; out[4 * n + 1] = row; out[4 * n + 2] = bucket; out[4 * n + 3] = sign;
     ++n;
   };
+  if (bitpos == 120 || bitpos == 116) {   // even-position digits (half-density tables), width 20 / 16, LDS-parked form
+    uint32_t park[9 * 3];
+    for (int k = 0; k < 8; ++k) park[3 * k + 1] = s.l[k];
+    park[3 * 8 + 1] = 0;
+    if (bitpos == 120) for_each_digit_even<20>(StridedLimbs{park + 1, 3}, emit);
+    else for_each_digit_even<16>(StridedLimbs{park + 1, 3}, emit);
+    return n;
+  }
   if (bitpos == 21) {  // the 2^19-bucket variant's digit width
     for_each_digit_naf<21>(s, emit);
   } else if (bitpos == 2) {   // the kernels' form: the scalar parked limb-major with a stride (StridedLimbs)

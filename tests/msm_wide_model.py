@@ -204,3 +204,35 @@ def bitpos_msm_model(points, scalars, w: int = NAF_W):
         S = E.jac_add(S, v)
     Wj = E.to_jac(W) if W is not None else E.JAC_ID
     return E.to_affine(E.jac_add(E.jac_double(Wj), E.jac_neg(S)))
+
+
+# ---- half-density tables (round 4): a table row for every EVEN bit position, digits that start at even positions only ----
+def even_digits(s: int, w: int = 20):
+    """[(row, d)] with row = position / 2, position even, d != 0 mod 4, |d| <= 2^(w-1), sum d * 4^row = s — msm_recode.cuh
+    for_each_digit_even.  A digit is taken where the remaining value (s >> p) + carry is not a multiple of 4."""
+    assert w % 2 == 0
+    out, p, carry = [], 0, 0
+    while (s >> p) + carry:
+        if ((s >> p) + carry) % 4 == 0:
+            p += 2
+            continue
+        rem = 256 - p
+        wd = ((rem // 2 + 1) & ~1) if w < rem <= 2 * w else w     # the last two digits share the remaining bits (even widths)
+        v = ((s >> p) & ((1 << wd) - 1)) + carry
+        d = v - (1 << wd) if v > (1 << (wd - 1)) else v
+        carry = 1 if d < 0 else 0
+        out.append((p >> 1, d))
+        p += wd
+    assert sum(d << (2 * r) for r, d in out) == s
+    return out
+
+
+def even_msm_model(points, scalars, w: int = 20):
+    """bucket = |d| - 1 with weight bucket + 1 (the window convention): the entries go through the unchanged reduction, no 2 W - S"""
+    sums = {}
+    for i, s in enumerate(scalars):
+        for r, d in even_digits(s % E.Q, w):
+            t = E.to_jac(E.g1_mul(points[i], 1 << (2 * r)))        # table row r: 4^r P_i
+            b = abs(d) - 1
+            sums[b] = E.jac_add(sums.get(b, E.JAC_ID), E.jac_neg(t) if d < 0 else t)
+    return host_finish(*bit_sums(sums, w))

@@ -26,6 +26,8 @@ def run_variant(env_extra, select=SELECT, marker="gpu", target="tests/test_gpu_m
     {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"},    # width-21 NAF digits over 2^19 buckets (the default above 2^19 terms)
     {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_ORDER": "0"},
     {"PLONK_MSM_BSUM": "lane"},    # one lane per bucket in msm_bucket_sum instead of a quad (small MSMs)
+    {"PLONK_MSM_TABLE": "halfpos"},                              # round 4: a table row for every second bit position, width-16 even-position digits
+    {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},   # ... width-20 digits over 2^19 buckets (keys whose 256 rows do not fit)
 ], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_variant_matches_the_oracle_on_the_edge_cases(variant):
     r = run_variant(variant)
@@ -34,7 +36,8 @@ def test_variant_matches_the_oracle_on_the_edge_cases(variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"}],
+@pytest.mark.parametrize("variant", [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"},
+                                     {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"}],
                          ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_prover_parity_holds_with_every_table_and_bucket_layout(variant):
     """whole proofs (reference KAT digest, random circuits, widget circuits vs the C oracle at 2^12 / 2^13) with the table /

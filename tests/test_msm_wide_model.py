@@ -143,3 +143,54 @@ def test_top_digits_are_not_skewed():
         # without the sharing bucket 0 alone receives ~ n * 2 / w entries
         assert max(cnt.values()) < max(12, 40 * total / nb) and cnt[0] < n / 50
         assert all(b < nb for b in cnt)
+
+
+# ---- half-density tables (round 4) -------------------------------------------------------------------------------
+def test_even_position_digits():
+    from msm_wide_model import even_digits
+    r = random.Random(2020)
+    for w, most in ((20, 14), (16, 16)):
+        for s in _edge_scalars(r):
+            dg = even_digits(s, w)
+            assert len(dg) <= most
+            assert all(d % 4 != 0 and 1 <= abs(d) <= (1 << (w - 1)) for _, d in dg)
+            assert all(0 <= row <= 127 for row, _ in dg)                       # 128 table rows: positions 0, 2, .. 254
+            assert all(2 * (q - p) >= w for (p, _), (q, _) in zip(dg[:-2], dg[1:-1]))
+        tot = sum(len(even_digits(r.randrange(E.Q), w)) for _ in range(2000)) / 2000
+        assert abs(tot - (254.9 / (w + 2 / 3) + 0.5)) < 0.25, tot                 # 12.8 for w = 20, 15.8 for w = 16
+
+
+def test_even_position_model_equals_the_oracle_msm():
+    from msm_wide_model import even_msm_model
+    r = random.Random(404)
+    pts = [E.g1_mul(E.G1_GEN, r.randrange(1, E.Q)) for _ in range(8)]
+    for sc in ([r.randrange(E.Q) for _ in range(8)], [0, 1, 2, 3, 4, E.Q - 1, 5, E.Q - 4]):
+        assert even_msm_model(pts, sc, 16) == E.msm_naive(pts, sc)
+    assert even_msm_model(pts, [r.randrange(E.Q) for _ in range(8)][:8], 20) is not None
+
+
+def test_product_even_recoding_matches_the_model():
+    import ctypes
+
+    from msm_wide_model import even_digits
+    from test_field_host import build_host_lib
+    lib = build_host_lib()
+    r = random.Random(77)
+    out = (ctypes.c_uint32 * 64)()
+    for s in _edge_scalars(r):
+        limbs = (ctypes.c_uint32 * 8)(*[(s >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+        for mode, w in ((120, 20), (116, 16)):
+            n = lib.h_msm_recode(limbs, mode, out)
+            got = [(out[4 * j + 1], (out[4 * j + 2] + 1) * (-1 if out[4 * j + 3] else 1)) for j in range(n)]
+            assert got == even_digits(s, w), (hex(s), w)
+            assert all(out[4 * j + 2] < (1 << (w - 1)) for j in range(n))
+    # the last two digits share the remaining bits (even widths of 10 .. 20 bits): the lowest buckets hold ~35x the mean — 1.6x
+    # the skew of the width-21 NAF (24x), far from the ~1 % of ALL entries in bucket 0 of an unshared top digit
+    from collections import Counter
+    cnt, total = Counter(), 0
+    for _ in range(6000):
+        for _, d in even_digits(r.randrange(E.Q), 20):
+            cnt[abs(d) - 1] += 1
+            total += 1
+    assert max(cnt.values()) < 30 and cnt[0] < 6000 / 50
+    assert sum(v for b, v in cnt.items() if b < 128) < 0.012 * total
