@@ -143,6 +143,34 @@ int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv,
   return PLONK_OK;
 }
 
+// All-gather of device buffers IN PLACE: rank r's contribution already sits at buf + r * bytes_per_rank; afterwards every
+// rank holds all of them (round 4: the z evaluations of a sharded grand product).  RCCL: ncclAllGather in place on the main
+// stream; callback transport: the slice goes through the host all-gather.
+int comm_allgather_dev(Ctx* c, const CommLink& l, void* buf_dev, size_t bytes_per_rank) {
+  if (l.world <= 1 || bytes_per_rank == 0) return PLONK_OK;
+  uint8_t* buf = (uint8_t*)buf_dev;
+  if (comm_loopback(c)) {
+    for (int r = 0; r < l.world; ++r)
+      if (r != l.rank)
+        HIP_TRY(hipMemcpyAsync(buf + bytes_per_rank * (size_t)r, buf + bytes_per_rank * (size_t)l.rank, bytes_per_rank, hipMemcpyDeviceToDevice, c->main_stream));
+    return PLONK_OK;
+  }
+  if (c->nccl_comm) {
+    RcclApi* api = rccl_api();
+    if (!api) return PLONK_ERR_STATE;
+    RCCL_TRY(api, api->AllGather(buf + bytes_per_rank * (size_t)l.rank, buf, bytes_per_rank, ncclUint8, (ncclComm_t)c->nccl_comm, c->main_stream));
+    return PLONK_OK;
+  }
+  if (!l.fn) return (set_last_error("comm_allgather_dev", "no communicator and no all-gather callback", __FILE__, __LINE__), PLONK_ERR_STATE);
+  std::vector<uint8_t> hs(bytes_per_rank), hr(bytes_per_rank * (size_t)l.world);
+  HIP_TRY(hipMemcpyAsync(hs.data(), buf + bytes_per_rank * (size_t)l.rank, bytes_per_rank, hipMemcpyDeviceToHost, c->main_stream));
+  HIP_TRY(hipStreamSynchronize(c->main_stream));
+  if (l.fn(l.user, hs.data(), hr.data(), bytes_per_rank) != 0) return (set_last_error("all-gather callback", "returned non-zero", __FILE__, __LINE__), PLONK_ERR_STATE);
+  HIP_TRY(hipMemcpyAsync(buf, hr.data(), hr.size(), hipMemcpyHostToDevice, c->main_stream));
+  HIP_TRY(hipStreamSynchronize(c->main_stream));   // hr leaves scope
+  return PLONK_OK;
+}
+
 // All-to-all of device buffers: send = [peer][bytes_per_peer], recv = [source][bytes_per_peer].
 // Callback transport: every rank contributes its whole send buffer to an all-gather and keeps the
 // pieces addressed to it (world x the traffic — it is the functional fallback, not the fast path).

@@ -197,6 +197,7 @@ struct CommLink {
 int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv, size_t bytes);
 int comm_sync(Ctx* c, hipStream_t st);   // stream wait that cannot hang on a dead peer (polls, aborts the communicator on time-out)
 int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* recv_dev, size_t bytes_per_peer);
+int comm_allgather_dev(Ctx* c, const CommLink& l, void* buf_dev, size_t bytes_per_rank);   // in place: rank r's part at buf + r * bytes
 
 // msm.hip
 int srs_load_device(Ctx* c, const G1Affine* pts_dev, uint64_t n);

@@ -365,6 +365,8 @@ static int scan_inplace(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
 // last phase converts back to the data domain (x * 2^256) for the inverse FFT that follows
 struct PScanArgs {
   Tw one_t, one_r;
+  Tw carry_t;
+  int has_carry;
 };
 __device__ __forceinline__ void ps_put(uint32_t (*sh)[SCAN_T], int t, const Fr29& v) {
 #pragma unroll
@@ -433,6 +435,7 @@ __global__ void __launch_bounds__(SCAN_T) pscan_totals_kernel(Fr* __restrict__ t
 __global__ void __launch_bounds__(SCAN_T) pscan_apply_kernel(Fr* __restrict__ data, uint64_t n, const Fr* __restrict__ totals, PScanArgs a) {
   // block 0 only converts; the others also multiply by the product of everything before them
   Fr29 off = tw29(a.one_r);
+  if (a.has_carry) off = Fr29::mul(tw29(a.carry_t), off);   // a range of a longer product: everything before the range
   if (blockIdx.x) off = Fr29::mul(ld29_(totals + blockIdx.x - 1), off);
   const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_E;
 #pragma unroll
@@ -443,7 +446,7 @@ __global__ void __launch_bounds__(SCAN_T) pscan_apply_kernel(Fr* __restrict__ da
 int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
   const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   if (nb > SCAN_T * SCAN_MAXPER) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // n <= 2^25
-  PScanArgs a;
+  PScanArgs a{};
   a.one_t = tw_of(Fr::one());
   a.one_r = tw_plain(Fr::one());
   if (nb == 1) {
@@ -453,6 +456,29 @@ int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
     hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb, (nb + SCAN_T - 1) / SCAN_T, a);
     hipLaunchKernelGGL(pscan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
   }
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+uint32_t scan_prefix_blocks(uint64_t n) { return (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
+int scan_prefix_product_local(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
+  const uint32_t nb = scan_prefix_blocks(n);
+  if (nb == 0 || nb > SCAN_T * SCAN_MAXPER) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  PScanArgs a{};
+  a.one_t = tw_of(Fr::one());
+  a.one_r = tw_plain(Fr::one());
+  hipLaunchKernelGGL(pscan_block_kernel<false>, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb, (nb + SCAN_T - 1) / SCAN_T, a);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+int scan_prefix_product_apply(Ctx* c, Fr* data, uint64_t n, const Fr* totals, const Fr& carry_twiddle) {
+  const uint32_t nb = scan_prefix_blocks(n);
+  PScanArgs a{};
+  a.one_t = tw_of(Fr::one());
+  a.one_r = tw_plain(Fr::one());
+  a.carry_t = tw_plain(carry_twiddle);   // already x * 2^261: re-sliced, not converted
+  a.has_carry = 1;
+  hipLaunchKernelGGL(pscan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
@@ -482,8 +508,9 @@ __device__ __forceinline__ Fr29 ld_slot(const void* base, uint64_t idx) {
   return r;
 }
 __global__ void __launch_bounds__(128) perm_terms_kernel(PermArgs a, PermConst k) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  const uint64_t j0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j0 >= a.count) return;
+  const uint64_t i = a.first + j0;
   if (i == 0) {
     const Fr one = tw29(k.one_t).to_fr();
     stf(a.num, one);
@@ -987,7 +1014,10 @@ int poly_perm_terms(Ctx* c, const PermArgs& a) {
   for (int j = 0; j < 4; ++j) k.bk_t[j] = tw_of(a.beta * a.ks[j]);
   k.b32_t = tw_of(a.beta * Fr::from_u64(32));
   k.one_t = tw_of(Fr::one());
-  hipLaunchKernelGGL(perm_terms_kernel, grid1(a.n, 128), dim3(128), 0, c->stream, a, k);
+  PermArgs r = a;
+  if (r.count == 0) { r.first = 0; r.count = a.n; }
+  if (r.first + r.count > a.n) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  hipLaunchKernelGGL(perm_terms_kernel, grid1(r.count, 128), dim3(128), 0, c->stream, r, k);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

@@ -16,6 +16,7 @@ struct SplitArgs {
 };
 struct PermArgs {
   uint64_t n;
+  uint64_t first = 0, count = 0;   // evaluation indices [first, first + count) only (a rank's share of the grand product); count == 0: all n
   const Fr* wires[4];
   const Fr* sigma[4];   // sigma_evaluations over the n-domain (prover.rs:95-100)
   Fr beta, gamma;
@@ -134,6 +135,12 @@ int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev);
 int poly_lincomb(Ctx* c, const LinCombArgs& a);
 int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, const Fr& zinv, Fr* scratch, Fr* totals);
 int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals);
+// the same scan in two steps for a RANGE of a longer product (sharded grand product): _local leaves the inclusive products of
+// the range's blocks in totals (the range's own product, twiddle form, at totals[scan_prefix_blocks(n) - 1]); _apply multiplies
+// every element by `carry` (twiddle form: the product of everything before the range) and converts to the data domain
+uint32_t scan_prefix_blocks(uint64_t n);
+int scan_prefix_product_local(Ctx* c, Fr* data, uint64_t n, Fr* totals);
+int scan_prefix_product_apply(Ctx* c, Fr* data, uint64_t n, const Fr* totals, const Fr& carry_twiddle);
 int scan_suffix_sum(Ctx* c, Fr* data, uint64_t n, Fr* totals);
 
 }  // namespace plonk

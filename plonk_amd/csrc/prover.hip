@@ -1234,10 +1234,50 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     pa.tw_lo29 = tbn->tw_lo29; pa.tw_hi29 = tbn->tw_hi29; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
     pa.num = p->scratch; pa.den = p->scratch + np;
     HIP_TRY(hipMemsetAsync(p->flag_dev, 0, sizeof(int), c->stream));
-    PTRY(poly_perm_terms(c, pa));
-    PTRY(poly_batch_inverse(c, pa.den, n, true));
-    PTRY(poly_mul_arrays(c, pa.num, pa.den, n, p->flag_dev));
-    PTRY(scan_prefix_product(c, pa.num, n, p->totals));
+    // Round 4: the grand product (permutation.rs:213-294) split over the ranks from 2^19 gates and four ranks on.  Rank r forms the n / W
+    // numerator / denominator terms of ITS evaluation indices, inverts, multiplies and scans them locally; the ranks exchange
+    // their range products (36 bytes each: the product in twiddle form + the zero-denominator flag), every rank scales its
+    // range by the product of the ranges before it, and the z evaluations are all-gathered in place (32 n / W bytes per
+    // rank; 0.5 MB per peer link at 2^20 gates and W = 8) for the one replicated step left, z's inverse transform.
+    // PLONK_SHARD_Z=0 / 1 forces either (the multi-rank tests run small circuits through both).
+    static const int shard_z_env = [] { const char* e = getenv("PLONK_SHARD_Z"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // rank alone, loop-back collectives (profiles/r04): W = 8 at 2^20 gates 7.41 -> 7.01 ms, at 2^22 21.9 -> 20.1; W = 2 at 2^20
+    // 19.05 -> 19.27 (half of 0.5 ms of work against two more host round trips): from four ranks on
+    const bool shard_z = (shard_z_env >= 0 ? shard_z_env == 1 : (L >= 19 && W >= 4)) && n % W == 0 && n / W >= 2;
+    if (!shard_z) {
+      PTRY(poly_perm_terms(c, pa));
+      PTRY(poly_batch_inverse(c, pa.den, n, true));
+      PTRY(poly_mul_arrays(c, pa.num, pa.den, n, p->flag_dev));
+      PTRY(scan_prefix_product(c, pa.num, n, p->totals));
+    } else {
+      const uint64_t cnt = n / W, first = cnt * (uint64_t)p->rank;
+      pa.first = first; pa.count = cnt;
+      PTRY(poly_perm_terms(c, pa));
+      PTRY(poly_batch_inverse(c, pa.den + first, cnt, true));
+      PTRY(poly_mul_arrays(c, pa.num + first, pa.den + first, cnt, p->flag_dev));
+      PTRY(scan_prefix_product_local(c, pa.num + first, cnt, p->totals));
+      struct { Fr total; int flag; int pad[7]; } mine, *all;
+      static_assert(sizeof(mine) == 64, "exchange record");
+      memset(&mine, 0, sizeof mine);
+      HIP_TRY(hipMemcpyAsync(p->ev_host, p->totals + (scan_prefix_blocks(cnt) - 1), sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      PTRY(comm_sync(c, c->stream));
+      mine.total = p->ev_host[0];
+      mine.flag = *p->flag_host;
+      std::vector<uint8_t> gathered(sizeof(mine) * (size_t)W);
+      PTRY(comm_allgather_host(c, p->link, &mine, gathered.data(), sizeof(mine)));
+      all = reinterpret_cast<decltype(all)>(gathered.data());
+      // products in twiddle form (raw integer x * 2^261 = the Montgomery form of 32 x): a * b * (1 / 32) stays in that form
+      Fr carry = Fr::from_u64(32);
+      int any_zero = 0;
+      for (uint32_t r = 0; r < W; ++r) {
+        any_zero |= all[r].flag;
+        if (r < (uint32_t)p->rank) carry = carry * all[r].total * p->inv32;
+      }
+      if (any_zero) return (plonk::set_last_error("invalid argument", "zero denominator in the permutation grand product", __FILE__, __LINE__), PLONK_ERR_ARG);
+      PTRY(scan_prefix_product_apply(c, pa.num + first, cnt, p->totals, carry));
+      PTRY(comm_allgather_dev(c, p->link, pa.num, sizeof(Fr) * cnt));
+    }
     PTRY(ntt_device(c, pa.num, p->zpoly, p->tmp8, L, true, false, n));
     BlindArgs ba;
     ba.count = 3;

@@ -104,6 +104,16 @@ def test_compiled_prover_matches_the_coefficient_form_prover(ranks, log_gates, p
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
+@pytest.mark.parametrize("ranks,log_gates,profile", [(2, 13, "widgets"), (8, 13, "widgets"), (4, 16, "dense")])
+def test_sharded_grand_product_matches_single_gpu(ranks, log_gates, profile):
+    """PLONK_SHARD_Z=1: the permutation grand product of round 2 split over the ranks (each rank its n / W evaluation indices,
+    range products exchanged, z evaluations all-gathered in place) — the default from 2^19 gates on, forced here on small
+    circuits; =0 (the replicated grand product) is what the other tests of this file run at these sizes."""
+    s = single(log_gates, profile)
+    m = multi(ranks, log_gates, profile, {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1", "PLONK_SHARD_Z": "1"})
+    assert m["n_gpus"] == ranks and m["proof_blake2b"] == s["proof_blake2b"]
+
+
 @pytest.mark.parametrize("ranks,log_gates,env", [(3, 13, {}), (2, 12, {"PLONK_SHARD_QUOTIENT": "0"})])
 def test_msm_only_sharding_matches_single_gpu(ranks, log_gates, env):
     """other world sizes / PLONK_SHARD_QUOTIENT=0: only the MSMs are sharded (round-1 path)."""
