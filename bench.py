@@ -600,7 +600,12 @@ def main():
             # additions = non-zero digits of the 11 commitments' scalars) over one VALU wave-instruction per 4 cycles per SIMD.  The
             # HBM figure the contract asks for (algorithmic (32 b + 96) m bytes per group launch over the launch time) is `hbm`.
             "roofline": dict(
-                {"bound": "valu-int-issue", "kernel": "msm_accumulate_kernel"},
+                {"bound": "valu-int-issue",
+                 # the variant that ran: 2^19 buckets (namespace nbl, lanes in order of length) above 2^18 terms over bit-position /
+                 # half-density rows, else 2^15 buckets (ordered lanes where slices are 32 entries long)
+                 "kernel": ("nbl::msm_accumulate_ordered_kernel" if table_rows in (256, 128) and m_local > (1 << 18) + 64 and
+                            os.environ.get("PLONK_MSM_BUCKETS", "") != "15" else
+                            ("nb15::msm_accumulate_ordered_kernel" if 3 * m_local > 16 * 32768 else "nb15::msm_accumulate_kernel"))},
                 **valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove),
                 **{"traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
                    "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},

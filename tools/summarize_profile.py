@@ -26,7 +26,8 @@ try:   # the launches that belong to proofs (bench.py's roofline leg times exact
     acc_d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr if "msm_accumulate" in r["Kernel_Name"]]   # any variant (ordered lanes by default)
     nproofs = (len(acc_d) - 4) // 4          # setup commits the 15 key polynomials in 4 group launches
     prove_d = acc_d[-4 * nproofs:]
-    out.append(f"\n`msm_accumulate_kernel` launches inside prove() only ({len(prove_d)} launches = {nproofs} proofs x 4 commitment groups): "
+    names = collections.Counter(r["Kernel_Name"].split("(")[0] for r in tr if "msm_accumulate" in r["Kernel_Name"])
+    out.append(f"\n`{names.most_common(1)[0][0]}` (every msm_accumulate launch of this run: {dict(names)}) — launches inside prove() only ({len(prove_d)} launches = {nproofs} proofs x 4 commitment groups): "
                f"average **{sum(prove_d) / len(prove_d) / 1e6:.3f} ms** per launch, {4 * sum(prove_d) / len(prove_d) / 1e6:.2f} ms per proof "
                "(compare `roofline.avg_launch_ms` / `kernel_ms_per_prove.msm_accumulate` printed by bench.py).")
 except Exception as e:  # noqa
@@ -36,9 +37,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = list(csv.DictReader(open(base + f"pmc_{C}/bench_counter_collection.csv")))
     agg = collections.defaultdict(list)
     for r in rows:
-        name = r["Kernel_Name"].split("(")[0][:70]
-        if "msm_accumulate" in name:
-            name = "plonk::msm_accumulate_kernel"       # one row for every variant (ordered lanes, nb15 / nbl namespaces)
+        name = r["Kernel_Name"].split("(")[0][:70]              # the kernel that RAN, namespace included (nb15:: / nbl::, ordered lanes or not)
         agg[name].append(float(r["Counter_Value"]))
     pm[C] = agg
     out.append(f"\n## {C} per launch (raw counter value, KiB)\n\n| kernel | launches | avg per launch |\n|---|---|---|")
@@ -49,20 +48,20 @@ try:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     for r in rows:
-        k = r["Kernel_Name"].split("(")[0][:50]
-        if "msm_accumulate" in k:
-            k = "plonk::msm_accumulate_kernel"
+        k = r["Kernel_Name"].split("(")[0][:70]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     out.append("\n## SQ counters (summed over launches of 1 proof + setup)\n\n| kernel | SQ_WAVES | SQ_INSTS_VALU | SQ_ACTIVE_INST_VALU | SQ_WAIT_INST_ANY | SQ_WAVE_CYCLES | SQ_BUSY_CYCLES |\n|---|---|---|---|---|---|---|")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[:8]:
         out.append("| `%s` | %s |" % (k, " | ".join("%.3g" % v.get(c, 0) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"))))
 except Exception as e:  # noqa
     out.append(f"\n(SQ counters unavailable: {e})")
-acc = "plonk::msm_accumulate_kernel"
+# the dominant kernel under the name it ran as: the msm_accumulate variant with the most launches in the counter pass
+cands = [k for k in pm["FETCH_SIZE"] if "msm_accumulate" in k]
+acc = max(cands, key=lambda k: len(pm["FETCH_SIZE"][k])) if cands else ""
 if acc in pm["FETCH_SIZE"]:
     f = pm["FETCH_SIZE"][acc]; w = pm["WRITE_SIZE"].get(acc, [0])
     fa, wa = sum(f) / len(f), sum(w) / len(w)
-    out.append("\n## HBM traffic of the dominant kernel (msm_accumulate, per launch = one commitment group)\n")
+    out.append(f"\n## HBM traffic of the dominant kernel (`{acc}`, per launch = one commitment group)\n")
     out.append(f"* raw FETCH_SIZE {fa:,.0f} KiB, WRITE_SIZE {wa:,.0f} KiB per launch (average over groups of 4/1/4/2 MSMs).")
     out.append(f"* MI355X_MICROARCH.md §HBM correction (gfx950 FETCH_SIZE = 1/2 of wide-read bytes): read = 2 x FETCH = {2 * fa * 1024 / 1e9:.2f} GB, "
                f"+ written {wa * 1024 / 1e9:.2f} GB = **{(2 * fa + wa) * 1024 / 1e9:.2f} GB per launch** (upper bound — the gather pattern here is 4 x 16 B per lane "
@@ -73,20 +72,20 @@ if acc in pm["FETCH_SIZE"]:
     import json
     valu = None
     try:
-        a = agg["plonk::msm_accumulate_kernel"]
+        a = agg[acc]
         # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles summed over waves (MI355X_MICROARCH.md,
         # "s_memtime tick vs SQ PMC units"); the kernel runs 2 waves per SIMD (216 VGPRs), so SIMD time =
         # WAVE_CYCLES / 2 and VALU-busy = ACTIVE_INST_VALU / (WAVE_CYCLES / 2).
         valu_raw = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
         valu = min(valu_raw, 1.0)   # waves that retire early make the 2-waves-per-SIMD denominator a slight underestimate
-        out.append(f"\n## VALU utilisation of msm_accumulate\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu_raw:.2f}** — "
+        out.append(f"\n## VALU utilisation of `{acc}`\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu_raw:.2f}** — "
                    "the integer VALU pipe is saturated; only fewer instructions per point addition make this kernel faster.")
         nk = max((k for k in agg if "ntt_pass_kernel" in k), key=lambda k: agg[k]["SQ_WAVE_CYCLES"])
         b = agg[nk]
         out.append(f"Same ratio for `{nk}` (2 workgroups x 4 waves per CU = 2 waves per SIMD): {b['SQ_ACTIVE_INST_VALU'] / (b['SQ_WAVE_CYCLES'] / 2):.2f}.")
     except Exception as e:  # noqa
         out.append(f"\n(VALU utilisation unavailable: {e})")
-    json.dump({"kernel": "msm_accumulate_kernel", "workload": "bench.py 2^20 gates, 1 GPU", "fetch_size_kib_per_launch": fa,
+    json.dump({"kernel": acc, "workload": "bench.py 2^20 gates, 1 GPU", "fetch_size_kib_per_launch": fa,
                "valu_busy_frac": valu, "valu_busy_formula": "SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD), quad-cycle units",
                "write_size_kib_per_launch": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
                "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes"},
