@@ -364,7 +364,10 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
  * pair ON THE LIBRARY'S STREAM and accumulated per slot.  Slots:
  *   0 ntt pass kernels, 1 msm bucket accumulation, 2 msm (all other kernels),
  *   3 quotient/pointwise kernels, 4 the polynomial work of prove() rounds 1-2 (wire / permutation
- *   polynomials: what stays replicated on every rank of a multi-GPU run). */
+ *   polynomials: what stays replicated on every rank of a multi-GPU run).
+ *   With PLONK_PROF_FINE=1 in the environment also, per phase of a commitment group (groups of >= 3 commitments: 16 + phase,
+ *   smaller groups: 24 + phase): 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums, 5 bit sums.
+ *   Slots 0 .. 31 are valid. */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches);
 int plonk_profile_reset(plonk_ctx* ctx);
