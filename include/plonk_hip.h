@@ -175,6 +175,12 @@ typedef struct {
 } plonk_prover_desc;
 int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out);
 void plonk_prover_destroy(plonk_prover* p);
+/* Prover::prove_with_version (prover.rs:365-413): version 3 = PlonkVersion::V3, the default of every prover (Transcript::base_v3,
+ * transcript.rs:131-145); version 2 = the legacy seeding the reference keeps behind its `legacy-proving` feature
+ * (Transcript::base + VerifierKey::seed_transcript_legacy, transcript.rs:110-129, widget.rs:224-228,260-265: the label s_sigma_4
+ * carries the commitment of s_sigma_1).  Nothing else of a proof depends on the version.  Other values: PLONK_ERR_ARG (V1 is
+ * Error::UnsupportedProvingVersion in the reference).  Applies to the proofs made after the call. */
+int plonk_prover_set_version(plonk_prover* p, int version);
 int plonk_prover_vk(plonk_prover* p, uint8_t out[15 * 48]);
 uint64_t plonk_prover_size(plonk_prover* p);
 /* diagnostic: read `count` Fr at `offset` of internal array `which` (0 wire polys, 1 z poly,

@@ -164,6 +164,7 @@ typedef struct {
   uint8_t vk[15][48];                          /* POLY order (K_*) */
   int threads;
   int trapdoor; fr tau, gscalar;               /* oracle_prover_set_trapdoor: the key is [g tau^i] G with KNOWN tau, g */
+  int version;                                 /* 3 (default) or 2: prove_with_version (prover.rs:365-413) */
 } oprover;
 
 static const u64 G1_GEN_X[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull, 0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
@@ -250,6 +251,8 @@ void oracle_prover_vk(const oprover* P, uint8_t out[15 * 48]) { memcpy(out, P->v
 void oracle_prover_set_trapdoor(oprover* P, const u64 tau_m[4], const u64 g_scalar_m[4]) {
   P->trapdoor = 1; P->tau = fr_ld(tau_m); P->gscalar = fr_ld(g_scalar_m);
 }
+
+void oracle_prover_set_version(void* h, int version) { ((oprover*)h)->version = version; }
 static void commit_trapdoor(const oprover* P, const fr* poly, u64 len, uint8_t raw[97]) {
   memset(raw, 0, 97);
   const u64 chunk = 1 << 14, nch = (len + chunk - 1) / chunk;
@@ -432,7 +435,8 @@ int oracle_prover_prove(const oprover* P, const u64* const wires[4], const u64* 
   strobe tr;
   tr_init(&tr, P->label, P->label_len);
   tr_domain_sep(&tr, P->constraints);
-  for (int k = 0; k < 15; ++k) tr_append(&tr, VK_LABEL[k], P->vk[VK_ORDER[k]], 48);
+  /* V2 (Transcript::base + seed_transcript_legacy, transcript.rs:110-129, widget.rs:224-228,260-265): the label s_sigma_4 carries s_sigma_1's commitment */
+  for (int k = 0; k < 15; ++k) tr_append(&tr, VK_LABEL[k], P->vk[(P->version == 2 && k == 14) ? K_S1 : VK_ORDER[k]], 48);
   tr_domain_sep(&tr, P->constraints);
   for (u64 i = 0; i < pi_count; ++i) tr_scalar(&tr, "pi", fr_ld(pi_val + 4 * i));
 

@@ -43,6 +43,8 @@ def load() -> ctypes.CDLL:
     lib.oracle_prover_vk.restype = None
     lib.oracle_prover_set_trapdoor.argtypes = [vp, vp, vp]
     lib.oracle_prover_set_trapdoor.restype = None
+    lib.oracle_prover_set_version.argtypes = [vp, ctypes.c_int]
+    lib.oracle_prover_set_version.restype = None
     lib.oracle_srs_generate.argtypes = [vp, vp, u64, vp, ctypes.c_int]
     lib.oracle_prover_prove.argtypes = [vp, ctypes.POINTER(vp), vp, vp, u64, vp, vp, vp]
     _lib = lib
@@ -133,6 +135,10 @@ class CProver:
     def set_trapdoor(self, tau_mont: bytes, g_scalar_mont: bytes):
         """the key is [g tau^i] G with known tau, g: commitments become [g p(tau)] G (same group elements, no MSM)"""
         self.lib.oracle_prover_set_trapdoor(self.h, tau_mont, g_scalar_mont)
+
+    def set_version(self, version: int):
+        """prove_with_version (prover.rs:365-413): 3 (default) or the legacy 2"""
+        self.lib.oracle_prover_set_version(self.h, version)
 
     def vk(self) -> bytes:
         out = ctypes.create_string_buffer(15 * 48)

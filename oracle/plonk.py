@@ -263,15 +263,17 @@ def compile_circuit(pp, label: bytes, composer: Composer, msm=E.msm_naive) -> Pr
     return Prover(label, pk, ck, vk, size, constraints, sig_ev, vinv)
 
 
-def seed_transcript_v3(label: bytes, vk: dict, constraints: int) -> Transcript:
+def seed_transcript_v3(label: bytes, vk: dict, constraints: int, version: int = 3) -> Transcript:
     """Transcript::base_v3 (transcript.rs:131-145) + VerifierKey::seed_transcript
-    (widget.rs:218-258)."""
+    (widget.rs:218-258).  version = 2: Transcript::base (transcript.rs:110-129) + seed_transcript_legacy
+    (widget.rs:260-265) — the legacy seeding binds the LABEL s_sigma_4 to the commitment of s_sigma_1
+    (seed_transcript_inner, widget.rs:224-228); everything else is the same."""
     t = Transcript(label)
     t.circuit_domain_sep(constraints)
     for lab in ["q_m", "q_l", "q_r", "q_o", "q_c", "q_f", "q_arith", "q_range", "q_logic",
                 "q_variable_group_add", "q_fixed_group_add",
                 "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]:
-        t.append_commitment(lab.encode(), vk[lab])
+        t.append_commitment(lab.encode(), vk["s_sigma_1" if (version == 2 and lab == "s_sigma_4") else lab])
     t.circuit_domain_sep(vk["n"])
     return t
 
@@ -496,13 +498,13 @@ def permutation_vec(domain, wires, beta, gamma, sigma_ev):   # permutation.rs:21
     return out
 
 
-def prove(prover: Prover, rng, composer: Composer, msm=E.msm_naive, trace: dict | None = None):
+def prove(prover: Prover, rng, composer: Composer, msm=E.msm_naive, trace: dict | None = None, version: int = 3):
     """prove_inner (prover.rs:415-761).  Returns (proof_bytes, public_inputs)."""
     assert len(composer.constraints) == prover.constraints         # composer.rs:452-459
     size = prover.size
     domain = EvaluationDomain(prover.constraints)
     pk, ck = prover.pk, prover.ck
-    tr = seed_transcript_v3(prover.label, prover.vk, prover.constraints)
+    tr = seed_transcript_v3(prover.label, prover.vk, prover.constraints, version)   # prove_with_version(V2 | V3), prover.rs:365-413
     pi_idx = composer.public_input_indexes()
     public_inputs = [composer.public_inputs[i] for i in pi_idx]
     dense_pi = [0] * size

@@ -51,7 +51,7 @@ EXPORTS = [
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_info", "plonk_comm_selftest", "plonk_comm_destroy",
-    "plonk_comm_measure_loopback",
+    "plonk_comm_measure_loopback", "plonk_prover_set_version",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
     "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
     "plonk_public_parameters_check", "plonk_srs_load_public_parameters",
@@ -194,6 +194,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.plonk_comm_destroy.argtypes = [vp]
     lib.plonk_comm_measure_loopback.argtypes = [vp, ci]
+    lib.plonk_prover_set_version.argtypes = [vp, ci]
     _lib = lib
     return lib
 
@@ -684,6 +685,10 @@ class Prover:
         proof = ctypes.create_string_buffer(1008)
         self.ctx._check(self.ctx.lib.plonk_prover_prove(self.handle, arr, idx, val, cnt, blinders_mont, proof))
         return proof.raw
+
+    def set_version(self, version: int):
+        """Prover::prove_with_version (prover.rs:365-413): 3 (default) or the legacy 2 (transcript seeding only)."""
+        self.ctx._check(self.ctx.lib.plonk_prover_set_version(self.handle, version))
 
     def prove_dev(self, wires_ptr: int, public_inputs, blinders_mont: bytes) -> bytes:
         idx, val, cnt = self._pi(public_inputs)

@@ -33,6 +33,7 @@ static const char* VK_LABEL[15] = {"q_m", "q_l", "q_r", "q_o", "q_c", "q_f", "q_
 
 struct Prover {
   Ctx* c = nullptr;
+  int transcript_version = 3;      // PlonkVersion of the transcript seeding: 3 (Transcript::base_v3) or the legacy 2 (plonk_prover_set_version)
   uint64_t n = 0, n8 = 0, np = 0, constraints = 0;   // n8 = quotient-domain size = qf * n
   uint32_t logn = 0;
   uint32_t qf = 8, lq = 3;         // quotient domain: 8n (the reference's) or 4n + de-aliasing, see quotient_low()
@@ -646,7 +647,9 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
 // (widget.rs:218-258) + the public inputs (prover.rs:440-442)
 static void seed_transcript(Transcript& tr, const Prover* p, const Fr* pi_val, uint64_t pi_count) {
   tr.circuit_domain_sep(p->constraints);
-  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[VK_ORDER[k]]);
+  // PlonkVersion::V2 (prove_with_version, prover.rs:365-413; feature `legacy-proving`): Transcript::base + seed_transcript_legacy
+  // (transcript.rs:110-129, widget.rs:224-228,260-265) bind the LABEL s_sigma_4 to the commitment of s_sigma_1; nothing else differs
+  for (int k = 0; k < 15; ++k) tr.append_commitment(VK_LABEL[k], p->vk[(p->transcript_version == 2 && k == 14) ? P_S1 : VK_ORDER[k]]);
   tr.circuit_domain_sep(p->constraints);   // vk.n == constraints (compiler.rs:279)
   for (uint64_t i = 0; i < pi_count; ++i) tr.append_scalar("pi", pi_val[i]);
 }
@@ -1592,6 +1595,14 @@ void plonk_prover_destroy(plonk_prover* pr) {
     prover_free(pr->p);
   }
   delete pr;
+}
+
+int plonk_prover_set_version(plonk_prover* pr, int version) {
+  if (!pr || !pr->p) return PLONK_ERR_ARG;
+  if (version != 2 && version != 3) return (plonk::set_last_error("invalid argument", "PlonkVersion: 2 (legacy) or 3; V1 is Error::UnsupportedProvingVersion in the reference too", __FILE__, __LINE__), PLONK_ERR_ARG);
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  pr->p->transcript_version = version;
+  return PLONK_OK;
 }
 
 int plonk_prover_vk(plonk_prover* pr, uint8_t out[15 * 48]) {

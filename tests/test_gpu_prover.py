@@ -96,6 +96,32 @@ def test_deterministic_v3_proof_matches_base_digest(ctx, kat_setup):
     gp2.close()
 
 
+def test_legacy_v2_transcript_matches_the_oracle(ctx, kat_setup):
+    """plonk_prover_set_version(2) = Prover::prove_with_version(V2) (prover.rs:365-413): only the transcript seeding differs
+    (the label s_sigma_4 carries s_sigma_1's commitment, widget.rs:224-228); bytes equal the C oracle's V2 proof, setting the
+    version back restores the KAT digest, other values are refused."""
+    import plonk_amd
+    from oracle import cbind
+    _, oprover, circuit = kat_setup
+    gp = gpu_prover(ctx, oprover)
+    rng = StdRng.seed_from_u64(0x9235E701)
+    blinders = [rng.random_scalar() for _ in range(14)]
+    comp = circuit()
+    wires = wires_of(comp, oprover.size)
+    from tests import circuits as C
+    cp = cbind.CProver(oprover.constraints, oprover.label, {k: C.fr_bytes(v) for k, v in oprover.pk.polys.items()},
+                       b"".join(E.g1_to_raw96(p) for p in oprover.ck))
+    cp.set_version(2)
+    want_v2 = cp.prove([C.fr_bytes(w) for w in C.wires_of(comp, oprover.size)], [], b"", C.fr_bytes(blinders))
+    gp.set_version(2)
+    assert gp.prove(wires, {}, blinders) == want_v2
+    gp.set_version(3)
+    assert hashlib.blake2b(gp.prove(wires, {}, blinders)).digest() == KAT_DIGEST
+    with pytest.raises(plonk_amd.PlonkError):
+        gp.set_version(1)
+    gp.close()
+
+
 def arithmetic_circuit(ngates, seed, with_pi=True):
     def build():
         r = random.Random(seed)

@@ -72,6 +72,35 @@ def test_c_prove_matches_bigint_oracle_with_widgets_and_public_inputs(seed):
         assert have[:len(want)] == want and not any(have[len(want):]), name
 
 
+def test_legacy_v2_transcript_differs_only_in_the_seeding(kat_setup):
+    """prove_with_version(V2) (prover.rs:365-413, feature `legacy-proving`): Transcript::base + seed_transcript_legacy bind the label
+    s_sigma_4 to the commitment of s_sigma_1 (widget.rs:224-228,260-265).  Both restatements agree byte for byte on a V2 proof,
+    it differs from the V3 proof (whose digest is the reference's KAT), and the commitments of round 1 — made before the first
+    challenge is drawn — are the same in both.  The reference holds no literal for V2: this pins the two restatements to each
+    other and to the code read, not to reference-produced bytes."""
+    _, oprover, circuit = kat_setup
+    cp = c_prover_from(oprover)
+    rng = StdRng.seed_from_u64(0x9235E701)
+    bl = [rng.random_scalar() for _ in range(14)]
+    comp = circuit()
+    wires = [C.fr_bytes(w) for w in C.wires_of(comp, oprover.size)]
+    v3 = cp.prove(wires, [], b"", C.fr_bytes(bl))
+    cp.set_version(2)
+    v2 = cp.prove(wires, [], b"", C.fr_bytes(bl))
+    cp.set_version(3)
+    assert cp.prove(wires, [], b"", C.fr_bytes(bl)) == v3 and hashlib.blake2b(v3).digest() == KAT_DIGEST
+    assert v2 != v3 and v2[:4 * 48] == v3[:4 * 48]
+
+    class Replay:
+        def __init__(self, vals):
+            self.vals = list(vals)
+
+        def random_scalar(self):
+            return self.vals.pop(0)
+    big, _ = O.prove(oprover, Replay(bl), circuit(), version=2)
+    assert big == v2
+
+
 def test_c_prove_rejects_unsatisfied_witness_like_the_reference():
     """quotient_poly.rs:132 -> Error::CircuitUnsatisfied (tests/common/mod.rs:60-80)."""
     case = C.compile_fast(C.big_widget_circuit(128, seed=3)(), b"unsat")
