@@ -139,3 +139,41 @@ def ruffini_local(poly, lo, hi, z):
 def ruffini_finish(S, lo, hi, z, carry):
     zi = pow(z, -1, MOD)
     return {lo + i: (S[i + 1] + carry) * pow(zi, lo + i + 1, MOD) % MOD for i in range(hi - lo)}
+
+
+# ---- round 2, sharded (round 4): the permutation grand product by evaluation-index range --------------------------------
+def grand_product_terms(n, wires, sigma_ev, beta, gamma, first, count):
+    """perm_terms on [first, first + count): t[0] = 1, t[i] = prod_j (w_j[i-1] + beta K_j w^(i-1) + gamma) / (w_j[i-1] + beta sigma_j[i-1] + gamma)
+    (permutation.rs:213-294 with the reference's shift: z[i] is the product of the ratios at rows < i)"""
+    ks = (1, 7, 13, 17)
+    w = omega(n.bit_length() - 1)
+    out = []
+    for i in range(first, first + count):
+        if i == 0:
+            out.append(1)
+            continue
+        r = i - 1
+        root = pow(w, r, MOD)
+        num = den = 1
+        for j in range(4):
+            num = num * ((wires[j][r] + beta * ks[j] % MOD * root + gamma) % MOD) % MOD
+            den = den * ((wires[j][r] + beta * sigma_ev[j][r] + gamma) % MOD) % MOD
+        out.append(num * pow(den, -1, MOD) % MOD)
+    return out
+
+
+def grand_product_rank(terms):
+    """local inclusive prefix products of a rank's terms and the range product (prover.hip: scan_prefix_product_local)"""
+    acc, out = 1, []
+    for t in terms:
+        acc = acc * t % MOD
+        out.append(acc)
+    return out, acc
+
+
+def grand_product_finish(local, totals, rank):
+    """scale by the product of the ranges before this one (scan_prefix_product_apply): the rank's slice of z's evaluations"""
+    carry = 1
+    for t in totals[:rank]:
+        carry = carry * t % MOD
+    return [v * carry % MOD for v in local]

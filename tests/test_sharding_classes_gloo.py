@@ -98,6 +98,31 @@ def test_range_sharded_evaluation_and_ruffini(world):
     assert [got[i] for i in range(n + 7)] == want
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_range_sharded_grand_product(world):
+    """round 2 of a sharded proof (round 4 of the build): every rank forms the terms of its n / W evaluation indices, scans them
+    locally, the range products are exchanged, and the scaled slices concatenate to the oracle's z evaluations
+    (permutation.rs:213-294) — prover.hip prover_prove_sharded, PLONK_SHARD_Z"""
+    from oracle import plonk as O
+    from oracle.fft import EvaluationDomain
+    n = 64
+    r = random.Random(33)
+    wires = [[r.randrange(Q) for _ in range(n)] for _ in range(4)]
+    sigma_ev = [[r.randrange(Q) for _ in range(n)] for _ in range(4)]
+    beta, gamma = r.randrange(Q), r.randrange(Q)
+    want = O.permutation_vec(EvaluationDomain(n), wires, beta, gamma, sigma_ev)
+    cnt = n // world
+    local, totals = [], []
+    for rank in range(world):
+        loc, tot = M.grand_product_rank(M.grand_product_terms(n, wires, sigma_ev, beta, gamma, rank * cnt, cnt))
+        local.append(loc)
+        totals.append(tot)
+    got = []
+    for rank in range(world):
+        got += M.grand_product_finish(local[rank], totals, rank)
+    assert got == want
+
+
 # ---- the same exchange as a real gloo job: all-to-all realised with all-gather, like the library callback
 def _free_port():
     s = socket.socket()
