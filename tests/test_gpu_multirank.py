@@ -54,9 +54,10 @@ def test_sharded_quotient_prove_matches_single_gpu(ranks, log_gates, profile):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("ranks", [2, 8])
+@pytest.mark.parametrize("ranks", [2, 4, 8])
 def test_sharded_prove_matches_single_gpu_at_2p20(ranks):
-    """BASELINE config 4's size: the sharded proof of the 2^20-gate bench circuit — W = 2 (Q = 4 classes) and W = 8
+    """BASELINE config 4's size: the sharded proof of the 2^20-gate bench circuit — W = 2 (Q = 4 classes; ranks of 2^19 points:
+    2^19 buckets), W = 4 (2^18 points: window rows, ordered 32-entry slices; sharded grand product) and W = 8
     (Q = 8: the 8n class layout) — must be the single-GPU proof byte for byte; the single-GPU bytes at this size are
     compared with the C oracle in tests/test_gpu_prove_sizes.py.  Launched as `python bench.py --gpus N`, i.e. through
     bench.py's own rank launcher (the ranks share this box's one GPU)."""

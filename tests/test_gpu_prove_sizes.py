@@ -178,6 +178,31 @@ def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     assert got == expected
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("log_n", [18, 19])
+def test_proof_bytes_equal_c_oracle_at_the_layout_crossover(ctx, monkeypatch, log_n):
+    """The two sizes either side of the table / bucket crossover (round 4: 2^18 + 64 terms): 2^18 gates run window rows, 2^15
+    buckets, 32-entry slices in order of length with single-slice buckets written by their lane and the rest summed by a quad
+    per bucket; 2^19 gates run bit-position rows and 2^19 buckets with ~12 entries per bucket.  bench.py's dense circuit, the
+    whole proof against the C oracle."""
+    import bench
+    monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    n = 1 << log_n
+    _cases.clear()
+    wires, cols, trivial = bench.synth_circuit(log_n)
+    polys = {k: C.fr_bytes(v) for k, v in trivial.items()}
+    for name, raw in cols.items():
+        polys[name] = cbind.ntt_bytes(raw, log_n, True, False, n)
+    srs = C.synthetic_srs(n + 7)
+    case = dict(constraints=n, size=n, label=b"bench", polys=polys, wires=wires, pi={}, pi_idx=[], pi_val=b"")
+    bl = C.blinders(1800 + log_n)
+    got, vk = gpu_proof(ctx, case, srs, bl)
+    cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk)
+    expected = cp.prove(wires, [], b"", bl)
+    cp.close()
+    assert got == expected
+
+
 @pytest.mark.parametrize("profile,log_n", [("bench-like", 13), ("widgets", 13), ("dense", 12),
                                             pytest.param("bench-like", 17, marks=pytest.mark.slow)])   # 2^17: chunked coarse bins inside prove()
 def test_wire_commitment_modes_agree_with_each_other_and_the_oracle(ctx, monkeypatch, profile, log_n):
