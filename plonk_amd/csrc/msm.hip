@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
     // additions at a lone wave's ~10 cycles per instruction: 200 us for ONE 2^16-term commitment, 400 for a group of four —
     // as long as the accumulation it follows (profiles/r04a).  A quad per bucket is 2^17 lanes and ns - 1 quad additions.
     const uint32_t nmulti = dense_quad ? MSM_NB : nheavy_all[2 * MSM_MAX_BATCH + kb];
-    const uint32_t* __restrict__ list = multi_list_all + (uint64_t)kb * MSM_NB;
+    const uint32_t* __restrict__ list = multi_list_all ? multi_list_all + (uint64_t)kb * MSM_NB : nullptr;
     const uint32_t q = threadIdx.x & 3;
     for (uint32_t i = ((blockIdx.x - fused) * blockDim.x + threadIdx.x) >> 2; i < nmulti; i += ((gridDim.x - fused) * blockDim.x) >> 2) {
       const uint32_t mb = dense_quad ? i : list[i];
