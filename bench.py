@@ -436,9 +436,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    log_n = args.log_gates
     if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":   # several ranks on ONE GPU (functional test on a 1-GPU box)
         local_rank = 0
-    log_n = args.log_gates
+        # Every rank sizes its tables for a device of its own ("at most half of the free HBM"): W ranks on one device would
+        # each take a row per bit position for both of their keys — 8 x 32 GiB at 2^22 gates / W = 8 — and run it out of memory.
+        # Sharing ranks therefore agree on the densest layout whose W copies fit in ~half of the device: every second bit
+        # position (the same 2^19-bucket kernels), else window rows.  A real multi-GPU run never takes this branch.
+        if world > 1 and "PLONK_MSM_TABLE" not in os.environ:
+            per_rank_points = ((1 << log_n) + 7 + world - 1) // world
+            bitpos_bytes = world * 2 * 256 * 128 * per_rank_points          # commit key + Lagrange-basis slice, 256 rows of 128 B
+            if per_rank_points > (1 << 18) + 64 and bitpos_bytes > 120 << 30:
+                os.environ["PLONK_MSM_TABLE"] = "halfpos" if bitpos_bytes // 2 <= 140 << 30 else "window"
     ctx = plonk_amd.Context(local_rank)
     dist = None
     allgather = None
