@@ -1200,38 +1200,61 @@ static constexpr uint32_t TP_RC2 = RCQ_SUMS + (1u << TP_E);      // stage-1.5 su
 // LPS lanes per sum of 128 buckets: a lane adds 128 / LPS buckets serially, then a log2(LPS)-step tree.  8 for groups of 2-4
 // commitments (15 + 3 additions per lane, 88 % of the lane-steps useful), 16 for a single commitment (7 + 4, 72 %): the rule
 // and its measurements are at the launch (msm_batch_device_v).
-template <int LPS>
+// The LPS partial sums of a sum are combined by QUADS (QT, round 4): the tree of the lane version runs log2(LPS) full
+// additions on every wave with half, a quarter, ... of its lanes active; here the 32 quads of the workgroup share the
+// PER * (LPS - 1) pair additions level by level (g1r_add_quad: ~2.7 k instructions against ~7.6 k), 4 quad additions in
+// sequence for LPS = 8 instead of 3 full ones.  slot(sum, k): where partial k of a sum sits in sh (rows: the lanes of a sum
+// are adjacent; columns: PER apart).
+template <int LPS, bool QT>
 __global__ void __launch_bounds__(128) msm_rowcol_tp_kernel(const G1RSlot* __restrict__ buckets_all, G1RSlot* __restrict__ rc1_all) {
   constexpr uint32_t PER = 128 / LPS;          // buckets per lane = sums per workgroup
   __shared__ G1R sh[128];
   const G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)blockIdx.y * MSM_NB;
   G1RSlot* __restrict__ rc1 = rc1_all + (uint64_t)blockIdx.y * TP_RC1;
   const uint32_t t = threadIdx.x;
-  if (blockIdx.x < TP_ROWS / PER) {         // PER rows per workgroup, LPS lanes per row
-    const uint32_t row = PER * blockIdx.x + t / LPS, s = t % LPS;
+  const bool rows = blockIdx.x < TP_ROWS / PER;   // uniform per workgroup
+  uint32_t s, out;
+  G1R acc;
+  if (rows) {                                  // PER rows per workgroup, LPS lanes per row
+    const uint32_t row = PER * blockIdx.x + t / LPS;
+    s = t % LPS;
+    out = row;
     const G1RSlot* base = buckets + (uint64_t)row * 128 + PER * s;
-    G1R acc = ld_g1r(base);
+    acc = ld_g1r(base);
     for (uint32_t k = 1; k < PER; ++k) acc = acc.add(ld_g1r(base + k));
-    for (uint32_t d = LPS / 2; d >= 1; d >>= 1) {
-      sh[t] = acc;
-      __syncthreads();
-      if (s < d) acc = acc.add(sh[t + d]);
-      __syncthreads();
-    }
-    if (s == 0) st_g1r(rc1 + row, acc);
-  } else {                                    // (part, PER columns) per workgroup, LPS lanes (PER rows each) per column
-    const uint32_t w = blockIdx.x - TP_ROWS / PER, p = w / LPS, l0 = PER * (w % LPS) + (t % PER), s = t / PER;
+  } else {                                     // (part, PER columns) per workgroup, LPS lanes (PER rows each) per column
+    const uint32_t w = blockIdx.x - TP_ROWS / PER, p = w / LPS, l0 = PER * (w % LPS) + (t % PER);
+    s = t / PER;
+    out = TP_ROWS + p * 128 + l0;
     const G1RSlot* base = buckets + ((uint64_t)128 * p + PER * s) * 128 + l0;
-    G1R acc = ld_g1r(base);
+    acc = ld_g1r(base);
     for (uint32_t k = 1; k < PER; ++k) acc = acc.add(ld_g1r(base + (uint64_t)k * 128));
+  }
+  const uint32_t stride = rows ? 1u : PER;     // distance in sh between partial k and k + 1 of the same sum
+  if (!QT) {
     for (uint32_t d = LPS / 2; d >= 1; d >>= 1) {
       sh[t] = acc;
       __syncthreads();
-      if (s < d) acc = acc.add(sh[t + PER * d]);
+      if (s < d) acc = acc.add(sh[t + stride * d]);
       __syncthreads();
     }
-    if (s == 0) st_g1r(rc1 + TP_ROWS + p * 128 + l0, acc);
+    if (s == 0) st_g1r(rc1 + out, acc);
+    return;
   }
+  sh[t] = acc;
+  __syncthreads();
+  const uint32_t q = t & 3, quad = t >> 2;
+  for (uint32_t m = LPS; m > 1; m >>= 1) {     // m partials per sum -> m / 2
+    const uint32_t half = m / 2, adds = PER * half;
+    for (uint32_t a = quad; a < adds; a += 32) {
+      const uint32_t sum = a / half, k = a % half;
+      const uint32_t i0 = rows ? sum * LPS + k : k * PER + sum;
+      const G1R r = g1r_add_quad(sh[i0], sh[i0 + stride * half], q);
+      if (q == 0) sh[i0] = r;                  // (distinct additions of a level touch distinct slots)
+    }
+    __syncthreads();
+  }
+  if (s == 0) st_g1r(rc1 + out, sh[t]);        // partial 0 of the thread's own sum: slot t
 }
 // stage 1.5 (quad additions, 64 logical lanes per sum): rc2 = [G_g (256) | C_l (128) | identity (128) | H_r (2^E)]
 __global__ void __launch_bounds__(256) msm_fold_quad_kernel(const G1RSlot* __restrict__ rc1_all, G1RSlot* __restrict__ rc2_all) {
@@ -1359,7 +1382,10 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   {   // many buckets: throughput row / column sums, the fold to the 2^15 shapes, then the same bit sums (outputs shifted by E)
     G1RSlot* rc1 = (G1RSlot*)w.chunk;
     G1RSlot* rc2 = rc1 + (size_t)TP_RC1 * MSM_MAX_BATCH;
-#define TPK(LPS) hipLaunchKernelGGL(msm_rowcol_tp_kernel<LPS>, dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1)
+    // PLONK_MSM_RCTREE=lane: the partial sums of a row / column combined by a lane tree instead of quads (A/B)
+    static const bool rc_lane_tree = [] { const char* e = getenv("PLONK_MSM_RCTREE"); return e && e[0] == 'l'; }();
+#define TPK(LPS) do { if (rc_lane_tree) hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, false>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); \
+                      else hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, true>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); } while (0)
     // lanes per sum of 128 buckets: the chip holds 2^17 lanes at two waves per SIMD and a commitment has 2^13 sums; fewer
     // lanes per sum waste less of the tree steps (useful additions per lane-step: LPS 4: 96 %, 8: 88 %, 16: 72 %, 32: 50 %)
     // but lengthen the serial chain.  Measured (profiles/r03e section 7): 8 / 8 / 16 for groups of >= 3 / 2 / 1 commitments
