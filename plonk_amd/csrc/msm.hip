@@ -859,9 +859,13 @@ __global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G
   G1R acc = G1R::identity();
   for (uint32_t i = L; i < (u == 16 ? 256u : 128u); i += 64) {
     G1R p = G1R::identity();
-    if (u >= 17) {                     // low row bit j = u - 17: the H_r whose index has bit j set (2^(E-1) of them)
-      const uint32_t j = u - 17;
-      if (i < (1u << extra) && ((i >> j) & 1u)) p = ld_g1r(rc + RCQ_SUMS + i);
+    if (u >= 17) {                     // low row bit j = u - 17: the parts P[sg][r] (16 per r, msm_fold_quad_kernel) of the H_r whose index r has bit j set
+      const uint32_t j = u - 17, hb = extra - 1u;                       // 16 * 2^(E-1) points, at most 128
+      if (i < (16u << hb)) {
+        const uint32_t sg = i >> hb, rr = i & ((1u << hb) - 1u);
+        const uint32_t r = ((rr >> j) << (j + 1)) | (1u << j) | (rr & ((1u << j) - 1u));
+        p = ld_g1r(rc + RCQ_SUMS + (sg << extra) + r);
+      }
     } else if (u == 16) {              // S = the sum of all 256 rows = of all buckets (bit-position entries: 2 W - S)
       p = ld_g1r(rc + i);
     } else if (u < 8) {                // 128 of the 256 rows
@@ -1196,7 +1200,8 @@ static uint32_t msm_ksl(uint64_t m) {
 static constexpr uint32_t TP_E = MSM_NB_BITS - 15;
 static constexpr uint32_t TP_ROWS = MSM_NB / 128, TP_PARTS = TP_ROWS / 128;
 static constexpr uint32_t TP_RC1 = 2 * TP_ROWS;                  // stage-1 sums per commitment
-static constexpr uint32_t TP_RC2 = RCQ_SUMS + (1u << TP_E);      // stage-1.5 sums per commitment: the 2^15 layout + H_r
+static constexpr uint32_t TP_NP = 16u << TP_E;                  // partial low-row sums P[sg][r] = sum of R_h over the 16 groups g of super-group sg, h = 2^E g + r
+static constexpr uint32_t TP_RC2 = RCQ_SUMS + TP_NP;            // stage-1.5 sums per commitment: the 2^15 layout + the P[sg][r]
 // LPS lanes per sum of 128 buckets: a lane adds 128 / LPS buckets serially, then a log2(LPS)-step tree.  8 for groups of 2-4
 // commitments (15 + 3 additions per lane, 88 % of the lane-steps useful), 16 for a single commitment (7 + 4, 72 %): the rule
 // and its measurements are at the launch (msm_batch_device_v).
@@ -1264,8 +1269,11 @@ __global__ void __launch_bounds__(256) msm_fold_quad_kernel(const G1RSlot* __res
   const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
   uint32_t npts, first, stride, dst;
   if (u < 256) { npts = 1u << TP_E; first = u << TP_E; stride = 1; dst = u; }                                   // G_g
-  else if (u < 256 + (1u << TP_E)) { npts = 256; first = u - 256; stride = 1u << TP_E; dst = RCQ_SUMS + (u - 256); }   // H_r
-  else { const uint32_t l0 = u - 256 - (1u << TP_E); npts = TP_PARTS; first = TP_ROWS + l0; stride = 128; dst = RC_ROWS + l0; }   // C_l
+  else if (u < 256 + TP_NP) {   // P[sg][r]: 16 of the 256 terms of H_r = sum_g R_(2^E g + r) — a whole H_r was 4 serial + 6 tree quad additions,
+    const uint32_t v = u - 256, sg = v >> TP_E, r = v & ((1u << TP_E) - 1u);   // the longest chain of this kernel; the bit sums add the 16 parts (r04)
+    npts = 16; first = ((16u * sg) << TP_E) + r; stride = 1u << TP_E; dst = RCQ_SUMS + v;
+  }
+  else { const uint32_t l0 = u - 256 - TP_NP; npts = TP_PARTS; first = TP_ROWS + l0; stride = 128; dst = RC_ROWS + l0; }   // C_l
   G1R acc = G1R::identity();
   for (uint32_t i = L; i < npts; i += 64) acc = g1r_add_quad(acc, ld_g1r(rc1 + first + (uint64_t)i * stride), q);
   for (uint32_t d = 32; d >= 1; d >>= 1) {
@@ -1401,7 +1409,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     FINE_BEGIN(4);
     if (lps == 4) TPK(4); else if (lps == 8) TPK(8); else if (lps == 16) TPK(16); else TPK(32);
 #undef TPK
-    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + (1u << TP_E) + 128, count), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
+    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + TP_NP + 128, count), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
     FINE_END(4);
     FINE_BEGIN(5);
     hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
