@@ -38,8 +38,14 @@
 
 namespace plonk {
 
-static constexpr int TILE_LOG = 11;
 static constexpr int NTT_THREADS = 256;
+static constexpr int NTT_THREAD_BITS = 8;
+// Elements per lane: 2^ELOG, tile = 2^(8 + ELOG) elements per 256-thread workgroup.  ELOG = 3 (8 elements, radix-8 register
+// rounds, 2048-element tiles, 72 KiB of LDS, ~234 VGPRs: two waves per SIMD) is the round 1-3 kernel; ELOG = 2 (round 4:
+// 4 elements, radix-4 rounds, 1024-element tiles, 36 KiB, <= 128 VGPRs: four waves per SIMD) trades one more LDS exchange
+// per pass for twice the waves to cover the strided tile loads and twiddle gathers (PLONK_NTT_ELOG, ntt_elog()).
+static constexpr int NTT_ELOG_MAX = 3;
+static constexpr int NTT_ELOG_DEFAULT = 3;
 static constexpr int TWLO_BITS = 13;
 static constexpr int GLO_BITS = 10;
 static constexpr int NTT_DIRECT_MAX_LOG = 25;
@@ -119,15 +125,15 @@ template <int POS, int RB>
 __device__ __forceinline__ int elem_index(int t, int e) {
   const int j = e & ((1 << RB) - 1);
   const int ge = e >> RB;
-  const int rest = (ge << (TILE_LOG - 3)) | t;
+  const int rest = (ge << NTT_THREAD_BITS) | t;
   const int lo = rest & ((1 << POS) - 1);
   const int hi = rest >> POS;
   return (hi << (POS + RB)) | (j << POS) | lo;
 }
 
 // One DIF stage on local bit LB of a register round (global row bit LO + LB).
-template <int RLOG, int LO, int LB>
-__device__ __forceinline__ void dif_stage(Fr29 (&v)[8], int rlow_thread, const Fr29Slot* __restrict__ wtab) {
+template <int RLOG, int LO, int LB, int E>
+__device__ __forceinline__ void dif_stage(Fr29 (&v)[E], int rlow_thread, const Fr29Slot* __restrict__ wtab) {
   constexpr int bitpos = LO + LB;
 #pragma unroll
   for (int x = 0; x < (1 << LB); ++x) {
@@ -141,7 +147,7 @@ __device__ __forceinline__ void dif_stage(Fr29 (&v)[8], int rlow_thread, const F
       w = ld_tw(wtab + (rlow << (8 - bitpos)));
     }
 #pragma unroll
-    for (int y = 0; y < (8 >> (LB + 1)); ++y) {         // bits above LB (incl. extra groups)
+    for (int y = 0; y < (E >> (LB + 1)); ++y) {         // bits above LB (incl. extra groups)
       const int e = (y << (LB + 1)) | x;
       const int e2 = e | (1 << LB);
       const Fr29 a = v[e], b = v[e2];
@@ -153,37 +159,40 @@ __device__ __forceinline__ void dif_stage(Fr29 (&v)[8], int rlow_thread, const F
 }
 
 // One register round: RB DIF stages on the row bits [LO, LO+RB), top bit first.
-template <int RLOG, int LO, int RB>
-__device__ __forceinline__ void dif_round(Fr29 (&v)[8], int t, const Fr29Slot* __restrict__ wtab) {
-  constexpr int CLOG = TILE_LOG - RLOG;
+template <int RLOG, int LO, int RB, int ELOG>
+__device__ __forceinline__ void dif_round(Fr29 (&v)[1 << ELOG], int t, const Fr29Slot* __restrict__ wtab) {
+  constexpr int CLOG = NTT_THREAD_BITS + ELOG - RLOG;
+  static_assert(RB <= ELOG && CLOG + LO <= NTT_THREAD_BITS, "the row bits below a round come from the thread index");
   const int rlow_thread = (LO > 0) ? ((t >> CLOG) & ((1 << LO) - 1)) : 0;
-  if constexpr (RB >= 3) dif_stage<RLOG, LO, 2>(v, rlow_thread, wtab);
-  if constexpr (RB >= 2) dif_stage<RLOG, LO, 1>(v, rlow_thread, wtab);
-  dif_stage<RLOG, LO, 0>(v, rlow_thread, wtab);
+  if constexpr (RB >= 3) dif_stage<RLOG, LO, 2, (1 << ELOG)>(v, rlow_thread, wtab);
+  if constexpr (RB >= 2) dif_stage<RLOG, LO, 1, (1 << ELOG)>(v, rlow_thread, wtab);
+  dif_stage<RLOG, LO, 0, (1 << ELOG)>(v, rlow_thread, wtab);
 }
 
-template <int RLOG, int R_IDX>
+template <int RLOG, int R_IDX, int ELOG>
 struct RoundGeom {
-  static constexpr int HI = RLOG - 3 * R_IDX;
-  static constexpr int LO = (HI - 3 > 0) ? HI - 3 : 0;
+  static constexpr int HI = RLOG - ELOG * R_IDX;
+  static constexpr int LO = (HI - ELOG > 0) ? HI - ELOG : 0;
   static constexpr int RB = HI - LO;
-  static constexpr int POS = (TILE_LOG - RLOG) + LO;
+  static constexpr int POS = (NTT_THREAD_BITS + ELOG - RLOG) + LO;
 };
 
-template <int RLOG, int R_IDX, int NR>
+template <int RLOG, int R_IDX, int NR, int ELOG>
 struct Rounds {
   // rounds R_IDX .. NR-1; on entry v holds round R_IDX's elements
-  __device__ static __forceinline__ void run(Fr29 (&v)[8], int t, uint32_t* data, const Fr29Slot* __restrict__ wtab) {
-    using G = RoundGeom<RLOG, R_IDX>;
-    dif_round<RLOG, G::LO, G::RB>(v, t, wtab);
+  __device__ static __forceinline__ void run(Fr29 (&v)[1 << ELOG], int t, uint32_t* data, const Fr29Slot* __restrict__ wtab) {
+    constexpr int TILE_LOG = NTT_THREAD_BITS + ELOG;
+    using G = RoundGeom<RLOG, R_IDX, ELOG>;
+    dif_round<RLOG, G::LO, G::RB, ELOG>(v, t, wtab);
     if constexpr (R_IDX + 1 < NR) {
-      using Gn = RoundGeom<RLOG, R_IDX + 1>;
+      using Gn = RoundGeom<RLOG, R_IDX + 1, ELOG>;
+      // a lane stores to the very indices it loaded this round's operands from: no barrier needed before the stores
 #pragma unroll
-      for (int e = 0; e < 8; ++e) lds_put(data, 1 << TILE_LOG, elem_index<G::POS, G::RB>(t, e), v[e]);
+      for (int e = 0; e < (1 << ELOG); ++e) lds_put(data, 1 << TILE_LOG, elem_index<G::POS, G::RB>(t, e), v[e]);
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = lds_get(data, 1 << TILE_LOG, elem_index<Gn::POS, Gn::RB>(t, e));
-      Rounds<RLOG, R_IDX + 1, NR>::run(v, t, data, wtab);
+      for (int e = 0; e < (1 << ELOG); ++e) v[e] = lds_get(data, 1 << TILE_LOG, elem_index<Gn::POS, Gn::RB>(t, e));
+      Rounds<RLOG, R_IDX + 1, NR, ELOG>::run(v, t, data, wtab);
     }
   }
 };
@@ -198,23 +207,26 @@ __device__ __forceinline__ Fr29 two_level(const Fr29Slot* lo, const Fr29Slot* hi
   if (use_hi) w = Fr29::mul(w, ld_tw(hi + (e >> lobits)));
   return w;
 }
-// compile-time loop over the 8 elements of a lane: f(std::integral_constant<int, e>) for e = 0 .. 7
+// compile-time loop over the E elements of a lane: f(std::integral_constant<int, e>) for e = 0 .. E - 1
 template <typename F, int... Is>
-__device__ __forceinline__ void for_e8_impl(F&& f, std::integer_sequence<int, Is...>) {
+__device__ __forceinline__ void for_elems_impl(F&& f, std::integer_sequence<int, Is...>) {
   (f(std::integral_constant<int, Is>{}), ...);
 }
-template <typename F>
-__device__ __forceinline__ void for_e8(F&& f) {
-  for_e8_impl(static_cast<F&&>(f), std::make_integer_sequence<int, 8>{});
+template <int E, typename F>
+__device__ __forceinline__ void for_elems(F&& f) {
+  for_elems_impl(static_cast<F&&>(f), std::make_integer_sequence<int, E>{});
 }
 
-template <int RLOG, bool TRANSPOSE>
-__global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
+template <int RLOG, bool TRANSPOSE, int ELOG>
+__global__ void __launch_bounds__(NTT_THREADS, ELOG == 2 ? 4 : 2) ntt_pass_kernel(NttPass p) {
+  constexpr int E = 1 << ELOG;
+  constexpr int TILE_LOG = NTT_THREAD_BITS + ELOG;
   constexpr int CLOG = TILE_LOG - RLOG;
   constexpr int C = 1 << CLOG;
-  constexpr int NR = (RLOG + 2) / 3;
+  constexpr int NR = (RLOG + ELOG - 1) / ELOG;
+  static_assert(CLOG >= 1 && RLOG <= 9, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint32_t* data = smem;                       // 9 * 2048 u32
+  uint32_t* data = smem;                       // 9 * 2^TILE_LOG u32
   const Fr29Slot* __restrict__ wtab = p.w512;
   const int t = threadIdx.x;
   const uint64_t cg0 = (uint64_t)blockIdx.x * C;
@@ -223,14 +235,14 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
   // block (index clamped to 0 beyond in_len, the value masked to zero afterwards): with a branch per element the
   // compiler waited for each load before issuing the next — eight exposed HBM latencies per wave at two waves per SIMD
   // (r03e: the passes ran at 5.7-6.4 cycles per VALU instruction against 4.7 in msm_accumulate).
-  // for_e8 is a compile-time loop: `#pragma unroll` gives up on bodies of this size (a Montgomery product is ~600
+  // for_elems is a compile-time loop: `#pragma unroll` gives up on bodies of this size (a Montgomery product is ~600
   // instructions) and a rolled loop would index the arrays in scratch memory.
-  using G0 = RoundGeom<RLOG, 0>;
-  Fr29 v[8];
+  using G0 = RoundGeom<RLOG, 0, ELOG>;
+  Fr29 v[E];
   {
-    Fr raw[8];
-    uint64_t gis[8];
-    for_e8([&](auto ec) __attribute__((always_inline)) {
+    Fr raw[E];
+    uint64_t gis[E];
+    for_elems<E>([&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value;
       const int idx = elem_index<G0::POS, G0::RB>(t, e);
       const uint64_t row = idx >> CLOG;
@@ -238,7 +250,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
       gis[e] = row * p.in_rs + (cg >> p.in_hshift) * p.in_hs + (cg & ((1ull << p.in_hshift) - 1));
       raw[e] = ld_fr(p.src + (gis[e] < p.in_len ? gis[e] : 0));   // in_len >= 1 (ntt_device)
     });
-    for_e8([&](auto ec) __attribute__((always_inline)) {
+    for_elems<E>([&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value;
       const uint32_t keep = gis[e] < p.in_len ? 0xffffffffu : 0u;
       const Fr29 x = Fr29::from_fr(raw[e]);
@@ -246,23 +258,23 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
       for (int l = 0; l < Fr29::N; ++l) v[e].l[l] = x.l[l] & keep;
     });
     if (p.pre_coset) {   // coset scale g^i of the valid coefficients (n + 3 of 4n in the prover: whole rows are skipped)
-      for_e8([&](auto ec) __attribute__((always_inline)) {
+      for_elems<E>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         if (gis[e] < p.in_len) v[e] = Fr29::mul(v[e], two_level(p.g_lo, p.g_hi, gis[e], GLO_BITS, true));
       });
     }
   }
-  Rounds<RLOG, 0, NR>::run(v, t, data, wtab);
+  Rounds<RLOG, 0, NR, ELOG>::run(v, t, data, wtab);
 
   // ---- epilogue: inter-pass twiddle / scaling, then store.  The pass-wide modes are tested OUTSIDE the element loops so
   // that each loop is one basic block: the eight twiddle loads (HBM gathers with the direct table of pass A) go out
   // together and the multiplications follow.
-  using GL = RoundGeom<RLOG, NR - 1>;
+  using GL = RoundGeom<RLOG, NR - 1, ELOG>;
   const uint64_t nmask = (1ull << p.logN) - 1;
   const bool use_hi = p.logN > TWLO_BITS;
-  uint32_t ks[8];
-  uint64_t cgs[8];
-  for_e8([&](auto ec) __attribute__((always_inline)) {
+  uint32_t ks[E];
+  uint64_t cgs[E];
+  for_elems<E>([&](auto ec) __attribute__((always_inline)) {
     constexpr int e = decltype(ec)::value;
     const int idx = elem_index<GL::POS, GL::RB>(t, e);
     const uint32_t prow = idx >> CLOG;
@@ -271,18 +283,18 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
   });
   if (p.tw_mode) {
     if (p.tw_direct) {
-      Fr29 tw[8];
-      for_e8([&](auto ec) __attribute__((always_inline)) {
+      Fr29 tw[E];
+      for_elems<E>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         const uint64_t twcol = (cgs[e] >> p.tw_shr) << p.tw_shr;
         tw[e] = ld_tw(p.tw_direct + ((((uint64_t)ks[e] * twcol) & nmask) >> p.tw_shr));   // tests/ntt_model.py: direct_index
       });
-      for_e8([&](auto ec) __attribute__((always_inline)) {
+      for_elems<E>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         v[e] = Fr29::mul(v[e], tw[e]);
       });
     } else {
-      for_e8([&](auto ec) __attribute__((always_inline)) {
+      for_elems<E>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         const uint64_t twcol = (cgs[e] >> p.tw_shr) << p.tw_shr;
         v[e] = Fr29::mul(v[e], two_level(p.tw_lo, p.tw_hi, ((uint64_t)ks[e] * twcol) & nmask, TWLO_BITS, use_hi));
@@ -290,36 +302,36 @@ __global__ void __launch_bounds__(NTT_THREADS, 2) ntt_pass_kernel(NttPass p) {
     }
   }
   if constexpr (!TRANSPOSE) {
-    uint64_t os[8];
-    for_e8([&](auto ec) __attribute__((always_inline)) {
+    uint64_t os[E];
+    for_elems<E>([&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value;
       os[e] = (uint64_t)ks[e] * p.out_rs + (cgs[e] >> p.out_hshift) * p.out_hs + (cgs[e] & ((1ull << p.out_hshift) - 1)) * p.out_ls;
     });
     if (p.post_mode == 1) {
-      for_e8([&](auto ec) __attribute__((always_inline)) {
+      for_elems<E>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         v[e] = Fr29::mul(v[e], p.scale);
       });
     } else if (p.post_mode == 2) {
-      for_e8([&](auto ec) __attribute__((always_inline)) {
+      for_elems<E>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         v[e] = Fr29::mul(v[e], two_level(p.g_lo, p.g_hi, os[e], GLO_BITS, true));
       });
     }
-    for_e8([&](auto ec) __attribute__((always_inline)) {
+    for_elems<E>([&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value;
       st_fr(p.dst + os[e], v[e].to_fr());
     });
   } else {
     constexpr int R = 1 << RLOG;
     __syncthreads();   // everyone finished reading `data` for the last round
-    for_e8([&](auto ec) __attribute__((always_inline)) {
+    for_elems<E>([&](auto ec) __attribute__((always_inline)) {
       constexpr int e = decltype(ec)::value;
       lds_put(data, 1 << TILE_LOG, (int)(cgs[e] - cg0) * R + (int)ks[e], v[e]);
     });
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < E; ++i) {
       const int u = i * NTT_THREADS + t;
       const int col = u >> RLOG;
       const uint64_t k = u & (R - 1);
@@ -504,26 +516,42 @@ int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
   return PLONK_OK;
 }
 
-template <int RLOG>
-static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint32_t nblocks) {
+template <int RLOG, int ELOG>
+static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint64_t cols) {
+  constexpr int TILE_LOG = NTT_THREAD_BITS + ELOG;
   constexpr size_t smem = (size_t)Fr29::N * (1 << TILE_LOG) * sizeof(uint32_t);
+  const uint32_t nblocks = (uint32_t)(cols >> (TILE_LOG - RLOG));   // a workgroup owns 2^(TILE_LOG - RLOG) columns of R rows
   if (transpose) {
-    smem_opt_in(c, (const void*)ntt_pass_kernel<RLOG, true>, smem);
-    hipLaunchKernelGGL((ntt_pass_kernel<RLOG, true>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
+    smem_opt_in(c, (const void*)ntt_pass_kernel<RLOG, true, ELOG>, smem);
+    hipLaunchKernelGGL((ntt_pass_kernel<RLOG, true, ELOG>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
   } else {
-    smem_opt_in(c, (const void*)ntt_pass_kernel<RLOG, false>, smem);
-    hipLaunchKernelGGL((ntt_pass_kernel<RLOG, false>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
+    smem_opt_in(c, (const void*)ntt_pass_kernel<RLOG, false, ELOG>, smem);
+    hipLaunchKernelGGL((ntt_pass_kernel<RLOG, false, ELOG>), dim3(nblocks), dim3(NTT_THREADS), smem, c->stream, p);
   }
 }
 
-static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, uint32_t nblocks) {
-  switch (rlog) {
+// Elements per lane of the pass kernels (log2): PLONK_NTT_ELOG=2|3 forces either; a radix of 2^9 always runs with 8
+// elements (a 1024-element tile would be two columns wide: 64-byte runs).
+static int ntt_elog(int rlog) {
+  static const int forced = [] { const char* e = getenv("PLONK_NTT_ELOG"); return e && (e[0] == '2' || e[0] == '3') ? e[0] - '0' : 0; }();
+  if (rlog >= 9) return 3;
+  return forced ? forced : NTT_ELOG_DEFAULT;
+}
+
+// cols: columns of the [R = 2^rlog rows][cols] view the pass transforms (N / R)
+static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, uint64_t cols) {
+  const int elog = ntt_elog(rlog);
+  switch (rlog * 4 + elog) {
     // ntt_plan() only produces radices 5..9 for N >= 2^11
-    case 5: launch_pass<5>(c, p, transpose, nblocks); break;
-    case 6: launch_pass<6>(c, p, transpose, nblocks); break;
-    case 7: launch_pass<7>(c, p, transpose, nblocks); break;
-    case 8: launch_pass<8>(c, p, transpose, nblocks); break;
-    case 9: launch_pass<9>(c, p, transpose, nblocks); break;
+    case 5 * 4 + 3: launch_pass<5, 3>(c, p, transpose, cols); break;
+    case 6 * 4 + 3: launch_pass<6, 3>(c, p, transpose, cols); break;
+    case 7 * 4 + 3: launch_pass<7, 3>(c, p, transpose, cols); break;
+    case 8 * 4 + 3: launch_pass<8, 3>(c, p, transpose, cols); break;
+    case 9 * 4 + 3: launch_pass<9, 3>(c, p, transpose, cols); break;
+    case 5 * 4 + 2: launch_pass<5, 2>(c, p, transpose, cols); break;
+    case 6 * 4 + 2: launch_pass<6, 2>(c, p, transpose, cols); break;
+    case 7 * 4 + 2: launch_pass<7, 2>(c, p, transpose, cols); break;
+    case 8 * 4 + 2: launch_pass<8, 2>(c, p, transpose, cols); break;
     default: return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   }
   HIP_TRY(hipGetLastError());
@@ -577,8 +605,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.in_len = in_len; p.pre_coset = (coset && !inverse) ? 1 : 0;
     p.post_mode = 0; p.g_lo = g_lo29; p.g_hi = g_hi29;
     p.w512 = (const Fr29Slot*)tb->w512_29;
-    const uint32_t nb = (uint32_t)((N >> r[0]) >> (TILE_LOG - r[0]));
-    if ((rc = launch_pass_rt(c, r[0], p, true, nb))) return rc;
+    if ((rc = launch_pass_rt(c, r[0], p, true, N >> r[0]))) return rc;
   }
   // ---- pass B : tmp in place
   if (np == 3) {
@@ -591,8 +618,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.tw_direct = (const Fr29Slot*)tb->tw_b29;
     p.in_len = N; p.pre_coset = 0; p.post_mode = 0; p.w512 = (const Fr29Slot*)tb->w512_29;
     p.g_lo = g_lo29; p.g_hi = g_hi29;
-    const uint32_t nb = (uint32_t)((N >> r[1]) >> (TILE_LOG - r[1]));
-    if ((rc = launch_pass_rt(c, r[1], p, false, nb))) return rc;
+    if ((rc = launch_pass_rt(c, r[1], p, false, N >> r[1]))) return rc;
   }
   // ---- pass C : tmp -> dst
   {
@@ -605,8 +631,7 @@ int ntt_device(Ctx* c, const Fr* src, Fr* dst, Fr* tmp, uint32_t L, bool inverse
     p.post_mode = (inverse && coset) ? 2 : 0;   // n^-1 already folded in pass A
     p.scale = Fr29::zero(); p.g_lo = g_lo29; p.g_hi = g_hi29;
     p.w512 = (const Fr29Slot*)tb->w512_29;
-    const uint32_t nb = (uint32_t)((N >> rl) >> (TILE_LOG - rl));
-    if ((rc = launch_pass_rt(c, rl, p, false, nb))) return rc;
+    if ((rc = launch_pass_rt(c, rl, p, false, N >> rl))) return rc;
   }
   return PLONK_OK;
 }

@@ -8,9 +8,16 @@ name in ntt.hip.
 """
 from oracle.bls12_381 import GENERATOR, Q, ROOT_OF_UNITY, fr_inv
 
-TILE_LOG = 11      # 2048 elements per workgroup tile
+TILE_LOG = 11      # 2048 elements per workgroup tile (ntt.hip: NTT_THREAD_BITS + ELOG)
 THREADS = 256
-E = 8              # elements per thread
+ELOG = 3           # log2 of the elements per thread: 3 (radix-8 register rounds) or 2 (round 4: radix-4 rounds, 1024-element tiles)
+
+
+def set_geometry(tile_log, threads, elog):
+    """Switch the model between the kernel's two compiled geometries (or a scaled-down one for fast tests)."""
+    global TILE_LOG, THREADS, ELOG
+    assert threads << elog == 1 << tile_log
+    TILE_LOG, THREADS, ELOG = tile_log, threads, elog
 
 
 def plan(L):
@@ -35,7 +42,7 @@ def elem_index(t, e, pos, rb):
     active row bits sit at idx bits [pos, pos + rb)."""
     j = e & ((1 << rb) - 1)
     ge = e >> rb
-    rest = (ge << (TILE_LOG - 3)) | t
+    rest = (ge << (TILE_LOG - ELOG)) | t
     lo = rest & ((1 << pos) - 1)
     hi = rest >> pos
     return (hi << (pos + rb)) | (j << pos) | lo
@@ -52,7 +59,7 @@ def bitrev(x, bits):
 def rounds(RLOG):
     out, hi = [], RLOG
     while hi > 0:
-        lo = max(hi - 3, 0)
+        lo = max(hi - ELOG, 0)
         out.append((lo, hi - lo))
         hi = lo
     return out
@@ -68,6 +75,7 @@ def tile_dif(vals, RLOG, w512):
         pos = CLOG + lo
         new = list(lds)
         for t in range(THREADS):
+            E = 1 << ELOG
             idxs = [elem_index(t, e, pos, rb) for e in range(E)]
             v = [lds[i] for i in idxs]
             for lb in reversed(range(rb)):           # local bit, top first

@@ -217,3 +217,19 @@ def test_two_level_twiddle_fallback_matches_the_oracle():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("elog", ["2", "3"])
+def test_elements_per_lane_variants_match_the_oracle(elog):
+    """PLONK_NTT_ELOG=2 / 3: the pass kernels with 4 elements per lane (radix-4 register rounds over 1024-element tiles, four
+    waves per SIMD) and with 8 (radix-8 rounds over 2048-element tiles, two waves) — whichever is not the default would
+    otherwise never run in this suite.  Same transforms, in a child process because the switch is read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_ntt.py", "-x", "-q", "-m", "gpu", "-k",
+                        "two_pass or batch_of_five or full_size_properties or empty_input or (three_pass and 19)"], cwd=root,
+                       env=dict(os.environ, PLONK_NTT_ELOG=elog), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

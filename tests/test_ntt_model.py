@@ -25,13 +25,30 @@ def test_single_and_two_pass_plans():
 
 
 def test_three_pass_decomposition_small_tile():
-    old = (M.TILE_LOG, M.THREADS)
+    old = (M.TILE_LOG, M.THREADS, M.ELOG)
     try:
-        M.TILE_LOG, M.THREADS = 8, 32
+        M.set_geometry(8, 32, 3)
         _check(13, [5, 4, 4])
         _check(14, [5, 5, 4])
     finally:
-        M.TILE_LOG, M.THREADS = old
+        M.set_geometry(*old)
+
+
+def test_four_elements_per_lane_geometry():
+    """ELOG = 2 (ntt.hip, PLONK_NTT_ELOG=2): radix-4 register rounds over 1024-element tiles — the kernel's own geometry on
+    two-pass plans, a scaled-down one (same thread / element split) on three-pass plans."""
+    old = (M.TILE_LOG, M.THREADS, M.ELOG)
+    try:
+        M.set_geometry(10, 256, 2)
+        for L in (11, 12):
+            _check(L)
+        _check(13, [8, 5])                            # radix 2^8: four rounds of 2 bits
+        _check(12, [7, 5])                            # radix 2^7: rounds of 2, 2, 2, 1 bits
+        M.set_geometry(7, 32, 2)
+        _check(13, [5, 4, 4])
+        _check(14, [5, 5, 4])
+    finally:
+        M.set_geometry(*old)
 
 
 def test_plan_radices_within_kernel_limits():
