@@ -43,9 +43,13 @@ static constexpr int NTT_THREAD_BITS = 8;
 // Elements per lane: 2^ELOG, tile = 2^(8 + ELOG) elements per 256-thread workgroup.  ELOG = 3 (8 elements, radix-8 register
 // rounds, 2048-element tiles, 72 KiB of LDS, ~234 VGPRs: two waves per SIMD) is the round 1-3 kernel; ELOG = 2 (round 4:
 // 4 elements, radix-4 rounds, 1024-element tiles, 36 KiB, <= 128 VGPRs: four waves per SIMD) trades one more LDS exchange
-// per pass for twice the waves to cover the strided tile loads and twiddle gathers (PLONK_NTT_ELOG, ntt_elog()).
-static constexpr int NTT_ELOG_MAX = 3;
-static constexpr int NTT_ELOG_DEFAULT = 3;
+// per pass for twice the waves to cover the strided tile loads and twiddle gathers: the same instructions per element
+// (+0.6 %), transforms alone 6-10 % faster from 2^20 to 2^24 and 44 % at 2^16 (twice the workgroups for a chip that a
+// 2^16-point pass does not fill) — profiles/r04/log_r4v.txt.  It is the default; the one place where it LOSES is side-stream
+// work issued under a busy MSM pipeline (prover.hip SideScope): at <= 128 VGPRs the passes co-reside with the sort and
+// reduction kernels of the main stream and take issue slots from the critical path (2^20 gates: prove() 32.8 -> 33.4 ms,
+// 2^22: 120.3 -> 122.3), so that scope asks for ELOG = 3 through Ctx::ntt_elog_hint.  PLONK_NTT_ELOG=2|3 forces either.
+static constexpr int NTT_ELOG_DEFAULT = 2;
 static constexpr int TWLO_BITS = 13;
 static constexpr int GLO_BITS = 10;
 static constexpr int NTT_DIRECT_MAX_LOG = 25;
@@ -530,17 +534,18 @@ static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint64_t cols)
   }
 }
 
-// Elements per lane of the pass kernels (log2): PLONK_NTT_ELOG=2|3 forces either; a radix of 2^9 always runs with 8
-// elements (a 1024-element tile would be two columns wide: 64-byte runs).
-static int ntt_elog(int rlog) {
+// Elements per lane of the pass kernels (log2): PLONK_NTT_ELOG=2|3 forces either, else the caller's hint (prover.hip), else
+// the default; a radix of 2^9 always runs with 8 elements (a 1024-element tile would be two columns wide: 64-byte runs).
+static int ntt_elog(const Ctx* c, int rlog) {
   static const int forced = [] { const char* e = getenv("PLONK_NTT_ELOG"); return e && (e[0] == '2' || e[0] == '3') ? e[0] - '0' : 0; }();
   if (rlog >= 9) return 3;
-  return forced ? forced : NTT_ELOG_DEFAULT;
+  if (forced) return forced;
+  return c->ntt_elog_hint == 2 || c->ntt_elog_hint == 3 ? c->ntt_elog_hint : NTT_ELOG_DEFAULT;
 }
 
 // cols: columns of the [R = 2^rlog rows][cols] view the pass transforms (N / R)
 static int launch_pass_rt(Ctx* c, int rlog, const NttPass& p, bool transpose, uint64_t cols) {
-  const int elog = ntt_elog(rlog);
+  const int elog = ntt_elog(c, rlog);
   switch (rlog * 4 + elog) {
     // ntt_plan() only produces radices 5..9 for N >= 2^11
     case 5 * 4 + 3: launch_pass<5, 3>(c, p, transpose, cols); break;

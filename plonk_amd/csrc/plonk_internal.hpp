@@ -135,6 +135,7 @@ struct Ctx {
   hipStream_t main_stream = nullptr;
   hipStream_t side_stream = nullptr;   // low priority: challenge-independent NTTs overlapped with MSM phases
   hipEvent_t acc_done = nullptr;       // when set: recorded by msm_batch_device right after its msm_accumulate launch (prover.hip gates side work on it)
+  int ntt_elog_hint = 0;               // 0: ntt.hip's default; 2 / 3: elements per lane (log2) of the pass kernels launched while it is set (prover.hip SideScope)
   std::mutex mu;         // serialises entry points (reference calls concurrently from rayon)
   std::mutex table_mu;
   std::map<uint32_t, NttTables*> ntt_tables;

@@ -138,15 +138,19 @@ static Fr omega_of(uint32_t L) {
 // Work that does not depend on a Fiat-Shamir challenge (the coset FFTs of the wire, public-input
 // and z polynomials) is issued on the context's low-priority side stream so it fills the
 // bandwidth-/latency-bound stretches of the MSM pipeline.  While a SideScope is alive every
-// launch helper (they all use c->stream) targets the side stream.
+// launch helper (they all use c->stream) targets the side stream.  These transforms run UNDER the sort, accumulation and
+// reduction kernels of the main stream: they use the 8-elements-per-lane pass kernels (two waves per SIMD, ~234 VGPRs), which
+// only take the CUs the main stream leaves free — the 4-element kernels (ntt.hip's default) co-reside with the main stream's
+// kernels and slow the critical path by more than they gain (profiles/r04/log_r4v.txt).
 struct SideScope {
   Ctx* c;
   explicit SideScope(Ctx* ctx, hipEvent_t wait_for) : c(ctx) {
     (void)hipEventRecord(wait_for, c->main_stream);
     (void)hipStreamWaitEvent(c->side_stream, wait_for, 0);
     c->stream = c->side_stream;
+    c->ntt_elog_hint = 3;
   }
-  ~SideScope() { c->stream = c->main_stream; }
+  ~SideScope() { c->stream = c->main_stream; c->ntt_elog_hint = 0; }
 };
 // Side work that must not start before an event ALREADY recorded on the main stream (the end of a group's
 // msm_accumulate): the transforms then fill the latency-bound tail of the group and the host synchronisation instead
