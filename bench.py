@@ -302,9 +302,12 @@ def ntt_roofline(ctx, log_n, qd8):
                      "hbm": {"achieved": round(64 * N / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)},
                      "hbm_frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)}
-    return {"bound": "valu-int-issue", "kernel": "ntt_pass_kernel (2-3 passes per transform)", "algorithmic_bytes": "64 N per transform",
+    elog = os.environ.get("PLONK_NTT_ELOG", "2")   # ntt.hip: 4 elements per lane by default (1024-element tiles, four waves per SIMD)
+    return {"bound": "valu-int-issue", "kernel": f"ntt_pass_kernel<R, T, ELOG = {elog}> (2-3 passes per transform)",
+            "elements_per_lane": 1 << int(elog) if elog in ("2", "3") else 4, "algorithmic_bytes": "64 N per transform",
             "note": "timed standalone with wall clock around 10 back-to-back launches; integer-VALU bound (Fr29 butterflies), "
-                    "a k-pass plan moves k x 64 N actual bytes", "transforms": out}
+                    "a k-pass plan moves k x 64 N actual bytes; inside prove() the side-stream transforms issued under a busy "
+                    "MSM pipeline use the 8-elements-per-lane kernels (DESIGN.md 4.1)", "transforms": out}
 
 
 def cpu_model():

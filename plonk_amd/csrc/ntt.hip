@@ -11,16 +11,17 @@
 //   stores TRANSPOSED; pass B (3-pass only) and pass C run the remaining digits
 //   in place.  Natural order in, natural order out, no bit-reversal pass
 //   (Stockham-style autosort through the transposed store).  Every pass moves a
-//   [R rows][C cols] tile of 2048 elements per 256-thread workgroup: global
+//   [R rows][C cols] tile of 256 * E elements per 256-thread workgroup: global
 //   loads/stores are runs of C (>= 4) consecutive 32-byte elements, the
 //   transposed store writes runs of R1 consecutive elements.
 //
-//   Inside a tile each thread keeps 8 elements and performs radix-8 decimation-in-frequency
+//   Inside a tile each thread keeps E elements and performs radix-E decimation-in-frequency
 //   rounds in registers, in the reduced-radix lazy form of fr29.cuh (9 x 29-bit limbs: a
 //   butterfly is ~290 VALU instructions, 162 of them v_mad_u64_u32, instead of ~890 with
 //   32-bit limbs and carry chains).  Rounds exchange data through LDS kept limb-planar
-//   (9 planes of u32, 72 KiB => two workgroups per CU) so DS traffic is plain 4-byte
-//   accesses.  Small twiddles (w_512^e) come from an L1-resident table; the inter-pass
+//   (9 planes of u32) so DS traffic is plain 4-byte accesses.  E = 4 (1024-element tiles, 36 KiB,
+//   four waves per SIMD) and E = 8 (2048-element tiles, 72 KiB, two waves) are both compiled:
+//   NTT_ELOG_DEFAULT below.  Small twiddles (w_512^e) come from an L1-resident table; the inter-pass
 //   twiddle w_N^e is TWLO[e & 8191] * TWHI[e >> 13].  Tables hold w * 2^261 (fr29.cuh) so
 //   data stays in the reference's Montgomery domain; elements are converted to canonical
 //   32-bit limbs only when a pass stores to HBM.
