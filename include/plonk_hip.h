@@ -25,7 +25,8 @@
  *
  * Ownership: the caller owns every host buffer; nothing is retained after return
  * except the SRS copy made by plonk_srs_load.  The context owns all device memory.
- * Errors: 0 = ok, < 0 = error code below; nothing throws or aborts across the ABI.
+ * Errors: 0 = ok, < 0 = error code below; nothing throws or aborts across the ABI (every
+ * entry point catches C++ exceptions: PLONK_ERR_NOMEM for std::bad_alloc, else PLONK_ERR_STATE).
  * The shim maps a non-zero NTT code to a panic (the reference asserts,
  * domain.rs:394,449) and PLONK_ERR_DEGREE to Error::PolynomialDegreeTooLarge
  * (key.rs:362-370).  Threading: every entry point takes a per-context mutex, so
@@ -52,7 +53,8 @@ enum {
   PLONK_ERR_STATE = -7,   /* prover: called out of order / missing key                  */
   PLONK_ERR_BYTES = -8,   /* serialized input too short (Error::NotEnoughBytes)         */
   PLONK_ERR_DATA = -9,    /* serialized input malformed (dusk_bytes::Error::InvalidData) */
-  PLONK_ERR_POINT = -10   /* commit-key point off curve / not in the subgroup (Error::PointMalformed) */
+  PLONK_ERR_POINT = -10,  /* commit-key point off curve / not in the subgroup (Error::PointMalformed) */
+  PLONK_ERR_NOMEM = -11   /* a host allocation failed inside the library (std::bad_alloc caught at the ABI)  */
 };
 
 /* `devices`: HIP device ordinals; ndev must be 1 (one process per GPU — multi-GPU runs

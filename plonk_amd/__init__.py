@@ -37,7 +37,7 @@ ERRORS = {
     -1: "PLONK_ERR_ARG", -2: "PLONK_ERR_HIP", -3: "PLONK_ERR_DEGREE (PolynomialDegreeTooLarge)",
     -4: "PLONK_ERR_NO_SRS", -5: "PLONK_ERR_NO_GPU", -6: "PLONK_ERR_UNSAT (CircuitUnsatisfied)",
     -7: "PLONK_ERR_STATE", -8: "PLONK_ERR_BYTES (NotEnoughBytes)", -9: "PLONK_ERR_DATA (InvalidData)",
-    -10: "PLONK_ERR_POINT (PointMalformed)",
+    -10: "PLONK_ERR_POINT (PointMalformed)", -11: "PLONK_ERR_NOMEM (host allocation failed inside the library)",
 }
 
 # every symbol include/plonk_hip.h declares (checked by tests/test_capi_symbols.py)

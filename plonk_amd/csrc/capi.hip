@@ -11,12 +11,10 @@
 
 namespace plonk {
 
-static thread_local std::string g_last_error;
+static thread_local char g_last_error[512] = "";   // a fixed buffer: recording an error never allocates (it may be the out-of-memory error)
 
 void set_last_error(const char* what, const char* detail, const char* file, int line) {
-  char buf[512];
-  snprintf(buf, sizeof buf, "%s:%d: %s -> %s", file, line, what, detail);
-  g_last_error = buf;
+  snprintf(g_last_error, sizeof g_last_error, "%s:%d: %s -> %s", file, line, what ? what : "?", detail ? detail : "?");
 }
 
 int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G1Affine* out_dev);
@@ -117,9 +115,11 @@ using namespace plonk;
 
 extern "C" {
 
-const char* plonk_last_error(void) { return g_last_error.c_str(); }
+const char* plonk_last_error(void) { return g_last_error; }
 
 int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!out || ndev > 1 || ndev < 0) return PLONK_ERR_ARG;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
@@ -143,6 +143,7 @@ int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
   }
   *out = ctx;
   return PLONK_OK;
+  });
 }
 
 void plonk_ctx_destroy(plonk_ctx* ctx) {
@@ -178,46 +179,63 @@ void* plonk_ctx_stream(plonk_ctx* ctx) { return ctx ? (void*)ctx->c.main_stream 
 
 // ---- device memory helpers ----------------------------------------------------
 int plonk_dev_alloc(plonk_ctx* ctx, uint64_t bytes, void** out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !out) return PLONK_ERR_ARG;
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
   return PLONK_OK;
+  });
 }
 int plonk_dev_free(plonk_ctx* ctx, void* p) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   HIP_TRY(hipFree(p));
   return PLONK_OK;
+  });
 }
 int plonk_dev_h2d(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.main_stream));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
+  });
 }
 int plonk_dev_d2h(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.main_stream));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
+  });
 }
 int plonk_dev_sync(plonk_ctx* ctx) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
+  });
 }
 
 // ---- NTT ------------------------------------------------------------------------
 int plonk_ntt_dev(plonk_ctx* ctx, const void* src, void* dst, void* tmp, uint32_t log_n, int inverse,
                   int coset, uint64_t in_len) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !src || !dst || log_n >= 28) return PLONK_ERR_ARG;
   if (log_n > 10 && !tmp) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
@@ -226,9 +244,12 @@ int plonk_ntt_dev(plonk_ctx* ctx, const void* src, void* dst, void* tmp, uint32_
   int rc = ntt_device(&ctx->c, (const Fr*)src, (Fr*)dst, (Fr*)tmp, log_n, inverse != 0, coset != 0, in_len);
   prof_end(&ctx->c, 0);
   return rc;
+  });
 }
 
 int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int coset, uint64_t in_len) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !a || log_n >= 28) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -243,6 +264,7 @@ int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int cose
   HIP_TRY(hipMemcpyAsync(a, c.ntt_buf, sizeof(Fr) * n, hipMemcpyDeviceToHost, c.stream));
   HIP_TRY(hipStreamSynchronize(c.stream));
   return PLONK_OK;
+  });
 }
 
 // The 5-way fan-out of compute_coset_evaluations (quotient_poly.rs:139-157) / the 4 wire iFFTs
@@ -252,6 +274,8 @@ int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int cose
 // together: the batch costs ~max(upload, download) per transform instead of their sum.
 int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_n, int inverse, int coset,
                     const uint64_t* in_len) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !a || count < 0 || log_n >= 28) return PLONK_ERR_ARG;
   for (int i = 0; i < count; ++i) if (!a[i]) return PLONK_ERR_ARG;
   if (count == 0) return PLONK_OK;
@@ -295,14 +319,18 @@ int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_
   }
   if (e != hipSuccess) { set_last_error("plonk_ntt_batch", hipGetErrorString(e), __FILE__, __LINE__); if (rc == PLONK_OK) rc = PLONK_ERR_HIP; }
   return rc;
+  });
 }
 
 // ---- SRS / MSM ---------------------------------------------------------------------
 int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!xy96_dev && npoints)) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   return srs_load_device(&ctx->c, (const G1Affine*)xy96_dev, npoints);
+  });
 }
 
 // The commit key is STREAMED from host memory: chunks of 2^18 points (24 MiB) alternate between two device
@@ -312,6 +340,8 @@ int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints) {
 // uploads are truly asynchronous; pageable memory works, the runtime then stages each chunk itself).
 // In a multi-GPU run every rank streams only its own point range of the host copy.
 int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -355,20 +385,29 @@ int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
   if (e != hipSuccess) { set_last_error("plonk_srs_load", hipGetErrorString(e), __FILE__, __LINE__); rc = PLONK_ERR_HIP; }
   if (rc == PLONK_OK) c.srs_n = npoints;
   return rc;
+  });
 }
 
 // pinned host memory for callers without HIP bindings (commit keys to stream, batch transform buffers)
 int plonk_host_alloc(uint64_t bytes, void** out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!out) return PLONK_ERR_ARG;
   HIP_TRY(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
   return PLONK_OK;
+  });
 }
 int plonk_host_free(void* p) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (p) HIP_TRY(hipHostFree(p));
   return PLONK_OK;
+  });
 }
 
 int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -389,10 +428,13 @@ int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
     rc = PLONK_ERR_POINT;
   }
   return rc;
+  });
 }
 
 int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t g_scalar[4], uint64_t npoints,
                            void* out_dev) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !tau || !g_scalar || !out_dev) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
@@ -400,9 +442,12 @@ int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t
   memcpy(&t, tau, 32);
   memcpy(&g, g_scalar, 32);
   return srs_generate_device(&ctx->c, t, g, npoints, (G1Affine*)out_dev);
+  });
 }
 
 int plonk_lagrange_key(plonk_ctx* ctx, uint32_t log_n, uint8_t* out_xy96) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !out_xy96 || log_n >= 27) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -415,9 +460,12 @@ int plonk_lagrange_key(plonk_ctx* ctx, uint32_t log_n, uint8_t* out_xy96) {
   if (hipStreamSynchronize(c.stream) != hipSuccess && rc == PLONK_OK) rc = PLONK_ERR_HIP;
   (void)hipFree(pts);
   return rc;
+  });
 }
 
 int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_dev) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!scalars && m) || !out97_dev) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
@@ -426,9 +474,12 @@ int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_d
   rc = msm_device(&ctx->c, (const Fr*)scalars, m, (G1*)ctx->c.msm.result);
   if (rc) return rc;
   return xyzz_to_affine97_device(&ctx->c, (const G1*)ctx->c.msm.result, (uint8_t*)out97_dev);
+  });
 }
 
 int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_xy_inf[97]) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!scalars && m) || !out_xy_inf) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -450,6 +501,7 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
   HIP_TRY(hipStreamSynchronize(c.stream));
   xyzz_to_affine97_host(finish_bit_sums(reinterpret_cast<const G1*>(c.msm.result_host), c.msm.last_rowbits, c.srs_rows == MSM_ROWS_BITPOS), out_xy_inf);
   return PLONK_OK;
+  });
 }
 
 // Prover::commit_polynomials' 4-way rayon::join fan-out (prover.rs:187-210) as ONE call: up to
@@ -457,6 +509,8 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
 // launch of every kernel, one latency-bound reduction tail), the 16 bit sums per commitment come back
 // in one copy and the host finishes them with one shared Fp inversion.
 int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64_t* m, int count, uint8_t* out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !scalars || !m || !out || count < 0) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -493,16 +547,22 @@ int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64
     batch_xyzz_to_affine97(sums, cnt, reinterpret_cast<uint8_t (*)[97]>(out + 97 * (size_t)k0));
   }
   return PLONK_OK;
+  });
 }
 
 // ---- measurement -------------------------------------------------------------------
 int plonk_profile_enable(plonk_ctx* ctx, int on) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   ctx->c.profile = on != 0;
   return PLONK_OK;
+  });
 }
 int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || slot < 0 || slot >= plonk::Ctx::PROF_SLOTS) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   int rc = prof_collect(&ctx->c);
@@ -510,13 +570,17 @@ int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* lau
   if (total_ms) *total_ms = ctx->c.acc_ms[slot];
   if (launches) *launches = ctx->c.acc_n[slot];
   return PLONK_OK;
+  });
 }
 int plonk_profile_reset(plonk_ctx* ctx) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   int rc = prof_collect(&ctx->c);
   for (int i = 0; i < plonk::Ctx::PROF_SLOTS; ++i) { ctx->c.acc_ms[i] = 0; ctx->c.acc_n[i] = 0; }
   return rc;
+  });
 }
 
 }  // extern "C"

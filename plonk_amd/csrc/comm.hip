@@ -211,13 +211,18 @@ using namespace plonk;
 extern "C" {
 
 int plonk_comm_measure_loopback(plonk_ctx* ctx, int on) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   ctx->c.comm_loopback = on != 0;
   return PLONK_OK;
+  });
 }
 
 int plonk_comm_unique_id(uint8_t out[128]) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!out) return PLONK_ERR_ARG;
   RcclApi* api = rccl_api();
   if (!api) return PLONK_ERR_STATE;
@@ -226,9 +231,12 @@ int plonk_comm_unique_id(uint8_t out[128]) {
   RCCL_TRY(api, api->GetUniqueId(&id));
   memcpy(out, &id, 128);
   return PLONK_OK;
+  });
 }
 
 int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int world) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -263,9 +271,12 @@ int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int worl
   c.comm_rank = rank;
   c.comm_world = world;
   return PLONK_OK;
+  });
 }
 
 int plonk_comm_destroy(plonk_ctx* ctx) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -281,10 +292,13 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   c.comm_world = 1;
   c.comm_rank = 0;
   return PLONK_OK;
+  });
 }
 
 // What the communicator itself reports (ncclCommUserRank / ncclCommCount): bench.py prints it as n_ranks_rccl.
 int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -298,10 +312,13 @@ int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world) {
   if (rank) *rank = r;
   if (world) *world = w;
   return PLONK_OK;
+  });
 }
 
 // Both collectives once, with a rank-dependent pattern, checked on every rank.
 int plonk_comm_selftest(plonk_ctx* ctx) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
@@ -338,6 +355,7 @@ int plonk_comm_selftest(plonk_ctx* ctx) {
     for (size_t i = 0; i < per; ++i)
       if (hr[per * src + i] != (uint8_t)(src * 31 + R * 5 + i)) return (set_last_error("plonk_comm_selftest", "all-to-all returned wrong bytes", __FILE__, __LINE__), PLONK_ERR_STATE);
   return PLONK_OK;
+  });
 }
 
 }  // extern "C"

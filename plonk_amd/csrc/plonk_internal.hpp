@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/plonk_hip.h"
+#include "api_guard.hpp"
 #include "curve.cuh"
 #include "msm_recode.cuh"
 

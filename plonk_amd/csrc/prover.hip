@@ -1552,7 +1552,9 @@ struct plonk_prover {
 extern "C" {
 
 int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_prover** out) {
-  if (!ctx || !desc || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !desc || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   if (!ctx->c.srs_table && desc->shard_world <= 1) return PLONK_ERR_NO_SRS;
@@ -1561,10 +1563,13 @@ int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_pro
   if (rc) return rc;
   *out = new plonk_prover{p, ctx};
   return PLONK_OK;
+  });
 }
 
 int plonk_compile(plonk_ctx* ctx, const plonk_circuit_desc* circuit, plonk_prover** out) {
-  if (!ctx || !circuit || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !circuit || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   HIP_TRY(hipSetDevice(ctx->c.device));
   if (!ctx->c.srs_table && circuit->shard_world <= 1) return PLONK_ERR_NO_SRS;
@@ -1588,6 +1593,7 @@ int plonk_compile(plonk_ctx* ctx, const plonk_circuit_desc* circuit, plonk_prove
   if (rc) return rc;
   *out = new plonk_prover{p, ctx};
   return PLONK_OK;
+  });
 }
 
 void plonk_prover_destroy(plonk_prover* pr) {
@@ -1602,43 +1608,55 @@ void plonk_prover_destroy(plonk_prover* pr) {
 }
 
 int plonk_prover_set_version(plonk_prover* pr, int version) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!pr || !pr->p) return PLONK_ERR_ARG;
   if (version != 2 && version != 3) return (plonk::set_last_error("invalid argument", "PlonkVersion: 2 (legacy) or 3; V1 is Error::UnsupportedProvingVersion in the reference too", __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   pr->p->transcript_version = version;
   return PLONK_OK;
+  });
 }
 
 int plonk_prover_vk(plonk_prover* pr, uint8_t out[15 * 48]) {
-  if (!pr || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   memcpy(out, pr->p->vk, 15 * 48);
   return PLONK_OK;
+  });
 }
 
 uint64_t plonk_prover_size(plonk_prover* pr) { return pr ? pr->p->n : 0; }
 
 // Test/diagnostic hook: copy `count` Fr starting at `offset` of an internal device array.
 int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t count, uint64_t* out) {
-  if (!pr || !out) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk::Prover* p = pr->p;
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   const Fr* base[] = {p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tparts, p->agg, p->wit,
                       p->evals8, p->sigma_n, p->scratch, p->evout, p->polys};
   const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->qn, p->sharded ? p->np : p->n8, 3 * p->np, p->np, p->np,
                           (uint64_t)(P_COUNT + 2) * p->qn, 4 * p->n, 2 * p->np, 16, (uint64_t)P_COUNT * p->np};
-  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   HIP_TRY(hipMemcpyAsync(out, base[which] + offset, sizeof(Fr) * count, hipMemcpyDeviceToHost, p->c->stream));
   HIP_TRY(hipStreamSynchronize(p->c->stream));
   return PLONK_OK;
+  });
 }
 
 int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64_t* pi_idx, const uint64_t* pi_val,
                            uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
-  if (!pr || !wires_dev || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !wires_dev || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   return prover_prove(pr->p, (const Fr*)wires_dev, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+  });
 }
 
 // ---- Prover::to_bytes / Verifier::to_bytes ------------------------------------------------------------------------
@@ -1670,13 +1688,15 @@ void put_vk(uint8_t* p, const Prover* pv) {   // VerifierKey::to_bytes: u64 n, 1
 }  // namespace
 
 int plonk_prover_to_bytes(plonk_prover* pr, uint8_t* out, uint64_t cap, uint64_t* len) {
-  if (!pr || !len) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !len) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   Ctx* c = p->c;
-  if (p->world > 1) return (plonk::set_last_error("a sharded prover holds one slice of the commit key; serialise where the whole key is", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
-  if (p->srs_gen != c->srs_gen) return (plonk::set_last_error("prover is bound to an SRS that was replaced on its context", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (p->world > 1) return (plonk::set_last_error("a sharded prover holds one slice of the commit key; serialise where the whole key is", api_fn, __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (p->srs_gen != c->srs_gen) return (plonk::set_last_error("prover is bound to an SRS that was replaced on its context", api_fn, __FILE__, __LINE__), PLONK_ERR_STATE);
   const uint64_t n = p->n, n8 = 8 * n, np = p->np;
   const uint32_t L = p->logn;
   const uint64_t eval_size = SER_DOMAIN + 32 * n8;
@@ -1764,11 +1784,14 @@ int plonk_prover_to_bytes(plonk_prover* pr, uint8_t* out, uint64_t cap, uint64_t
   w += SER_VK;
   if ((uint64_t)(w - out) != total) return (plonk::set_last_error("plonk_prover_to_bytes", "length accounting", __FILE__, __LINE__), PLONK_ERR_STATE);
   return PLONK_OK;
+  });
 }
 
 int plonk_verifier_to_bytes(plonk_prover* pr, const uint8_t* opening_key, uint64_t opening_key_len, const uint64_t* pi_idx,
                             uint64_t pi_count, uint8_t* out, uint64_t cap, uint64_t* len) {
-  if (!pr || !len || (opening_key_len && !opening_key) || (pi_count && !pi_idx)) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !len || (opening_key_len && !opening_key) || (pi_count && !pi_idx)) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk::Prover* p = pr->p;
   const uint64_t total = 48 + p->label.size() + SER_VK + opening_key_len + 8 * pi_count;
   *len = total;
@@ -1786,31 +1809,37 @@ int plonk_verifier_to_bytes(plonk_prover* pr, const uint8_t* opening_key, uint64
   w += opening_key_len;
   for (uint64_t i = 0; i < pi_count; ++i) { put_be64(w, pi_idx[i]); w += 8; }
   return PLONK_OK;
+  });
 }
 
 int plonk_prover_prove_witnesses(plonk_prover* pr, const uint64_t* witnesses, uint64_t count, const uint64_t* pi_idx,
                                  const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
-  if (!pr || !blinders || !proof || (count && !witnesses) || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !blinders || !proof || (count && !witnesses) || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   Ctx* c = p->c;
-  if (!p->wire_idx) return (plonk::set_last_error("prover was not built by plonk_compile: it has no wire -> witness table", __func__, __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (!p->wire_idx) return (plonk::set_last_error("prover was not built by plonk_compile: it has no wire -> witness table", api_fn, __FILE__, __LINE__), PLONK_ERR_STATE);
   if (count != p->witnesses) return (plonk::set_last_error("invalid argument", "witness count differs from the compiled circuit's", __FILE__, __LINE__), PLONK_ERR_ARG);
   // a_scalars .. d_scalars of prove_inner (prover.rs:446-460), gathered in HBM
   if (count) HIP_TRY(hipMemcpyAsync(p->wit_vals, witnesses, sizeof(Fr) * count, hipMemcpyHostToDevice, c->stream));
   PTRY(poly_gather_wires(c, p->wire_idx, p->wit_vals, p->wires, p->constraints, p->n));
   return prover_prove(p, p->wires, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
+  });
 }
 
 int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const uint64_t* pi_idx, const uint64_t* pi_val,
                        uint64_t pi_count, const uint64_t* blinders, uint8_t proof[1008]) {
-  if (!pr || !wires || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !wires || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   Ctx* c = p->c;
-  for (int k = 0; k < 4; ++k) if (!wires[k]) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  for (int k = 0; k < 4; ++k) if (!wires[k]) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   // the four columns travel on the copy stream while round 1 already transforms the ones that have arrived
   if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   HIP_TRY(hipStreamSynchronize(c->stream));   // the previous proof has finished reading p->wires
@@ -1823,6 +1852,7 @@ int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const u
   p->wires_pending = false;
   (void)hipStreamSynchronize(c->copy_stream);
   return rc;
+  });
 }
 
 }  // extern "C"

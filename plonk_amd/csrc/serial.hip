@@ -277,8 +277,8 @@ int public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncat
   info->points_total = npts;
   uint64_t keep = npts;
   if (truncated_degree) {   // PublicParameters::trim -> CommitKey::truncate (srs.rs:188-196, key.rs:336-355)
-    uint64_t d = truncated_degree + ADDED_BLINDING_DEGREE;
-    if (d > npts - 1) FAIL(PLONK_ERR_DEGREE, "TruncatedDegreeTooLarge");
+    uint64_t d;
+    if (__builtin_add_overflow(truncated_degree, ADDED_BLINDING_DEGREE, &d) || d > npts - 1) FAIL(PLONK_ERR_DEGREE, "TruncatedDegreeTooLarge");
     if (d == 1) d = 2;      // (unreachable with the +6, kept for the literal rule)
     keep = d + 1;
   }
@@ -333,19 +333,27 @@ using namespace plonk;
 extern "C" {
 
 int plonk_prover_blob_check(const uint8_t* blob, uint64_t len, plonk_prover_blob_info* info) {
-  if (!blob || !info) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!blob || !info) return (set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   return blob_check(blob, len, info);
+  });
 }
 
 int plonk_public_parameters_check(const uint8_t* bytes, uint64_t len, uint64_t truncated_degree, int mode,
                                   plonk_public_parameters_info* info) {
-  if (!bytes || !info) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!bytes || !info) return (set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   return public_parameters_check(bytes, len, truncated_degree, mode, info);
+  });
 }
 
 int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint64_t len, uint64_t truncated_degree,
                                      int mode, uint8_t opening_key_out[240], uint64_t* points_loaded) {
-  if (!ctx || !bytes) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !bytes) return (set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk_public_parameters_info info;
   int rc = public_parameters_check(bytes, len, truncated_degree, mode, &info);
   if (rc) return rc;
@@ -406,10 +414,13 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
   if (opening_key_out) memcpy(opening_key_out, bytes + info.opening_key_off, OPENING_KEY_BYTES);
   if (points_loaded) *points_loaded = info.points_kept;
   return PLONK_OK;
+  });
 }
 
 int plonk_prover_from_bytes(plonk_ctx* ctx, const uint8_t* blob, uint64_t len, plonk_prover** out) {
-  if (!ctx || !blob || !out) return (set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !blob || !out) return (set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk_prover_blob_info info;
   int rc = blob_check(blob, len, &info);
   if (rc) return rc;
@@ -443,6 +454,7 @@ int plonk_prover_from_bytes(plonk_ctx* ctx, const uint8_t* blob, uint64_t len, p
   for (int k = 0; k < 15; ++k) memcpy(vk + 48 * k, blob + info.vk_off + 48 * BLOB_POS[k], 48);
   desc.vk_commitments = vk;
   return plonk_prover_create(ctx, &desc, out);
+  });
 }
 
 }  // extern "C"

@@ -289,3 +289,24 @@ extern "C" void h_fr_inv_gcd_mont(const uint32_t* a, uint32_t* o) {
   const Fr r = fr_inv_gcd(x);
   memcpy(o, &r, 32);
 }
+
+// ---- api_guard.hpp: the exception barrier every int-returning C-ABI entry point runs inside ----
+#include <cstdio>
+#include <stdexcept>
+#include "../../plonk_amd/csrc/api_guard.hpp"
+static char g_guard_msg[256];
+namespace plonk {
+void set_last_error(const char* what, const char* detail, const char*, int) { snprintf(g_guard_msg, sizeof g_guard_msg, "%s -> %s", what, detail); }
+}
+// kind 0: the body's own return value; 1: std::bad_alloc; 2: std::runtime_error; 3: a non-std exception
+extern "C" int h_api_guard(int kind, char msg_out[256]) {
+  g_guard_msg[0] = 0;
+  const int rc = plonk::api_guard("h_api_guard", [&]() -> int {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) throw std::runtime_error("boom");
+    if (kind == 3) throw 42;
+    return 7;
+  });
+  memcpy(msg_out, g_guard_msg, 256);
+  return rc;
+}

@@ -20,7 +20,7 @@ def build_host_lib():
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
     hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
             for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp", "g1codec.cuh",
-                      "msm_recode.cuh", "fp_safegcd.cuh", "hostg2.hpp")]
+                      "msm_recode.cuh", "fp_safegcd.cuh", "hostg2.hpp", "api_guard.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
     return ctypes.CDLL(SO)
@@ -457,3 +457,35 @@ def test_host_fr_inverse_safegcd_montgomery_form(lib):
     for v in [0, 1, 2, Q - 1, Q - 2, (Q - 1) // 2, 1 << 254] + [r.randrange(Q) for _ in range(300)]:
         lib.h_fr_inv_gcd_mont(fr_limbs(v), out)
         assert fr_val(out) == (pow(v, -1, Q) if v else 0), v
+
+
+def test_abi_exception_barrier_turns_exceptions_into_codes(lib):
+    """plonk_amd/csrc/api_guard.hpp: every int-returning entry point of the C-ABI runs inside api_guard — a C++ exception
+    never unwinds into the C / Rust caller (include/plonk_hip.h: PLONK_ERR_NOMEM for std::bad_alloc, else PLONK_ERR_STATE)."""
+    msg = ctypes.create_string_buffer(256)
+    assert lib.h_api_guard(0, msg) == 7 and msg.value == b""
+    assert lib.h_api_guard(1, msg) == -11 and b"bad_alloc" in msg.value and msg.value.startswith(b"h_api_guard")
+    assert lib.h_api_guard(2, msg) == -7 and b"boom" in msg.value
+    assert lib.h_api_guard(3, msg) == -7 and b"unknown" in msg.value
+
+
+def test_every_int_entry_point_runs_inside_the_exception_barrier():
+    """Source check: each `int plonk_*` definition of the library opens with the api_guard lambda (the one-line
+    plonk_ctx_table_rows cannot throw)."""
+    import re
+    root = os.path.join(HERE, "..", "plonk_amd", "csrc")
+    seen = 0
+    for f in ("capi.hip", "prover.hip", "serial.hip", "comm.hip"):
+        lines = open(os.path.join(root, f)).read().split("\n")
+        for i, line in enumerate(lines):
+            m = re.match(r"^int (plonk_\w+)\(", line)
+            if not m or m.group(1) == "plonk_ctx_table_rows":
+                continue
+            j = i
+            while not lines[j].rstrip().endswith(("{", ";")):
+                j += 1
+            if lines[j].rstrip().endswith(";"):
+                continue                                   # a declaration
+            assert "api_guard(api_fn" in lines[j + 2], (f, m.group(1))
+            seen += 1
+    assert seen >= 42
