@@ -44,6 +44,18 @@ static ProfState* prof_state(Ctx* c) {
   if (it != g_prof.end()) return it->second;
   return g_prof[c] = new ProfState();
 }
+static void prof_release(Ctx* c) {   // plonk_ctx_destroy: the context's event pool goes with it (and a later context at the same address starts clean)
+  ProfState* ps = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto it = g_prof.find(c);
+    if (it == g_prof.end()) return;
+    ps = it->second;
+    g_prof.erase(it);
+  }
+  for (hipEvent_t e : ps->pool) (void)hipEventDestroy(e);
+  delete ps;
+}
 static hipEvent_t prof_event(ProfState* ps) {
   if (ps->used == ps->pool.size()) {
     hipEvent_t e;
@@ -167,8 +179,10 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   MsmWork& w = c.msm;
   (void)hipFree(w.tmp_words); (void)hipFree(w.entries); (void)hipFree(w.coarse_cnt); (void)hipFree(w.coarse_off); (void)hipFree(w.coarse_cur); (void)hipFree(w.big_off); (void)hipFree(w.big_cnt); (void)hipFree(w.nheavy); (void)hipFree(w.heavy_list); (void)hipFree(w.seg_sum);
   (void)hipFree(w.offsets); (void)hipFree(w.slice_off); (void)hipFree(w.full_off); (void)hipFree(w.part_list); (void)hipFree(w.partial); (void)hipFree(w.buckets);
+  (void)hipFree(w.multi_list); (void)hipFree(w.layout);
   (void)hipFree(w.chunk); (void)hipFree(w.result); (void)hipFree(w.scalars_stage);
   if (w.result_host) (void)hipHostFree(w.result_host);
+  prof_release(&c);
   (void)hipStreamDestroy(c.main_stream);
   if (c.side_stream) (void)hipStreamDestroy(c.side_stream);
   delete ctx;

@@ -258,6 +258,9 @@ int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int worl
       return PLONK_ERR_HIP;
     }
   }
+  (void)hipFree(c.comm_send);   // left over when comm_sync aborted the previous communicator
+  (void)hipFree(c.comm_recv);
+  c.comm_send = c.comm_recv = nullptr;
   hipError_t e = hipMalloc((void**)&c.comm_send, COMM_STAGE);
   if (e == hipSuccess) e = hipMalloc((void**)&c.comm_recv, COMM_STAGE * (size_t)world);
   if (e != hipSuccess) {
@@ -280,11 +283,13 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   if (!ctx) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
-  if (!c.nccl_comm) return PLONK_OK;
+  if (!c.nccl_comm && !c.comm_send && !c.comm_recv) return PLONK_OK;
   (void)hipSetDevice(c.device);
   (void)hipStreamSynchronize(c.main_stream);
-  RcclApi* api = rccl_api();
-  if (api) (void)api->CommDestroy((ncclComm_t)c.nccl_comm);
+  if (c.nccl_comm) {   // (already gone after a time-out abort in comm_sync: only the staging buffers are left to free)
+    RcclApi* api = rccl_api();
+    if (api) (void)api->CommDestroy((ncclComm_t)c.nccl_comm);
+  }
   c.nccl_comm = nullptr;
   (void)hipFree(c.comm_send);
   (void)hipFree(c.comm_recv);
