@@ -1561,7 +1561,9 @@ int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_pro
   plonk::Prover* p = nullptr;
   int rc = prover_build(&ctx->c, desc, nullptr, &p);
   if (rc) return rc;
-  *out = new plonk_prover{p, ctx};
+  plonk_prover* h = new (std::nothrow) plonk_prover{p, ctx};
+  if (!h) { prover_free(p); return (plonk::set_last_error(api_fn, "out of host memory", __FILE__, __LINE__), PLONK_ERR_NOMEM); }
+  *out = h;
   return PLONK_OK;
   });
 }
@@ -1591,7 +1593,9 @@ int plonk_compile(plonk_ctx* ctx, const plonk_circuit_desc* circuit, plonk_prove
   plonk::Prover* p = nullptr;
   int rc = prover_build(&ctx->c, &d, &src, &p);
   if (rc) return rc;
-  *out = new plonk_prover{p, ctx};
+  plonk_prover* h = new (std::nothrow) plonk_prover{p, ctx};
+  if (!h) { prover_free(p); return (plonk::set_last_error(api_fn, "out of host memory", __FILE__, __LINE__), PLONK_ERR_NOMEM); }
+  *out = h;
   return PLONK_OK;
   });
 }
@@ -1640,7 +1644,7 @@ int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t cou
                       p->evals8, p->sigma_n, p->scratch, p->evout, p->polys};
   const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->qn, p->sharded ? p->np : p->n8, 3 * p->np, p->np, p->np,
                           (uint64_t)(P_COUNT + 2) * p->qn, 4 * p->n, 2 * p->np, 16, (uint64_t)P_COUNT * p->np};
-  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset + count > cap[which]) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (which < 0 || which >= (int)(sizeof(base) / sizeof(base[0])) || offset > cap[which] || count > cap[which] - offset) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   HIP_TRY(hipMemcpyAsync(out, base[which] + offset, sizeof(Fr) * count, hipMemcpyDeviceToHost, p->c->stream));
   HIP_TRY(hipStreamSynchronize(p->c->stream));
