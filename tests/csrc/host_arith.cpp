@@ -310,3 +310,38 @@ extern "C" int h_api_guard(int kind, char msg_out[256]) {
   memcpy(msg_out, g_guard_msg, 256);
   return rc;
 }
+
+// ---- tools/ubench/coop_mul.hpp: the 16-lane cooperative Montgomery product, lanes emulated with arrays ----
+#include "../../tools/ubench/coop_mul.hpp"
+namespace {
+struct HostLanes {   // a value per lane of one 16-lane DPP row; shifts fill with zero like row_shr / row_shl with bound_ctrl
+  struct u32 { uint32_t v[16]; };
+  struct u64 { uint64_t v[16]; };
+  static u64 zero64() { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = 0; return r; }
+  static u64 mad(const u64& acc, uint32_t uni, const u32& lane) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = acc.v[k] + (uint64_t)uni * lane.v[k]; return r; }
+  template <int S> static u32 shr32(const u32& x) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = k - S >= 0 ? x.v[k - S] : 0; return r; }
+  template <int S> static u32 shl32(const u32& x) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = k + S <= 15 ? x.v[k + S] : 0; return r; }
+  template <int S> static u64 shr64(const u64& x) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = k - S >= 0 ? x.v[k - S] : 0; return r; }
+  template <int S> static u64 shl64(const u64& x) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = k + S <= 15 ? x.v[k + S] : 0; return r; }
+  static u32 lane_lt(int n) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = k < n ? 0xffffffffu : 0u; return r; }
+  static u32 lane_eq(int n) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = k == n ? 0xffffffffu : 0u; return r; }
+  static u64 select64(const u32& m, const u64& a, const u64& b) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = m.v[k] ? a.v[k] : b.v[k]; return r; }
+  static u32 and32(const u32& a, uint32_t c) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k] & c; return r; }
+  static u32 and32(const u32& a, const u32& b) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k] & b.v[k]; return r; }
+  static u32 add32(const u32& a, const u32& b) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k] + b.v[k]; return r; }
+  static u64 add64(const u64& a, const u64& b) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k] + b.v[k]; return r; }
+  static u32 lo32(const u64& a) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = (uint32_t)a.v[k]; return r; }
+  static u64 widen(const u32& a) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k]; return r; }
+  static u64 shr64_bits(const u64& a, int s) { u64 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k] >> s; return r; }
+  static u32 nonzero32(const u32& a) { u32 r; for (int k = 0; k < 16; ++k) r.v[k] = a.v[k] ? 0xffffffffu : 0u; return r; }
+};
+}  // namespace
+// a: 14 uniform limbs, b: 14 limbs (lane j holds limb j) -> the 16 lanes of the result (lanes 14, 15 must come out zero)
+extern "C" void h_coop_mul(const uint32_t a[14], const uint32_t b[14], uint32_t out[16]) {
+  HostLanes::u32 bd;
+  for (int k = 0; k < 16; ++k) bd.v[k] = k < 14 ? b[k] : 0;
+  coop::Uniform au;
+  for (int k = 0; k < 14; ++k) au.l[k] = a[k];
+  const HostLanes::u32 r = coop::Mul<HostLanes>::mul(au, bd);
+  for (int k = 0; k < 16; ++k) out[k] = r.v[k];
+}

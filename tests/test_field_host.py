@@ -489,3 +489,46 @@ def test_every_int_entry_point_runs_inside_the_exception_barrier():
             assert "api_guard(api_fn" in lines[j + 2], (f, m.group(1))
             seen += 1
     assert seen >= 42
+
+
+def test_cooperative_16_lane_product_model(lib):
+    """tools/ubench/coop_mul.hpp (measurement prototype): the 16-lane cooperative Montgomery product
+    with its lanes emulated by arrays — columns from shifted operands, redundant quotient, the two-pass carry into column 14
+    and the lane-13 flag — equals a b / 2^392 modulo p for normalised, lazy and extreme operands, with limbs under 2^30."""
+    r = random.Random(1628)
+    RP = 1 << 392
+    rinv = pow(RP, -1, P)
+
+    def limbs(x, lazy=0):
+        ls = [(x >> (28 * i)) & 0xFFFFFFF for i in range(14)]
+        for i in range(lazy):                        # the same value with some limbs pushed above 2^28 (borrowing from the next)
+            j = r.randrange(13)
+            if ls[j + 1] > 0 and ls[j] + (1 << 28) < (1 << 30):
+                ls[j + 1] -= 1
+                ls[j] += 1 << 28
+        return ls
+
+    def value(ls):
+        return sum(int(v) << (28 * i) for i, v in enumerate(ls))
+
+    cases = [(0, 0), (1, 1), (P - 1, P - 1), (RP % P, RP % P), (0, P - 1), ((1 << 384) - 1, (1 << 384) - 1)]
+    cases += [(r.randrange(P), r.randrange(P)) for _ in range(200)]
+    cases += [(r.randrange(8 * P), r.randrange(8 * P)) for _ in range(100)]       # lazy VALUES (a few p), as the point formulas keep them
+    for n, (a, b) in enumerate(cases):
+        la, lb = limbs(a, lazy=n % 5), limbs(b, lazy=(n // 5) % 7)
+        assert value(la) == a and value(lb) == b
+        out = (ctypes.c_uint32 * 16)()
+        lib.h_coop_mul((ctypes.c_uint32 * 14)(*la), (ctypes.c_uint32 * 14)(*lb), out)
+        got = list(out)
+        assert got[14] == 0 and got[15] == 0 and all(v < (1 << 30) for v in got)
+        assert value(got[:14]) % P == a * b * rinv % P, (n, a, b)
+        assert value(got[:14]) < a * b // RP + 5 * P
+    # the largest operands of the contract (values under 2^388, every limb but the top at the lazy maximum 2^30 - 1): the
+    # column accumulators must not wrap and nothing may leave limb 13
+    top = [(1 << 30) - 1] * 13 + [(1 << 22) - 1]
+    assert value(top) < 1 << 388
+    out = (ctypes.c_uint32 * 16)()
+    lib.h_coop_mul((ctypes.c_uint32 * 14)(*top), (ctypes.c_uint32 * 14)(*top), out)
+    got = list(out)
+    assert got[14] == 0 and got[15] == 0 and all(v < (1 << 30) for v in got)
+    assert value(got[:14]) % P == value(top) * value(top) * rinv % P
