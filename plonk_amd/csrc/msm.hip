@@ -1422,8 +1422,11 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   if (bit_sums && tail_quad) {
     // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
     FINE_BEGIN(4);
-    if (count >= 3) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
-    else if (count == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    static const int rcwv_env = [] { const char* e = getenv("PLONK_MSM_RCWV"); return e ? atoi(e) : 0; }();   // A/B runs: waves per sum for groups of 1 / 2 / >= 3 commitments as a 3-digit number, e.g. 421
+    int wv = count >= 3 ? 1 : (count == 2 ? 2 : 4);
+    if (rcwv_env >= 111) wv = count >= 3 ? rcwv_env % 10 : (count == 2 ? (rcwv_env / 10) % 10 : rcwv_env / 100);
+    if (wv == 1) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    else if (wv == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     else hipLaunchKernelGGL(msm_rowcol_quad_kernel<4>, dim3(RCQ_SUMS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     FINE_END(4);
     FINE_BEGIN(5);
