@@ -60,6 +60,8 @@ enum {
 /* `devices`: HIP device ordinals; ndev must be 1 (one process per GPU — multi-GPU runs
  * use one context per rank).  devices == NULL -> device 0. */
 int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev);
+/* Frees every device buffer, stream and event the context owns.  Provers built on the context hold a pointer to it:
+ * destroy them FIRST (plonk_prover_destroy locks and synchronises the context it was created on). */
 void plonk_ctx_destroy(plonk_ctx* ctx);
 const char* plonk_last_error(void);
 
