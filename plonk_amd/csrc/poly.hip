@@ -12,6 +12,8 @@
 //                          src/proof_system/linearization_poly.rs:168-264, key.rs:394-414
 //   ruffini_*              Polynomial::ruffini, src/fft/polynomial.rs:345-367
 // All arithmetic is exact Fr; results are the same field elements as the reference's.
+#include <cstdlib>
+
 #include "plonk_internal.hpp"
 #include "fr29.cuh"
 #include "fp_safegcd.cuh"
@@ -169,23 +171,27 @@ __device__ __forceinline__ Fr29 pow_tw(const Fr29& xt, uint64_t e, const Fr29& o
 // everything after).  ~7 reduced-radix products per element + 380 per workgroup, against
 // 27 32-bit-limb products per element for one inversion per 16 elements.
 // ---------------------------------------------------------------------------
-static constexpr int BI_T = 256, BI_E = 16;
+// The geometry is a template parameter (round 4): T lanes x E elements per workgroup.  256 x 16 (one workgroup per CU at 2^20
+// elements) is the round 1-3 kernel; smaller workgroups give small arrays more of the chip and a shorter critical path (the
+// inversion of ONE lane is on it either way) — poly_batch_inverse picks by size.
 struct BatchInvArgs {
   Tw one_t;      // 1 * R''
   Tw one_r;      // R (plain): twiddle form -> data form
   Tw conv;       // R''^2 / R: data form -> twiddle form (Fr29::twiddle_from_fr's constant)
 };
+template <int BI_T>
 __device__ __forceinline__ void lds_put(uint32_t (*sh)[BI_T], int t, const Fr29& v) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) sh[i][t] = v.l[i];
 }
+template <int BI_T>
 __device__ __forceinline__ Fr29 lds_get(uint32_t (*sh)[BI_T], int t) {
   Fr29 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = sh[i][t];
   return r;
 }
-template <bool TW_IO>   // true: the array holds twiddle-form values (raw integers x * 2^261 mod q), in and out
+template <bool TW_IO, int BI_T, int BI_E>   // TW_IO: the array holds twiddle-form values (raw integers x * 2^261 mod q), in and out
 __global__ void __launch_bounds__(BI_T) batch_inverse_kernel(Fr* __restrict__ v, uint64_t n, BatchInvArgs a) {
   __shared__ uint32_t shp[9][BI_T], shs[9][BI_T], shinv[9];
   const int t = threadIdx.x;
@@ -1002,8 +1008,23 @@ int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n, bool twiddle_form) {
     r.conv = tw_of(Fr::from_u64(32));
     return r;
   }();
-  if (twiddle_form) hipLaunchKernelGGL(batch_inverse_kernel<true>, grid1(n, BI_T * BI_E), dim3(BI_T), 0, c->stream, v, n, a);
-  else hipLaunchKernelGGL(batch_inverse_kernel<false>, grid1(n, BI_T * BI_E), dim3(BI_T), 0, c->stream, v, n, a);
+  // geometry: lanes x elements per workgroup.  Up to 2^17 elements (every proof below 2^18 gates, and a rank's range of a
+  // sharded grand product) one wave x 4 elements: the array spreads over 4x as many CUs and the scans need no workgroup
+  // barrier (2^16 gates: -27 us on the critical path of round 2, 2^12: -25 us); above, 256 x 16 does 16x fewer inversions
+  // (2^20: 32.81 against 33.06 ms).  Same results either way; PLONK_BI_CFG=0..3 forces one geometry (A/B runs,
+  // profiles/r04/SUMMARY.md section 8).
+  static const int cfg_env = [] { const char* e = getenv("PLONK_BI_CFG"); return e ? atoi(e) : -1; }();
+  const int cfg = cfg_env >= 0 && cfg_env <= 3 ? cfg_env : (n <= (1ull << 17) ? 1 : 0);
+#define BI_LAUNCH(T, E)                                                                                                              \
+  do {                                                                                                                               \
+    if (twiddle_form) hipLaunchKernelGGL((batch_inverse_kernel<true, T, E>), grid1(n, T * E), dim3(T), 0, c->stream, v, n, a);         \
+    else hipLaunchKernelGGL((batch_inverse_kernel<false, T, E>), grid1(n, T * E), dim3(T), 0, c->stream, v, n, a);                     \
+  } while (0)
+  if (cfg == 1) BI_LAUNCH(64, 4);
+  else if (cfg == 2) BI_LAUNCH(64, 16);
+  else if (cfg == 3) BI_LAUNCH(128, 8);
+  else BI_LAUNCH(256, 16);
+#undef BI_LAUNCH
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
