@@ -2,9 +2,6 @@
 // reference interfaces each entry point replaces).
 #include <cstdio>
 #include <cstring>
-#include <condition_variable>
-#include <string>
-#include <thread>
 
 #include "plonk_internal.hpp"
 #include "hostg1.hpp"
