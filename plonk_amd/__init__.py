@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import Iterable, Sequence
 
 # dmabuf IPC: RCCL between processes needs it on this platform's driver, and it must be in the environment before the
@@ -325,9 +326,12 @@ class Context:
             raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
         self.handle = h
         self.srs_points = 0
+        self._provers = weakref.WeakSet()   # provers hold a pointer to the native context: close() destroys them first (plonk_hip.h)
 
     def close(self):
         if getattr(self, "handle", None):
+            for p in list(getattr(self, "_provers", ())):
+                p.close()
             self.lib.plonk_ctx_destroy(self.handle)
             self.handle = None
 
@@ -539,6 +543,7 @@ class Prover:
         h = ctypes.c_void_p()
         ctx._check(ctx.lib.plonk_prover_create(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
         self.handle = h
+        ctx._provers.add(self)
         self.size = ctx.lib.plonk_prover_size(h)
         self._keep = None
 
@@ -552,6 +557,7 @@ class Prover:
         h = ctypes.c_void_p()
         ctx._check(ctx.lib.plonk_prover_from_bytes(ctx.handle, blob, len(blob), ctypes.byref(h)))
         self.handle = h
+        ctx._provers.add(self)
         self.size = ctx.lib.plonk_prover_size(h)
         return self
 
@@ -610,6 +616,7 @@ class Prover:
         h = ctypes.c_void_p()
         ctx._check(ctx.lib.plonk_compile(ctx.handle, ctypes.byref(desc), ctypes.byref(h)))
         self.handle = h
+        ctx._provers.add(self)
         self.size = ctx.lib.plonk_prover_size(h)
         self._keep = None
         return self
@@ -704,7 +711,8 @@ class Prover:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.ctx.lib.plonk_prover_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):          # a closed context already destroyed its provers
+                self.ctx.lib.plonk_prover_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
