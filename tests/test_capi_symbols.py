@@ -47,3 +47,33 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "oracle/" not in txt or f.endswith(".py"), f
+
+
+def test_python_binding_destroys_provers_before_their_context():
+    """include/plonk_hip.h: provers hold a pointer to the context they were built on and must be destroyed first.  The ctypes
+    mirror enforces it (no GPU needed: a stub library records the calls)."""
+    import weakref
+
+    import plonk_amd
+    calls = []
+
+    class Lib:
+        def plonk_ctx_destroy(self, h):
+            calls.append(("ctx_destroy", h))
+
+        def plonk_prover_destroy(self, h):
+            calls.append(("prover_destroy", h))
+
+    ctx = plonk_amd.Context.__new__(plonk_amd.Context)
+    ctx.lib, ctx.handle, ctx._provers = Lib(), 111, weakref.WeakSet()
+    provers = []
+    for h in (222, 333):
+        p = plonk_amd.Prover.__new__(plonk_amd.Prover)
+        p.ctx, p.handle = ctx, h
+        ctx._provers.add(p)
+        provers.append(p)
+    provers[1].close()
+    ctx.close()
+    provers[0].close()
+    ctx.close()
+    assert calls == [("prover_destroy", 333), ("prover_destroy", 222), ("ctx_destroy", 111)]
