@@ -71,22 +71,23 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
     srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
     lag_slice = None
-    if world in (2, 4, 8) and n >= 64 and os.environ.get("PLONK_WIRE_COMMIT", "")[:1] != "c" and os.environ.get("PLONK_SHARD_QUOTIENT", "")[:1] != "0":
+    eff = ctx.get_config()
+    if world in (2, 4, 8) and n >= 64 and not eff.wire_commit and eff.shard_quotient >= 0:
         # multi-GPU: the Lagrange-basis key needs the WHOLE commit key once (a group FFT); every rank derives it from the
         # full synthetic key and keeps its slice (a real deployment computes it once and ships the slices)
         full = ctx.alloc(96 * (n + 2))
         ctx.srs_generate_dev(TAU, G_SCALAR, n + 2, full.ptr)
         # this load only feeds the group FFT (row 0 of the tables): the 16 window rows are enough, the 256 bit-position
         # rows of the full key would be 32 GiB per rank of pure setup
-        saved = os.environ.get("PLONK_MSM_TABLE")
-        os.environ["PLONK_MSM_TABLE"] = "window"
+        cfg = ctx.get_config()
+        saved = cfg.table_mode
+        cfg.table_mode = plonk_amd.TABLE_WINDOW
+        ctx.set_config(cfg)
         try:
             ctx.srs_load_dev(full.ptr, n + 2)
         finally:
-            if saved is None:
-                del os.environ["PLONK_MSM_TABLE"]
-            else:
-                os.environ["PLONK_MSM_TABLE"] = saved
+            cfg.table_mode = saved
+            ctx.set_config(cfg)
         full.free()
         key = ctx.lagrange_key(log_n)
         llo, lhi = min(lo, n + 2), min(hi, n + 2)
@@ -302,9 +303,9 @@ def ntt_roofline(ctx, log_n, qd8):
                      "hbm": {"achieved": round(64 * N / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)},
                      "hbm_frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4)}
-    elog = os.environ.get("PLONK_NTT_ELOG", "2")   # ntt.hip: 4 elements per lane by default (1024-element tiles, four waves per SIMD)
+    elog = ctx.get_config().ntt_elements_log2 or 2   # ntt.hip: 4 elements per lane by default (1024-element tiles, four waves per SIMD)
     return {"bound": "valu-int-issue", "kernel": f"ntt_pass_kernel<R, T, ELOG = {elog}> (2-3 passes per transform)",
-            "elements_per_lane": 1 << int(elog) if elog in ("2", "3") else 4, "algorithmic_bytes": "64 N per transform",
+            "elements_per_lane": 1 << elog, "algorithmic_bytes": "64 N per transform",
             "note": "timed standalone with wall clock around 10 back-to-back launches; integer-VALU bound (Fr29 butterflies), "
                     "a k-pass plan moves k x 64 N actual bytes; inside prove() the side-stream transforms issued under a busy "
                     "MSM pipeline use the 8-elements-per-lane kernels (DESIGN.md 4.1)", "transforms": out}
@@ -440,6 +441,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     log_n = args.log_gates
+    gpu_config = plonk_amd.GpuConfig()   # all defaults (include/plonk_hip.h plonk_gpu_config); the line reports the effective values
     if os.environ.get("PLONK_BENCH_SHARE_GPU") == "1":   # several ranks on ONE GPU (functional test on a 1-GPU box)
         local_rank = 0
         # Every rank sizes its tables for a device of its own ("at most half of the free HBM"): W ranks on one device would
@@ -450,8 +452,8 @@ def main():
             per_rank_points = ((1 << log_n) + 7 + world - 1) // world
             bitpos_bytes = world * 2 * 256 * 128 * per_rank_points          # commit key + Lagrange-basis slice, 256 rows of 128 B
             if per_rank_points > (1 << 18) + 64 and bitpos_bytes > 120 << 30:
-                os.environ["PLONK_MSM_TABLE"] = "halfpos" if bitpos_bytes // 2 <= 140 << 30 else "window"
-    ctx = plonk_amd.Context(local_rank)
+                gpu_config.table_mode = plonk_amd.TABLE_HALFPOS if bitpos_bytes // 2 <= 140 << 30 else plonk_amd.TABLE_WINDOW
+    ctx = plonk_amd.Context(local_rank, gpu_config)
     dist = None
     allgather = None
     collective = None
@@ -465,6 +467,11 @@ def main():
         want_rccl = os.environ.get("PLONK_BENCH_BACKEND", "nccl") == "nccl"
         ok = 0
         if want_rccl:
+            # PLONK_BENCH_TRANSPORT_LIBRARY (set by the tests only): another file with the nccl* entry points — the stand-in of
+            # tests/fake_rccl, which lets ranks that SHARE one GPU run the library's device-pointer collectives
+            tl = os.environ.get("PLONK_BENCH_TRANSPORT_LIBRARY")
+            if tl:
+                plonk_amd.Context.comm_set_library(tl)
             # rank 0 creates the ncclUniqueId, gloo broadcasts it, every rank joins with its context
             box = [None]
             if rank == 0:
@@ -488,8 +495,16 @@ def main():
                     ctx.comm_destroy()
                 except Exception:   # noqa: BLE001
                     pass
-        collective = "rccl" if ok else "gloo"
-        n_ranks_rccl = ctx.comm_info()[1] if ok else 0
+        collective = "gloo"
+        if ok:
+            # what the library actually loaded decides the label: only a librccl file may be called "rccl", and only its
+            # communicator's size is reported as n_ranks_rccl — a stand-in can never pass for hardware collectives
+            loaded = os.path.basename(plonk_amd.Context.comm_library())
+            if loaded.startswith("librccl"):
+                collective, n_ranks_rccl = "rccl", ctx.comm_info()[1]
+            else:
+                collective = "stand-in:" + loaded
+                assert ctx.comm_info() == (rank, world)
         if not ok:
             def allgather(send: bytes) -> bytes:   # host-callback transport (tests / fallback)
                 t = torch.frombuffer(bytearray(send), dtype=torch.uint8)
@@ -564,21 +579,21 @@ def main():
                     pmc_src = os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of an earlier run, not this run)"
                 except Exception:   # noqa: BLE001
                     pass
-        qd8 = os.environ.get("PLONK_QUOTIENT_DOMAIN", "")[:1] == "8" or world == 8
+        eff = ctx.get_config()              # the EFFECTIVE configuration (struct + A/B overrides), as the library resolved it
+        qd8 = eff.quotient_domain == 8 or world == 8
         table_rows = ctx.table_rows()
-        # uniform scalars: 16 signed 16-bit windows; NAF digits over bit-position tables: 254.9 / (w + 1) + 1/2 per scalar, minus
-        # the first entry of every slice (an assignment, not an addition) — w = 21 over 2^19 buckets from 2^19 terms on (one slice
-        # of ~24 entries per bucket), w = 17 over 2^15 buckets below
+        # what the library says a commitment group of this size runs as over the commit key (the same function its launcher
+        # follows: plonk_ctx_describe_msm) — kernel variant, bucket count, digit width
+        plan = ctx.describe_msm(m_local, 4)
+        w_bits, nb = plan["digit_width"], 1 << plan["bucket_bits"]
+        # additions per scalar, uniform scalars: 16 signed 16-bit windows; width-w NAF digits over bit-position rows: 254.9 / (w + 1)
+        # + 1/2; even-position digits over half-density rows: 254.9 / (w + 2/3) + 1/2 — minus the first entry of every bucket's
+        # slice where a bucket is one slice (an assignment, not an addition: 2^19 buckets)
         if table_rows == 16:
             digits_per_scalar = 16.0 - 0.5
-        elif table_rows == 128:   # even-position digits (a row for every second bit position), w = 20 over 2^19 buckets above 2^18 terms
-            digits_per_scalar = round(254.86 / (20 + 2 / 3) + 0.5 - (1 << 19) / max(m_local, 1), 2) if m_local > (1 << 18) + 64 else 15.8 - 0.5
-        elif m_local > (1 << 19) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":
-            digits_per_scalar = round(254.86 / 22 + 0.5 - (1 << 19) / max(m_local, 1), 2)
-        elif m_local > (1 << 18) + 64 and os.environ.get("PLONK_MSM_BUCKETS", "") != "15":   # w = 19 over 2^17 buckets
-            digits_per_scalar = round(254.86 / 20 + 0.5 - (1 << 17) / max(m_local, 1), 2)
         else:
-            digits_per_scalar = 14.67 - 0.5
+            per = 254.86 / (w_bits + (1 if table_rows == 256 else 2 / 3)) + 0.5
+            digits_per_scalar = round(per - (nb / max(m_local, 1) if plan["bucket_bits"] > 15 else 0.5), 2)
         npoly = 6 if pi else 5
         out = {
             "metric": "prove() wall-clock (ms) at 2^%d gates" % log_n,
@@ -603,6 +618,7 @@ def main():
                        "srs": "rank's point range streamed from pinned host memory in 2^18-point chunks (upload of chunk k+1 under "
                               "the window-table build of chunk k): %d points in %.2f s" % (min(per, srs_total), build_prover.srs_stream_s),
                        "collective": collective, "n_ranks_rccl": n_ranks_rccl, "setup_s": round(t_setup, 1),
+                       "gpu_config": eff.as_dict(),   # plonk_gpu_config as the library resolved it (defaults + A/B overrides)
                        "prover_built_by": "plonk_compile (gate columns)" if args.from_circuit else "plonk_prover_create (coefficient forms)"},
             # whole-job MSM rate: all 11 x (n + 6) terms of a proof over the time rank 0 spends in its (sharded) MSM kernels
             "msm_mscalar_per_s": round(11 * (n + 6) / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),
@@ -615,9 +631,8 @@ def main():
                 {"bound": "valu-int-issue",
                  # the variant that ran: 2^19 buckets (namespace nbl, lanes in order of length) above 2^18 terms over bit-position /
                  # half-density rows, else 2^15 buckets (ordered lanes where slices are 32 entries long)
-                 "kernel": ("nbl::msm_accumulate_ordered_kernel" if table_rows in (256, 128) and m_local > (1 << 18) + 64 and
-                            os.environ.get("PLONK_MSM_BUCKETS", "") != "15" else
-                            ("nb15::msm_accumulate_ordered_kernel" if 3 * m_local > 16 * 32768 else "nb15::msm_accumulate_kernel"))},
+                 "kernel": plan["accumulate_kernel"], "bucket_bits": plan["bucket_bits"], "digit_width": plan["digit_width"],
+                 "slice_entries": plan["slice_entries"]},
                 **valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove),
                 **{"traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
                    "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},

@@ -65,6 +65,70 @@ int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev);
 void plonk_ctx_destroy(plonk_ctx* ctx);
 const char* plonk_last_error(void);
 
+/* ---- configuration ("a small plonk_gpu_config struct passed at context creation") ----------------
+ * Everything that changes what a context BUILDS or RUNS is a field here; a zeroed struct with struct_size set means "all
+ * defaults", and plonk_ctx_create(out, devices, ndev) == plonk_ctx_create_ex(out, device, NULL).  The environment names of
+ * earlier rounds (PLONK_MSM_TABLE, PLONK_MSM_BUCKETS, PLONK_QUOTIENT_DOMAIN, PLONK_WIRE_COMMIT, PLONK_SHARD_QUOTIENT /
+ * _Z / _SIDE, PLONK_NTT_ELOG, PLONK_COMM_TIMEOUT_MS, PLONK_TABLE_BUDGET_MB, PLONK_SIDE_CUS and the kernel-tuning names
+ * listed in DESIGN.md section 2) remain as OVERRIDES FOR A/B RUNS ONLY: they are read once, when a context is created or
+ * reconfigured, on top of the struct — never latched inside the library at first use.
+ *
+ * table_budget_bytes: HBM that ALL precomputed point tables of this context may take together (its commit key and the
+ *   Lagrange-basis keys of the provers built on it).  0 = 80 % of the device's TOTAL memory.  The layout of a key is the
+ *   densest that fits: the commit key takes a row per bit position (32 KiB per point) when that is at most 60 % of the
+ *   budget, a row per second bit position (16 KiB) when at most 30 %, else the 16 window rows (2 KiB); a prover's
+ *   Lagrange-basis key, built last, takes the densest layout that fits in what is left.  The rule reads the budget and what
+ *   THIS context already holds — not the memory that happens to be free — so two contexts given the same budget choose the
+ *   same layouts whatever their neighbours do (until round 4: "half of what hipMemGetInfo reports free right now").
+ *   Keys of at most 2^18 + 64 points always take window rows (measured faster), table_mode forces a layout.
+ * plonk_ctx_get_config returns the EFFECTIVE values (defaults and overrides resolved); plonk_ctx_set_config replaces
+ *   them for the key loads, provers and MSMs that follow (e.g. a key that is loaded only to derive another one from it:
+ *   table_mode = PLONK_TABLE_WINDOW for that load).  Existing tables and provers keep what they were built with. */
+enum { PLONK_TABLE_AUTO = 0, PLONK_TABLE_WINDOW = 16, PLONK_TABLE_HALFPOS = 128, PLONK_TABLE_BITPOS = 256 };
+typedef struct plonk_gpu_config {
+  uint32_t struct_size;          /* sizeof(plonk_gpu_config) of the caller (shorter = older header: missing fields default) */
+  uint32_t reserved;             /* 0 */
+  uint64_t table_budget_bytes;   /* 0 = 80 % of the device's total memory */
+  int32_t table_mode;            /* PLONK_TABLE_AUTO | _WINDOW | _HALFPOS | _BITPOS */
+  int32_t msm_bucket_bits;       /* 0 = by the number of terms (2^19 buckets above 2^18 terms over bit-position rows), 15, 19 */
+  int32_t quotient_domain;       /* 0 = 4: quotient on the 4n coset + de-aliasing; 8: the reference's 8n evaluation */
+  int32_t wire_commit;           /* 0 = from the wire VALUES over the Lagrange-basis key; 1 = coefficient form like the reference */
+  int32_t shard_quotient;        /* multi-GPU: 0 = default (by residue class for world 2 / 4 / 8), 1 = on, -1 = off (MSMs only) */
+  int32_t shard_grand_product;   /* multi-GPU: 0 = default (from 2^19 gates and 4 ranks), 1 = on, -1 = off (replicated) */
+  int32_t shard_side_stream;     /* multi-GPU: 0 / 1 = replicated transforms on the side stream under the commitments, -1 = off */
+  int32_t ntt_elements_log2;     /* 0 = default (2: four elements per lane; side-stream transforms under a busy MSM: 3), 2, 3 */
+  int32_t comm_timeout_ms;       /* 0 = 120000: how long a wait behind a collective polls before the communicator is aborted */
+  int32_t side_stream_cus;       /* 0 = default; > 0: compute units reserved for the side stream (CU masks on both streams); -1 = none */
+} plonk_gpu_config;
+int plonk_ctx_create_ex(plonk_ctx** out, int device, const plonk_gpu_config* config /* NULL = defaults */);
+int plonk_ctx_get_config(plonk_ctx* ctx, plonk_gpu_config* out /* struct_size set by the caller */);
+int plonk_ctx_set_config(plonk_ctx* ctx, const plonk_gpu_config* config);
+
+/* What an MSM of `count` scalar sets of at most m terms WOULD run as on this context right now — over the commit key
+ * (table_rows = 0) or over a key of table_rows rows / table_points points (a prover's Lagrange-basis key); bit_sum_tail = 1:
+ * as plonk_msm, plonk_msm_batch and every commitment group of prove() run (the host finishes the bit sums: the only tail the
+ * 2^19-bucket kernels have), 0: as plonk_msm_dev (final sum on the device, 2^15 buckets) — and what the LAST one did run as
+ * (plonk_ctx_last_msm).  The variant tests assert these, so a switch that is silently
+ * ignored fails a test. */
+enum { PLONK_PLAN_TAIL_SERIAL = 1, PLONK_PLAN_BUCKET_SUM_LANE = 2, PLONK_PLAN_ACCUMULATE_LDS = 4, PLONK_PLAN_SORT13 = 8, PLONK_PLAN_ROWCOL_AFFINE = 16 };
+typedef struct plonk_msm_plan {
+  uint32_t table_rows;           /* 16 window rows / 128 / 256 bit-position rows of the key */
+  uint32_t bucket_bits;          /* 15 or 19 (17: opt-in A/B build) */
+  uint32_t digit_width;          /* bits of a signed digit: 16 (windows), or bucket_bits + 2 (NAF over bit positions; + 1 for half density) */
+  uint32_t slice_entries;        /* entries a lane accumulates serially */
+  uint32_t ordered_lanes;        /* 1: msm_accumulate_ordered_kernel (lanes in order of slice length) */
+  uint32_t wide_words;           /* 1: 64-bit sort words (rows x points above 2^27) */
+  uint32_t flags;                /* PLONK_PLAN_*: which opt-in kernel variants of the A/B switches are in effect */
+  uint32_t reserved;
+  uint64_t terms;                /* m the plan was made for */
+  char accumulate_kernel[64];    /* e.g. "nbl::msm_accumulate_ordered_kernel" */
+} plonk_msm_plan;
+int plonk_ctx_describe_msm(plonk_ctx* ctx, uint64_t m, int count, int bit_sum_tail, uint32_t table_rows, uint64_t table_points,
+                           plonk_msm_plan* out);
+int plonk_ctx_last_msm(plonk_ctx* ctx, plonk_msm_plan* out);
+/* bytes of precomputed tables the context holds right now (commit key + Lagrange-basis keys) and its budget */
+int plonk_ctx_table_bytes(plonk_ctx* ctx, uint64_t* in_use, uint64_t* budget);
+
 /* In-place transform of a[0 .. 1<<log_n) (host memory).
  *   inverse = 0: forward with w;  1: inverse with w^-1 and the n^-1 scale.
  *   coset   = 1: forward pre-scales coefficient i by 7^i for i < in_len;
@@ -278,7 +342,19 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  * Measurement aid, never for production: after plonk_comm_measure_loopback(ctx, 1) every collective of a sharded prover on
  * THIS context returns the rank's own contribution in its peers' places (local copies, no transport), so that one rank of a
  * W-rank job can be timed alone on one GPU (tools/rank_alone.py).  Proofs made that way are wrong by construction:
- * plonk_prover_prove* returns PLONK_ERR_UNSAT from its final identity check.  Nothing in the environment switches it on. */
+ * plonk_prover_prove* returns PLONK_ERR_UNSAT from its final identity check.  Nothing in the environment switches it on.
+ *
+ * Transport library: RCCL is looked up as librccl.so(.1) on the loader path, then under /opt/rocm/lib.
+ * plonk_comm_set_library(path) names another shared object exporting the nccl* entry points BEFORE the first
+ * communicator call of the process (PLONK_ERR_STATE once a library is loaded): a deployment whose RCCL lives elsewhere, or
+ * the test suite's stand-in (tests/fake_rccl: device-pointer collectives over hipIpc between ranks that SHARE one GPU —
+ * RCCL refuses two ranks per device — so that the W > 1 branch of every exchange runs on a 1-GPU box).
+ * plonk_comm_library writes the path of what was actually loaded (NUL-terminated, truncated to cap); a host program that
+ * reports which collective a measurement used must take it from here (bench.py prints "rccl" only for a librccl file).
+ * After a time-out whose abort did not drain the stream (or a transport without ncclCommAbort) the context is UNUSABLE:
+ * sharded proofs and plonk_comm_init return PLONK_ERR_STATE; destroy it. */
+int plonk_comm_set_library(const char* path);
+int plonk_comm_library(char* out, uint64_t cap);
 int plonk_comm_measure_loopback(plonk_ctx* ctx, int on);
 int plonk_comm_unique_id(uint8_t out[128]);
 int plonk_comm_init(plonk_ctx* ctx, const uint8_t unique_id[128], int rank, int world);

@@ -52,7 +52,9 @@ EXPORTS = [
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_info", "plonk_comm_selftest", "plonk_comm_destroy",
-    "plonk_comm_measure_loopback", "plonk_prover_set_version",
+    "plonk_comm_measure_loopback", "plonk_prover_set_version", "plonk_comm_set_library", "plonk_comm_library",
+    "plonk_ctx_create_ex", "plonk_ctx_get_config", "plonk_ctx_set_config", "plonk_ctx_describe_msm", "plonk_ctx_last_msm",
+    "plonk_ctx_table_bytes",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
     "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
     "plonk_public_parameters_check", "plonk_srs_load_public_parameters",
@@ -60,6 +62,37 @@ EXPORTS = [
 
 POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q_logic",
               "q_fixed_group_add", "q_variable_group_add", "s_sigma_1", "s_sigma_2", "s_sigma_3", "s_sigma_4"]
+
+
+TABLE_AUTO, TABLE_WINDOW, TABLE_HALFPOS, TABLE_BITPOS = 0, 16, 128, 256
+PLAN_TAIL_SERIAL, PLAN_BUCKET_SUM_LANE, PLAN_ACCUMULATE_LDS, PLAN_SORT13, PLAN_ROWCOL_AFFINE = 1, 2, 4, 8, 16
+
+
+class GpuConfig(ctypes.Structure):
+    """plonk_gpu_config (include/plonk_hip.h): zero = default for every field; struct_size is filled in by the binding."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("table_budget_bytes", ctypes.c_uint64),
+                ("table_mode", ctypes.c_int32), ("msm_bucket_bits", ctypes.c_int32), ("quotient_domain", ctypes.c_int32),
+                ("wire_commit", ctypes.c_int32), ("shard_quotient", ctypes.c_int32), ("shard_grand_product", ctypes.c_int32),
+                ("shard_side_stream", ctypes.c_int32), ("ntt_elements_log2", ctypes.c_int32), ("comm_timeout_ms", ctypes.c_int32),
+                ("side_stream_cus", ctypes.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_size = ctypes.sizeof(GpuConfig)
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_ if k not in ("struct_size", "reserved")}
+
+
+class _MsmPlan(ctypes.Structure):
+    _fields_ = [("table_rows", ctypes.c_uint32), ("bucket_bits", ctypes.c_uint32), ("digit_width", ctypes.c_uint32),
+                ("slice_entries", ctypes.c_uint32), ("ordered_lanes", ctypes.c_uint32), ("wide_words", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("terms", ctypes.c_uint64), ("accumulate_kernel", ctypes.c_char * 64)]
+
+    def as_dict(self) -> dict:
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["accumulate_kernel"] = d["accumulate_kernel"].decode()
+        return d
 
 
 class _ProverDesc(ctypes.Structure):
@@ -195,6 +228,14 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.plonk_comm_destroy.argtypes = [vp]
     lib.plonk_comm_measure_loopback.argtypes = [vp, ci]
+    lib.plonk_ctx_create_ex.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(GpuConfig)]
+    lib.plonk_ctx_get_config.argtypes = [vp, ctypes.POINTER(GpuConfig)]
+    lib.plonk_ctx_set_config.argtypes = [vp, ctypes.POINTER(GpuConfig)]
+    lib.plonk_ctx_describe_msm.argtypes = [vp, u64, ci, ci, u32, u64, ctypes.POINTER(_MsmPlan)]
+    lib.plonk_ctx_last_msm.argtypes = [vp, ctypes.POINTER(_MsmPlan)]
+    lib.plonk_ctx_table_bytes.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.plonk_comm_set_library.argtypes = [ctypes.c_char_p]
+    lib.plonk_comm_library.argtypes = [vp, u64]
     lib.plonk_prover_set_version.argtypes = [vp, ci]
     _lib = lib
     return lib
@@ -317,11 +358,14 @@ class PinnedBuffer:
 class Context:
     """One GPU, one stream (plonk_ctx).  One process per GPU in multi-GPU runs."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, config: "GpuConfig | None" = None):
         self.lib = load_library()
         h = ctypes.c_void_p()
-        dev = (ctypes.c_int * 1)(device)
-        rc = self.lib.plonk_ctx_create(ctypes.byref(h), dev, 1)
+        if config is None:
+            dev = (ctypes.c_int * 1)(device)
+            rc = self.lib.plonk_ctx_create(ctypes.byref(h), dev, 1)
+        else:
+            rc = self.lib.plonk_ctx_create_ex(ctypes.byref(h), device, ctypes.byref(config))
         if rc != PLONK_OK:
             raise PlonkError(rc, (self.lib.plonk_last_error() or b"").decode())
         self.handle = h
@@ -444,6 +488,34 @@ class Context:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    # ---- configuration / introspection ----------------------------------------------------
+    def get_config(self) -> "GpuConfig":
+        """the EFFECTIVE configuration (defaults and environment overrides resolved)"""
+        g = GpuConfig()
+        self._check(self.lib.plonk_ctx_get_config(self.handle, ctypes.byref(g)))
+        return g
+
+    def set_config(self, config: "GpuConfig"):
+        self._check(self.lib.plonk_ctx_set_config(self.handle, ctypes.byref(config)))
+
+    def describe_msm(self, m: int, count: int = 1, bit_sum_tail: bool = True, table_rows: int = 0, table_points: int = 0) -> dict:
+        """what an MSM of `count` sets of <= m terms would run as (table_rows = 0: over the context's commit key)"""
+        p = _MsmPlan()
+        self._check(self.lib.plonk_ctx_describe_msm(self.handle, m, count, int(bit_sum_tail), table_rows, table_points, ctypes.byref(p)))
+        return p.as_dict()
+
+    def last_msm(self) -> dict:
+        """what the last MSM group on this context did run as"""
+        p = _MsmPlan()
+        self._check(self.lib.plonk_ctx_last_msm(self.handle, ctypes.byref(p)))
+        return p.as_dict()
+
+    def table_bytes(self) -> tuple[int, int]:
+        """(bytes of point tables the context holds, its budget)"""
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self.lib.plonk_ctx_table_bytes(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
     def table_rows(self) -> int:
         """256: one table row per bit position (width-17 NAF digits), 16: window rows, 0: no key"""
         return int(self.lib.plonk_ctx_table_rows(self.handle))
@@ -482,6 +554,24 @@ class Context:
         if rc != PLONK_OK:
             raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
         return out.raw
+
+    @staticmethod
+    def comm_set_library(path: str):
+        """Name the transport library (default: librccl) before the first communicator call of the process."""
+        lib = load_library()
+        rc = lib.plonk_comm_set_library(os.fsencode(path))
+        if rc != PLONK_OK:
+            raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
+
+    @staticmethod
+    def comm_library() -> str:
+        """Path of the transport library that was actually loaded (dladdr of its ncclAllGather)."""
+        lib = load_library()
+        out = ctypes.create_string_buffer(1024)
+        rc = lib.plonk_comm_library(out, 1024)
+        if rc != PLONK_OK:
+            raise PlonkError(rc, (lib.plonk_last_error() or b"").decode())
+        return out.value.decode()
 
     def comm_init(self, unique_id: bytes, rank: int, world: int):
         assert len(unique_id) == 128

@@ -122,24 +122,135 @@ static int ensure_scalar_staging(Ctx* c, uint64_t m) {
 
 using namespace plonk;
 
+namespace plonk {
+
+// plonk_gpu_config -> Config.  Order: defaults, the caller's struct (fields beyond its struct_size keep their defaults), the
+// environment overrides (A/B runs).  Called at context creation and plonk_ctx_set_config — the ONLY place where the library
+// reads the environment for a behaviour switch.
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e && e[0] ? atoi(e) : dflt; }
+static char env_chr(const char* name) { const char* e = getenv(name); return e ? e[0] : 0; }
+
+void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
+  Config g;
+  plonk_gpu_config u{};
+  if (user) memcpy(&u, user, user->struct_size < sizeof(u) ? user->struct_size : sizeof(u));
+  g.table_budget = u.table_budget_bytes;
+  g.table_mode = u.table_mode;
+  g.bucket_bits = u.msm_bucket_bits;
+  g.quotient_domain = u.quotient_domain == 8 ? 8 : 4;
+  g.wire_commit_coeff = u.wire_commit == 1;
+  g.shard_quotient = u.shard_quotient;
+  g.shard_z = u.shard_grand_product;
+  g.shard_side = u.shard_side_stream;
+  g.ntt_elog = u.ntt_elements_log2;
+  g.comm_timeout_ms = u.comm_timeout_ms > 0 ? u.comm_timeout_ms : 120000;
+  g.side_cus = u.side_stream_cus;
+  // ---- environment overrides
+  switch (env_chr("PLONK_MSM_TABLE")) { case 'w': g.table_mode = MSM_ROWS_WINDOW; break; case 'h': g.table_mode = MSM_ROWS_HALFPOS; break; case 'b': g.table_mode = MSM_ROWS_BITPOS; break; default: break; }
+  if (const int mb = env_int("PLONK_TABLE_BUDGET_MB", 0); mb > 0) g.table_budget = (uint64_t)mb << 20;
+  if (const int b = env_int("PLONK_MSM_BUCKETS", 0); b) g.bucket_bits = b;
+  if (env_chr("PLONK_QUOTIENT_DOMAIN") == '8') g.quotient_domain = 8;
+  if (env_chr("PLONK_QUOTIENT_DOMAIN") == '4') g.quotient_domain = 4;
+  if (env_chr("PLONK_WIRE_COMMIT") == 'c') g.wire_commit_coeff = 1;
+  if (const char v = env_chr("PLONK_SHARD_QUOTIENT")) g.shard_quotient = v == '0' ? -1 : 1;
+  if (const char v = env_chr("PLONK_SHARD_Z")) g.shard_z = v == '1' ? 1 : -1;
+  if (const char v = env_chr("PLONK_SHARD_SIDE")) g.shard_side = v == '0' ? -1 : 1;
+  if (const char v = env_chr("PLONK_NTT_ELOG"); v == '2' || v == '3') g.ntt_elog = v - '0';
+  if (const int t = env_int("PLONK_COMM_TIMEOUT_MS", 0); t > 0) g.comm_timeout_ms = t;
+  if (getenv("PLONK_SIDE_CUS")) g.side_cus = env_int("PLONK_SIDE_CUS", 0);
+  g.ksl = env_int("PLONK_MSM_KSL", 0);
+  g.prof_fine = env_chr("PLONK_PROF_FINE") == '1';
+  g.acc_lds = env_chr("PLONK_MSM_ACC") == 'l';
+  if (const char v = env_chr("PLONK_MSM_ORDER")) g.order = v == '1' ? 1 : 0;
+  g.tail_serial = env_chr("PLONK_MSM_TAIL") == 's';
+  g.bsum_lane = env_chr("PLONK_MSM_BSUM") == 'l';
+  g.rc_lane_tree = env_chr("PLONK_MSM_RCTREE") == 'l';
+  g.lps = env_int("PLONK_MSM_LPS", 0);
+  g.rcwv = env_int("PLONK_MSM_RCWV", 0);
+  if (const char v = env_chr("PLONK_MSM_SORT13")) g.sort13 = v == '1' ? 1 : 0;
+  if (const char v = env_chr("PLONK_MSM_RCAFFINE")) g.rc_affine = v == '1' ? 1 : 0;
+  g.ntt_direct = env_chr("PLONK_NTT_DIRECT") != '0';
+  g.bi_cfg = env_int("PLONK_BI_CFG", -1);
+  if (const char v = env_chr("PLONK_SIDE_DEFER")) g.side_defer = v == '1' ? 1 : (v == '2' ? 2 : 0);
+  // ---- resolution
+  if (g.table_mode != (int)MSM_ROWS_WINDOW && g.table_mode != (int)MSM_ROWS_HALFPOS && g.table_mode != (int)MSM_ROWS_BITPOS) g.table_mode = 0;
+  if (g.ntt_elog != 2 && g.ntt_elog != 3) g.ntt_elog = 0;
+  if (g.side_cus < 0) g.side_cus = 0;
+  if (g.table_budget == 0) {
+    size_t total = 0;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != device) (void)hipSetDevice(device);
+    if (hipDeviceTotalMem(&total, device) != hipSuccess || total == 0) total = 256ull << 30;
+    g.table_budget = (uint64_t)total / 10 * 8;
+  }
+  *out = g;
+}
+
+static int config_check(const plonk_gpu_config* u, const char* api_fn) {
+  if (!u) return PLONK_OK;
+  if (u->struct_size < 8 || u->struct_size > 4096) return (set_last_error("invalid argument", "plonk_gpu_config.struct_size is not set", __FILE__, __LINE__), PLONK_ERR_ARG);
+  plonk_gpu_config c{};
+  memcpy(&c, u, u->struct_size < sizeof(c) ? u->struct_size : sizeof(c));
+  auto bad = [&](const char* what) { set_last_error(api_fn, what, __FILE__, __LINE__); return PLONK_ERR_ARG; };
+  if (c.table_mode != PLONK_TABLE_AUTO && c.table_mode != PLONK_TABLE_WINDOW && c.table_mode != PLONK_TABLE_HALFPOS && c.table_mode != PLONK_TABLE_BITPOS) return bad("plonk_gpu_config.table_mode");
+  if (c.msm_bucket_bits != 0 && c.msm_bucket_bits != 15 && c.msm_bucket_bits != 17 && c.msm_bucket_bits != 19) return bad("plonk_gpu_config.msm_bucket_bits");
+  if (c.quotient_domain != 0 && c.quotient_domain != 4 && c.quotient_domain != 8) return bad("plonk_gpu_config.quotient_domain");
+  if (c.wire_commit != 0 && c.wire_commit != 1) return bad("plonk_gpu_config.wire_commit");
+  if (c.ntt_elements_log2 != 0 && c.ntt_elements_log2 != 2 && c.ntt_elements_log2 != 3) return bad("plonk_gpu_config.ntt_elements_log2");
+  for (int v : {c.shard_quotient, c.shard_grand_product, c.shard_side_stream}) if (v < -1 || v > 1) return bad("plonk_gpu_config.shard_*: -1, 0 or 1");
+  if (c.comm_timeout_ms < 0 || c.side_stream_cus < -1 || c.side_stream_cus > 200) return bad("plonk_gpu_config.comm_timeout_ms / side_stream_cus");
+  return PLONK_OK;
+}
+
+// plonk_gpu_config.side_stream_cus = k > 0: the side stream is re-created on k compute units of its own and the main stream
+// on the others (hipExtStreamCreateWithCUMask), so that side-stream transforms neither take issue slots from the critical
+// path's kernels nor wait behind them (DESIGN.md 7.5 / VERDICT r4 item 4).  k CUs are taken evenly from the XCDs.
+static int side_stream_partition(Ctx* c) {
+  const int k = c->cfg.side_cus;
+  if (k <= 0) return PLONK_OK;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+  const int ncu = prop.multiProcessorCount;
+  if (k >= ncu) return (set_last_error("plonk_gpu_config.side_stream_cus", "must leave compute units for the main stream", __FILE__, __LINE__), PLONK_ERR_ARG);
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> side(words, 0u), main(words, 0u);
+  // CU i of the mask belongs to XCD i % 8 on MI300-class parts (the mask interleaves the XCDs): taking every (ncu / k)-th
+  // bit spreads the side stream's CUs over all XCDs
+  int taken = 0;
+  for (int i = 0; i < ncu; ++i) {
+    const bool s = taken < k && (int64_t)i * k / ncu != (int64_t)(i + 1) * k / ncu;
+    if (s) { side[i / 32] |= 1u << (i % 32); ++taken; } else main[i / 32] |= 1u << (i % 32);
+  }
+  hipStream_t ms = nullptr, ss = nullptr;
+  HIP_TRY(hipExtStreamCreateWithCUMask(&ms, (uint32_t)words, main.data()));
+  if (hipExtStreamCreateWithCUMask(&ss, (uint32_t)words, side.data()) != hipSuccess) { (void)hipStreamDestroy(ms); return (set_last_error("hipExtStreamCreateWithCUMask", "side stream", __FILE__, __LINE__), PLONK_ERR_HIP); }
+  (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->side_stream);
+  c->stream = c->main_stream = ms;
+  c->side_stream = ss;
+  return PLONK_OK;
+}
+
+}  // namespace plonk
+
 extern "C" {
 
 const char* plonk_last_error(void) { return g_last_error; }
 
-int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
-  const char* const api_fn = __func__;
-  return plonk::api_guard(api_fn, [&]() -> int {
-  if (!out || ndev > 1 || ndev < 0) return PLONK_ERR_ARG;
+static int create_context(plonk_ctx** out, int dev, const plonk_gpu_config* config, const char* api_fn) {
+  if (!out) return PLONK_ERR_ARG;
+  { const int rc = config_check(config, api_fn); if (rc) return rc; }
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
     set_last_error("hipGetDeviceCount", "no HIP device visible", __FILE__, __LINE__);
     return PLONK_ERR_NO_GPU;
   }
-  const int dev = (devices && ndev == 1) ? devices[0] : 0;
   if (dev < 0 || dev >= count) return PLONK_ERR_ARG;
   HIP_TRY(hipSetDevice(dev));
   auto* ctx = new plonk_ctx();
   ctx->c.device = dev;
+  config_resolve(config, dev, &ctx->c.cfg);
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   hipError_t e = hipStreamCreateWithPriority(&ctx->c.stream, hipStreamNonBlocking, prio_greatest);
@@ -150,9 +261,102 @@ int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
     delete ctx;
     return PLONK_ERR_HIP;
   }
+  { const int rc = side_stream_partition(&ctx->c); if (rc) { (void)hipStreamDestroy(ctx->c.stream); (void)hipStreamDestroy(ctx->c.side_stream); delete ctx; return rc; } }
   *out = ctx;
   return PLONK_OK;
+}
+
+int plonk_ctx_create(plonk_ctx** out, const int* devices, int ndev) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!out || ndev > 1 || ndev < 0) return PLONK_ERR_ARG;
+  return create_context(out, (devices && ndev == 1) ? devices[0] : 0, nullptr, api_fn);
   });
+}
+
+int plonk_ctx_create_ex(plonk_ctx** out, int device, const plonk_gpu_config* config) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int { return create_context(out, device, config, api_fn); });
+}
+
+int plonk_ctx_get_config(plonk_ctx* ctx, plonk_gpu_config* out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !out || out->struct_size < 8 || out->struct_size > 4096) return (set_last_error("invalid argument", "plonk_ctx_get_config: set struct_size = sizeof(plonk_gpu_config)", __FILE__, __LINE__), PLONK_ERR_ARG);
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  const Config& g = ctx->c.cfg;
+  plonk_gpu_config full{};
+  full.struct_size = (uint32_t)sizeof(plonk_gpu_config);
+  full.table_budget_bytes = g.table_budget;
+  full.table_mode = g.table_mode;
+  full.msm_bucket_bits = g.bucket_bits;
+  full.quotient_domain = g.quotient_domain;
+  full.wire_commit = g.wire_commit_coeff;
+  full.shard_quotient = g.shard_quotient;
+  full.shard_grand_product = g.shard_z;
+  full.shard_side_stream = g.shard_side;
+  full.ntt_elements_log2 = g.ntt_elog;
+  full.comm_timeout_ms = g.comm_timeout_ms;
+  full.side_stream_cus = g.side_cus;
+  const uint32_t want = out->struct_size < sizeof(full) ? out->struct_size : (uint32_t)sizeof(full);
+  memcpy(out, &full, want);
+  out->struct_size = want;
+  return PLONK_OK;
+  });
+}
+
+int plonk_ctx_set_config(plonk_ctx* ctx, const plonk_gpu_config* config) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx) return PLONK_ERR_ARG;
+  { const int rc = config_check(config, api_fn); if (rc) return rc; }
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  const int cus_before = ctx->c.cfg.side_cus;
+  config_resolve(config, ctx->c.device, &ctx->c.cfg);
+  if (ctx->c.cfg.side_cus != cus_before) {   // streams are created once: the partition of the CUs is fixed at creation
+    ctx->c.cfg.side_cus = cus_before;
+    return (set_last_error("plonk_ctx_set_config", "side_stream_cus can only be chosen at plonk_ctx_create_ex", __FILE__, __LINE__), PLONK_ERR_STATE);
+  }
+  return PLONK_OK;
+  });
+}
+
+int plonk_ctx_table_bytes(plonk_ctx* ctx, uint64_t* in_use, uint64_t* budget) {
+  if (!ctx) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  if (in_use) *in_use = ctx->c.table_bytes;
+  if (budget) *budget = ctx->c.cfg.table_budget;
+  return PLONK_OK;
+}
+
+static void plan_out(const plonk_msm_plan_internal& p, plonk_msm_plan* out) {
+  memset(out, 0, sizeof(*out));
+  out->table_rows = p.table_rows; out->bucket_bits = p.bucket_bits; out->digit_width = p.digit_width;
+  out->slice_entries = p.slice_entries; out->ordered_lanes = p.ordered_lanes; out->wide_words = p.wide_words; out->flags = p.flags; out->terms = p.terms;
+  snprintf(out->accumulate_kernel, sizeof(out->accumulate_kernel), "%s", p.kernel);
+}
+
+int plonk_ctx_describe_msm(plonk_ctx* ctx, uint64_t m, int count, int bit_sum_tail, uint32_t table_rows, uint64_t table_points, plonk_msm_plan* out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !out || count < 1 || count > MSM_MAX_BATCH) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  Ctx& c = ctx->c;
+  if (table_rows == 0) { table_rows = c.srs_rows; table_points = c.srs_n; if (!c.srs_table) return PLONK_ERR_NO_SRS; }
+  if (table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_HALFPOS && table_rows != MSM_ROWS_BITPOS) return PLONK_ERR_ARG;
+  plonk_msm_plan_internal p;
+  msm_plan(&c, table_rows, table_points, m, count, bit_sum_tail != 0, &p);
+  plan_out(p, out);
+  return PLONK_OK;
+  });
+}
+
+int plonk_ctx_last_msm(plonk_ctx* ctx, plonk_msm_plan* out) {
+  if (!ctx || !out) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  if (!ctx->c.last_plan.table_rows) return (set_last_error("plonk_ctx_last_msm", "no MSM has run on this context", __FILE__, __LINE__), PLONK_ERR_STATE);
+  plan_out(ctx->c.last_plan, out);
+  return PLONK_OK;
 }
 
 void plonk_ctx_destroy(plonk_ctx* ctx) {

@@ -38,16 +38,25 @@ struct RcclApi {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// The transport library.  Default: librccl from the loader path / /opt/rocm/lib.  plonk_comm_set_library names another file
+// BEFORE the first communicator call of the process: a deployment whose RCCL lives elsewhere — and the test suite's
+// stand-in (tests/fake_rccl: hipIpc collectives between ranks that share one GPU, which RCCL itself refuses).  Whatever
+// was loaded is reported by plonk_comm_library, so a benchmark line can never pass a stand-in off as RCCL.
+static std::mutex g_rccl_mu;
+static std::string g_rccl_path;       // explicit path ("" = search the default names)
+static std::string g_rccl_loaded;     // what dlopen resolved (dladdr of ncclAllGather)
+
 static RcclApi* rccl_api() {
   static RcclApi api;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lk(mu);
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (api.lib) return &api;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
-  for (const char* nm : names)
-    if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
-  if (!h) { set_last_error("dlopen(librccl)", dlerror(), __FILE__, __LINE__); return nullptr; }
+  if (!g_rccl_path.empty()) h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  else
+    for (const char* nm : names)
+      if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) { set_last_error(g_rccl_path.empty() ? "dlopen(librccl)" : "dlopen(plonk_comm_set_library path)", dlerror(), __FILE__, __LINE__); return nullptr; }
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
@@ -62,6 +71,8 @@ static RcclApi* rccl_api() {
     dlclose(h);
     return nullptr;
   }
+  Dl_info di;
+  g_rccl_loaded = (dladdr((void*)api.AllGather, &di) && di.dli_fname) ? di.dli_fname : (g_rccl_path.empty() ? "librccl" : g_rccl_path);
   api.lib = h;
   return &api;
 }
@@ -88,10 +99,7 @@ static constexpr size_t COMM_STAGE = 16384;   // bytes per rank of a small (host
 // inside the collective for ever, and a plain hipStreamSynchronize would hang with them: with a communicator the stream
 // is POLLED, and after PLONK_COMM_TIMEOUT_MS (default 120 s) the communicator is aborted (ncclCommAbort) and the call
 // returns PLONK_ERR_STATE, so that every surviving rank gets an error instead of a hang.
-static long comm_timeout_ms() {
-  static const long v = [] { const char* e = getenv("PLONK_COMM_TIMEOUT_MS"); const long t = e ? atol(e) : 0; return t > 0 ? t : 120000L; }();
-  return v;
-}
+static long comm_timeout_ms(const Ctx* c) { return c->cfg.comm_timeout_ms > 0 ? c->cfg.comm_timeout_ms : 120000L; }   // plonk_gpu_config.comm_timeout_ms
 int comm_sync(Ctx* c, hipStream_t st) {
   if (!c->nccl_comm) { HIP_TRY(hipStreamSynchronize(st)); return PLONK_OK; }
   const auto t0 = std::chrono::steady_clock::now();
@@ -101,13 +109,28 @@ int comm_sync(Ctx* c, hipStream_t st) {
     if (e != hipErrorNotReady) { set_last_error("hipStreamQuery", hipGetErrorString(e), __FILE__, __LINE__); return PLONK_ERR_HIP; }
     if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));   // first ~ms: busy poll (collectives take tens of us)
     if ((spin & 1023) == 1023 &&
-        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_ms()) {
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_ms(c)) {
       RcclApi* api = rccl_api();
-      if (api && api->CommAbort) (void)api->CommAbort((ncclComm_t)c->nccl_comm);
+      const bool aborted = api && api->CommAbort && api->CommAbort((ncclComm_t)c->nccl_comm) == ncclSuccess;
       c->nccl_comm = nullptr;   // aborted: the context falls back to "no communicator" and every later sharded call fails loudly
       // the abort releases the collective's kernel; what was queued BEHIND it on this stream (copies into caller-owned host
-      // buffers) must not still be running when the error reaches the caller
-      (void)hipStreamSynchronize(st);
+      // buffers) must not still be running when the error reaches the caller.  The drain is BOUNDED: without a
+      // successful abort — or if the abort does not retire the kernel — a blocking synchronise would be the very hang this
+      // function exists to prevent; the stream is polled for 10 s and, if it never drains, the context is marked unusable.
+      bool drained = false;
+      if (aborted) {
+        const auto t1 = std::chrono::steady_clock::now();
+        while (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() < 10000) {
+          if (hipStreamQuery(st) != hipErrorNotReady) { drained = true; break; }
+          std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+      }
+      if (!drained) {
+        c->comm_poisoned = true;   // work of a dead collective may still sit on the stream: every later entry point of this context refuses
+        set_last_error("comm_sync", aborted ? "collective timed out; the communicator was aborted but the stream did not drain: context unusable"
+                                            : "collective timed out and the transport has no working abort: context unusable", __FILE__, __LINE__);
+        return PLONK_ERR_STATE;
+      }
       set_last_error("comm_sync", "collective timed out (a peer rank failed or never joined): communicator aborted", __FILE__, __LINE__);
       return PLONK_ERR_STATE;
     }
@@ -133,10 +156,19 @@ int comm_allgather_host(Ctx* c, const CommLink& l, const void* send, void* recv,
   if (c->nccl_comm) {
     RcclApi* api = rccl_api();
     if (!api || bytes > COMM_STAGE) return (set_last_error("comm_allgather_host", "message too large / no rccl", __FILE__, __LINE__), PLONK_ERR_ARG);
-    HIP_TRY(hipMemcpyAsync(c->comm_send, send, bytes, hipMemcpyHostToDevice, c->main_stream));
+    // Both host legs go through PINNED staging buffers.  Round 5, found by the peer-failure test on the stand-in transport: with
+    // the caller's pageable `recv` as the target, hipMemcpyAsync(DeviceToHost) does not return until the stream has reached the
+    // copy — i.e. the host sat INSIDE that call behind the collective, where no time-out polls, and a dead peer hung the rank
+    // (the stand-in's kernels give up after a minute; RCCL's never do).  Pinned copies are queued and return; the wait is
+    // comm_sync's poll.
+    memcpy(c->comm_send_host, send, bytes);
+    HIP_TRY(hipMemcpyAsync(c->comm_send, c->comm_send_host, bytes, hipMemcpyHostToDevice, c->main_stream));
     RCCL_TRY(api, api->AllGather(c->comm_send, c->comm_recv, bytes, ncclUint8, (ncclComm_t)c->nccl_comm, c->main_stream));
-    HIP_TRY(hipMemcpyAsync(recv, c->comm_recv, bytes * (size_t)l.world, hipMemcpyDeviceToHost, c->main_stream));
-    return comm_sync(c, c->main_stream);
+    HIP_TRY(hipMemcpyAsync(c->comm_recv_host, c->comm_recv, bytes * (size_t)l.world, hipMemcpyDeviceToHost, c->main_stream));
+    const int rs = comm_sync(c, c->main_stream);
+    if (rs) return rs;
+    memcpy(recv, c->comm_recv_host, bytes * (size_t)l.world);
+    return PLONK_OK;
   }
   if (!l.fn) return (set_last_error("comm_allgather_host", "no communicator and no all-gather callback", __FILE__, __LINE__), PLONK_ERR_STATE);
   if (l.fn(l.user, send, recv, bytes) != 0) return (set_last_error("all-gather callback", "returned non-zero", __FILE__, __LINE__), PLONK_ERR_STATE);
@@ -220,6 +252,28 @@ int plonk_comm_measure_loopback(plonk_ctx* ctx, int on) {
   });
 }
 
+int plonk_comm_set_library(const char* path) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!path || !path[0]) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!g_rccl_loaded.empty()) return (set_last_error("plonk_comm_set_library", "a transport library is already loaded in this process", __FILE__, __LINE__), PLONK_ERR_STATE);
+  g_rccl_path = path;
+  return PLONK_OK;
+  });
+}
+
+int plonk_comm_library(char* out, uint64_t cap) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!out || cap == 0) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (g_rccl_loaded.empty()) return (set_last_error("plonk_comm_library", "no transport library loaded yet", __FILE__, __LINE__), PLONK_ERR_STATE);
+  snprintf(out, (size_t)cap, "%s", g_rccl_loaded.c_str());
+  return PLONK_OK;
+  });
+}
+
 int plonk_comm_unique_id(uint8_t out[128]) {
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
@@ -242,6 +296,7 @@ int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int worl
   std::lock_guard<std::mutex> lk(c.mu);
   HIP_TRY(hipSetDevice(c.device));
   if (c.nccl_comm) return (set_last_error("plonk_comm_init", "context already has a communicator", __FILE__, __LINE__), PLONK_ERR_STATE);
+  if (c.comm_poisoned) return (set_last_error("plonk_comm_init", "context unusable: a collective timed out and its stream never drained", __FILE__, __LINE__), PLONK_ERR_STATE);
   RcclApi* api = rccl_api();
   if (!api) return PLONK_ERR_STATE;
   ncclUniqueId id;
@@ -261,18 +316,31 @@ int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int worl
   (void)hipFree(c.comm_send);   // left over when comm_sync aborted the previous communicator
   (void)hipFree(c.comm_recv);
   c.comm_send = c.comm_recv = nullptr;
+  (void)hipHostFree(c.comm_send_host);
+  (void)hipHostFree(c.comm_recv_host);
+  c.comm_send_host = c.comm_recv_host = nullptr;
   hipError_t e = hipMalloc((void**)&c.comm_send, COMM_STAGE);
   if (e == hipSuccess) e = hipMalloc((void**)&c.comm_recv, COMM_STAGE * (size_t)world);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c.comm_send_host, COMM_STAGE, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c.comm_recv_host, COMM_STAGE * (size_t)world, hipHostMallocDefault);
   if (e != hipSuccess) {
     (void)api->CommDestroy(comm);
     (void)hipFree(c.comm_send);
-    c.comm_send = nullptr;
+    (void)hipFree(c.comm_recv);
+    (void)hipHostFree(c.comm_send_host);
+    c.comm_send = c.comm_recv = c.comm_send_host = nullptr;
     set_last_error("hipMalloc(comm staging)", hipGetErrorString(e), __FILE__, __LINE__);
     return PLONK_ERR_HIP;
   }
   c.nccl_comm = comm;
   c.comm_rank = rank;
   c.comm_world = world;
+  {   // the communicator can come up without the variable and fail later, inside an IPC exchange nobody annotates
+    const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+    if (world > 1 && !(ipc && ipc[0] == '0'))
+      set_last_error("plonk_comm_init: warning", "HSA_ENABLE_IPC_MODE_LEGACY=0 is not in the environment; on a dmabuf-only driver device-memory "
+                     "exchange between processes fails later with hipIpcGetMemHandle: invalid argument — export it before the first HIP call", __FILE__, __LINE__);
+  }
   return PLONK_OK;
   });
 }
@@ -283,7 +351,7 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   if (!ctx) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
   std::lock_guard<std::mutex> lk(c.mu);
-  if (!c.nccl_comm && !c.comm_send && !c.comm_recv) return PLONK_OK;
+  if (!c.nccl_comm && !c.comm_send && !c.comm_recv && !c.comm_send_host) return PLONK_OK;
   (void)hipSetDevice(c.device);
   (void)hipStreamSynchronize(c.main_stream);
   if (c.nccl_comm) {   // (already gone after a time-out abort in comm_sync: only the staging buffers are left to free)
@@ -293,7 +361,9 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   c.nccl_comm = nullptr;
   (void)hipFree(c.comm_send);
   (void)hipFree(c.comm_recv);
-  c.comm_send = c.comm_recv = nullptr;
+  (void)hipHostFree(c.comm_send_host);
+  (void)hipHostFree(c.comm_recv_host);
+  c.comm_send = c.comm_recv = c.comm_send_host = c.comm_recv_host = nullptr;
   c.comm_world = 1;
   c.comm_rank = 0;
   return PLONK_OK;

@@ -938,34 +938,44 @@ __global__ void msm_identity_kernel(G1* out) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-// Rows of the tables of an n-point key.  A row per bit position (256 rows, 32 KiB per point) saves 8 % of the
-// additions of every MSM over the key (25 % with the 2^19-bucket layout it also enables); it is chosen when the tables
-// take at most HALF of the HBM that is free right now — 2^20 points: 32 GiB, twice per prover context (commit key and
-// Lagrange-basis key) of 288 GB; 2^22 points: 137 GB for the commit key, after which the Lagrange-basis key (4 of the 11
-// commitments) falls back to the 16 window rows (8.6 GiB).  PLONK_MSM_TABLE=window | bitpos forces either.
-uint32_t msm_table_rows(uint64_t n) {
-  if (const char* e = getenv("PLONK_MSM_TABLE")) {
-    if (e[0] == 'w') return MSM_ROWS_WINDOW;
-    if (e[0] == 'b') return (uint64_t)MSM_ROWS_BITPOS * n <= (1ull << 31) ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
-    if (e[0] == 'h') return MSM_ROWS_HALFPOS;   // a row for every second bit position (round 4)
-  }
-  if ((uint64_t)MSM_ROWS_BITPOS * n > (1ull << 31)) return MSM_ROWS_WINDOW;   // 31-bit table index of an entry
+// Rows of the tables of an n-point key.  A row per bit position (256 rows, 32 KiB per point) saves 8 % of the additions of
+// every MSM over the key (25 % with the 2^19-bucket layout it also enables); a row per SECOND bit position (128 rows, round
+// 4: for_each_digit_even, 12.8 instead of 16 additions per scalar) is half the memory.  Which one a key gets follows the
+// context's TABLE BUDGET (plonk_gpu_config.table_budget_bytes, default 80 % of the device's total memory) and what the
+// context already holds — not the memory that happens to be free (until round 4: "half of what hipMemGetInfo reports free
+// right now", so a neighbour process or a second context silently changed the layout, the additions per scalar and the
+// run time):
+//   * the COMMIT key is loaded before the prover's buffers and the Lagrange-basis key exist and leaves room for them
+//     (ADVICE r4): bit-position rows when they take at most 60 % of the budget, every second position at most 30 %;
+//   * a prover's LAGRANGE-basis key is built last, nothing grows after it: the densest layout that fits in what is left.
+// 2^20 points: 32 GiB per key, twice per prover context, of 288 GB; 2^22: 137 GB for the commit key + 69 GB of half-density
+// rows for the Lagrange-basis key.  plonk_gpu_config.table_mode (PLONK_MSM_TABLE=window|halfpos|bitpos) forces a layout.
+uint64_t msm_table_bytes(uint32_t rows, uint64_t n) {
+  const uint64_t scratch = sizeof(Fp28Slot) * 3 * (uint64_t)(rows - 1) * (1ull << 16);   // srs_table_kernel's per-chunk scratch
+  return sizeof(G1AffineR) * (uint64_t)rows * n + (rows > MSM_ROWS_WINDOW ? scratch : 0);
+}
+uint32_t msm_table_rows(const Ctx* c, uint64_t n, bool last_key) {
+  auto index_ok = [n](uint32_t rows) { return (uint64_t)rows * n <= (1ull << 31); };   // 31-bit table index of an entry
+  const int mode = c->cfg.table_mode;
+  if (mode == (int)MSM_ROWS_WINDOW) return MSM_ROWS_WINDOW;
+  if (mode == (int)MSM_ROWS_HALFPOS) return MSM_ROWS_HALFPOS;                          // (table_index_check refuses an oversized key)
+  if (mode == (int)MSM_ROWS_BITPOS) return index_ok(MSM_ROWS_BITPOS) ? MSM_ROWS_BITPOS : MSM_ROWS_WINDOW;
   // small keys: the saved additions do not pay for the longer recoding, the skewed top digit and — with the 2^19-bucket
   // layout — a reduction over 16x the buckets (same-box pairs, window rows vs bit-position rows: 2^16 gates 5.33 / 5.59 ms,
   // 2^18 11.16 / 11.37, 2^19 20.23 / 20.43; 2^20 37.8 / 34.9, 2^21 71.9* / 64.4, 2^22 147.0 / 131.8; * = 2^15 buckets).
   // profiles/r03c/sizes_2p18_to_2p22.txt
   // round 4: keys of 2^18 .. 2^19 points take bit-position rows too (2^19 buckets win from 2^19 terms on, see msm_batch_device)
   if (n <= (1ull << 18) + 64) return MSM_ROWS_WINDOW;
-  size_t fr = 0, tot = 0;
-  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MSM_ROWS_WINDOW;
-  const uint64_t scratch = sizeof(Fp28Slot) * 3 * (MSM_ROWS_BITPOS - 1) * (1ull << 16);
-  const uint64_t need = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_BITPOS * n + scratch;
-  if (need <= fr / 2) return MSM_ROWS_BITPOS;
-  // no room for a row per bit (the Lagrange-basis key of a 2^22-gate circuit beside the commit key's 137 GB): a row for
-  // every SECOND bit position is half the memory and 12.8 instead of 16 additions per scalar (round 4, msm_recode.cuh
-  // for_each_digit_even).  It may take most of what is left: the key is built last (prover.hip) and nothing else grows.
-  const uint64_t need_half = sizeof(G1AffineR) * (uint64_t)MSM_ROWS_HALFPOS * n + scratch / 2;
-  if (need_half <= fr / 10 * 7) return MSM_ROWS_HALFPOS;
+  const uint64_t budget = c->cfg.table_budget;
+  const uint64_t left = budget > c->table_bytes ? budget - c->table_bytes : 0;
+  // the 31-bit index limit is checked per layout (keys of 2^23 .. 2^24 points can still take half-density rows)
+  const uint32_t layouts[2] = {MSM_ROWS_BITPOS, MSM_ROWS_HALFPOS};
+  const uint64_t share[2] = {budget / 10 * 6, budget / 10 * 3};
+  for (int k = 0; k < 2; ++k) {
+    if (!index_ok(layouts[k])) continue;
+    const uint64_t need = msm_table_bytes(layouts[k], n);
+    if (need <= left && (last_key || need <= share[k])) return layouts[k];
+  }
   return MSM_ROWS_WINDOW;
 }
 static int table_index_check(uint32_t rows, uint64_t n) {
@@ -975,12 +985,20 @@ static int table_index_check(uint32_t rows, uint64_t n) {
 // allocate the tables of an n-point key (replacing the old key); the rows are filled by srs_table_chunk
 int srs_table_begin(Ctx* c, uint64_t n) {
   ++c->srs_gen;   // provers built on the previous key refuse to prove (prover.hip)
-  if (c->srs_table) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->srs_table)); c->srs_table = nullptr; c->srs_n = 0; c->srs_rows = 0; }
+  if (c->srs_table) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(c->srs_table));
+    c->table_bytes -= c->srs_table_alloc < c->table_bytes ? c->srs_table_alloc : c->table_bytes;
+    c->srs_table_alloc = 0;
+    c->srs_table = nullptr; c->srs_n = 0; c->srs_rows = 0;
+  }
   if (n == 0) return PLONK_OK;
-  const uint32_t rows = msm_table_rows(n);
+  const uint32_t rows = msm_table_rows(c, n, false);
   { const int rc = table_index_check(rows, n); if (rc) return rc; }
   HIP_TRY(hipMalloc((void**)&c->srs_table, sizeof(G1AffineR) * (size_t)rows * n));
   c->srs_rows = rows;
+  c->srs_table_alloc = sizeof(G1AffineR) * (uint64_t)rows * n;   // (callers set srs_n once the rows are filled; the bytes are held from here on)
+  c->table_bytes += c->srs_table_alloc;
   return PLONK_OK;
 }
 // scratch of srs_table_kernel, kept on the context between the chunks of one load
@@ -1019,7 +1037,7 @@ int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_ou
   *table_out = nullptr;
   *rows_out = 0;
   if (n == 0) return PLONK_OK;
-  const uint32_t rows = msm_table_rows(n);
+  const uint32_t rows = msm_table_rows(c, n, true);
   { const int rc = table_index_check(rows, n); if (rc) return rc; }
   G1AffineR* t = nullptr;
   HIP_TRY(hipMalloc((void**)&t, sizeof(G1AffineR) * (size_t)rows * n));
@@ -1029,7 +1047,14 @@ int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_ou
   if (rc) { (void)hipFree(t); return rc; }
   *table_out = t;
   *rows_out = rows;
+  c->table_bytes += sizeof(G1AffineR) * (uint64_t)rows * n;   // released by srs_table_release (prover_free)
   return PLONK_OK;
+}
+void srs_table_release(Ctx* c, void* table, uint32_t rows, uint64_t n) {
+  if (!table) return;
+  (void)hipFree(table);
+  const uint64_t held = sizeof(G1AffineR) * (uint64_t)rows * n;
+  c->table_bytes -= held < c->table_bytes ? held : c->table_bytes;
 }
 
 // ---------------------------------------------------------------------------
@@ -1168,8 +1193,8 @@ namespace PLONK_MSM_NS {
 // Slice length.  2^15 buckets: 32 entries from m = 2^20 up; halved with m below that (down to 4) so that a smaller MSM
 // still spreads over ~2^19 lanes instead of leaving most SIMDs idle behind 32 serial additions.  2^19 buckets: always 32 —
 // a bucket holds ~24 entries at m = 2^20, i.e. one lane per bucket (in order of length) and almost no second slices.
-static uint32_t msm_ksl(uint64_t m) {
-  static const int forced = [] { const char* e = getenv("PLONK_MSM_KSL"); return e ? atoi(e) : 0; }();   // tuning experiments only
+uint32_t msm_ksl(const Ctx* c, uint64_t m) {
+  const int forced = c->cfg.ksl;   // PLONK_MSM_KSL: tuning experiments only
   if (forced == 4 || forced == 8 || forced == 16 || forced == 32 || forced == 64 || forced == 128) return (uint32_t)forced;
   // 2^17 buckets (r04): 32-entry slices although a bucket holds ~53 entries at 2^19 terms.  One lane per bucket (128-entry
   // slices) is a single round of 2^17 lanes per commitment whose longest buckets set the kernel's time: accumulate ran at
@@ -1186,6 +1211,9 @@ static uint32_t msm_ksl(uint64_t m) {
   while (r < MSM_KSL && (uint64_t)r * MSM_NB < 3 * m) r *= 2;
   return r;
 }
+
+// lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default where slices are 32 entries long
+bool msm_acc_ordered(const Ctx* c, uint32_t ksl) { return c->cfg.order >= 0 ? c->cfg.order == 1 : ksl >= 32; }
 
 #if PLONK_MSM_NB_BITS > 15
 // ---- reduction tail for MANY buckets: throughput first ---------------------------------------------------------------
@@ -1300,7 +1328,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   const int count = bt.count;
   const void* table = bt.table;
   int rc = PLONK_OK;
-  bt.ksl = msm_ksl(mmax);
+  bt.ksl = msm_ksl(c, mmax);
   bt.wide = msm_needs_wide_words(bt.rows, bt.table_n) ? 1u : 0u;
   if (MSM_NB_BITS > 15 && !bit_sums) return (plonk::set_last_error("msm", "the 2^19-bucket variant only emits bit sums", __FILE__, __LINE__), PLONK_ERR_ARG);
   {
@@ -1311,7 +1339,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   // PLONK_PROF_FINE=1: every phase of the group on its own slot (16 + phase for groups of >= 3 commitments, 24 + phase below;
   // phases: 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums (+ fold), 5 bit sums) —
   // hipEvents between the launches, i.e. kernel times WITHOUT a profiler attached (tools/msm_phases.py)
-  static const bool fine = [] { const char* e = getenv("PLONK_PROF_FINE"); return e && e[0] == '1'; }();
+  const bool fine = c->cfg.prof_fine;
   const int fbase = count >= 3 ? 16 : 24;
 #define FINE_BEGIN(ph) do { if (fine) prof_begin(c, fbase + (ph)); } while (0)
 #define FINE_END(ph) do { if (fine) prof_end(c, fbase + (ph)); } while (0)
@@ -1327,13 +1355,12 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   FINE_BEGIN(1);
   // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
   // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
-  static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
+  const bool acc_lds = c->cfg.acc_lds;
   // lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default where slices are 32
   // entries long (m > 2^19; r03a same-box A/B at 2^20: accumulate 26.5 -> 25.7 ms per proof, the waves no longer wait
   // for their longest lane); shorter slices (smaller m) leave the accumulation latency-bound and the ordering loses
   // (r02e: +1.1 ms at 2^16).  PLONK_MSM_ORDER=1 / 0 forces either.
-  static const int order_env = [] { const char* e = getenv("PLONK_MSM_ORDER"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-  const bool acc_ordered = order_env >= 0 ? order_env == 1 : bt.ksl >= 32;
+  const bool acc_ordered = msm_acc_ordered(c, bt.ksl);
   if (acc_ordered && !acc_lds) {
     rc = msm_order_slices(c, bt);
     if (rc) return rc;
@@ -1354,12 +1381,12 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
     const uint32_t heavy_thresh = bt.heavy_thresh;                  // the list of heavy buckets was written by msm_slices_kernel
     // PLONK_MSM_TAIL=serial: one lane per addition in the heavy-bucket, row/column and bit-sum kernels (A/B, fallback)
-    static const bool tail_quad_ = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
+    const bool tail_quad_ = !c->cfg.tail_serial;
     const uint32_t fused = (tail_quad_ || MSM_NB_BITS > 15) ? HEAVY_FUSED_WGS : 0u;   // segment workers inside msm_bucket_sum's grid
     const bool list_mode = MSM_NB_BITS > 15 && acc_ordered && !acc_lds;   // bucket sums driven by msm_layout_apply's list
     // few slices per bucket (small MSMs over 2^15 buckets): a quad per bucket (dense_quad above); PLONK_MSM_BSUM=lane restores
     // the one-lane-per-bucket kernels for A/B
-    static const bool bsum_lane = [] { const char* e = getenv("PLONK_MSM_BSUM"); return e && e[0] == 'l'; }();
+    const bool bsum_lane = c->cfg.bsum_lane;
     const bool dense_quad = !list_mode && tail_quad_ && !bsum_lane && avg_slices <= 8;
 #define BSUM(G) hipLaunchKernelGGL(msm_bucket_sum_kernel<G>, dim3((list_mode ? 1024u : (dense_quad ? MSM_NB * 4 / 128 : MSM_NB * G / 128)) + fused, count), dim3(128), 0, st, bt, \
                                    (const G1RSlot*)w.partial, w.slice_off, (G1RSlot*)w.buckets, heavy_thresh, w.nheavy, (const HeavyItem*)w.heavy_list, \
@@ -1374,7 +1401,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   }
   FINE_END(2);
   FINE_BEGIN(3);
-  static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
+  const bool tail_quad = !c->cfg.tail_serial;
   if (tail_quad || MSM_NB_BITS > 15) {
     hipLaunchKernelGGL(msm_heavy_bucket_quad_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
                        (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets, HEAVY_FUSED_WGS);
@@ -1391,7 +1418,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     G1RSlot* rc1 = (G1RSlot*)w.chunk;
     G1RSlot* rc2 = rc1 + (size_t)TP_RC1 * MSM_MAX_BATCH;
     // PLONK_MSM_RCTREE=lane: the partial sums of a row / column combined by a lane tree instead of quads (A/B)
-    static const bool rc_lane_tree = [] { const char* e = getenv("PLONK_MSM_RCTREE"); return e && e[0] == 'l'; }();
+    const bool rc_lane_tree = c->cfg.rc_lane_tree;
 #define TPK(LPS) do { if (rc_lane_tree) hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, false>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); \
                       else hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, true>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); } while (0)
     // lanes per sum of 128 buckets: the chip holds 2^17 lanes at two waves per SIMD and a commitment has 2^13 sums; fewer
@@ -1399,7 +1426,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     // but lengthen the serial chain.  Measured (profiles/r03e section 7): 8 / 8 / 16 for groups of >= 3 / 2 / 1 commitments
     // (until then 8 / 16 / 32: the small groups over-subscribed the chip two-fold for the sake of depth); 4 for the large
     // groups gains nothing at 2^20 and loses 0.5 ms at 2^22, where the kernel shares the chip with longer transforms.
-    static const int lps_env = [] { const char* e = getenv("PLONK_MSM_LPS"); return e ? atoi(e) : 0; }();   // A/B runs
+    const int lps_env = c->cfg.lps;   // PLONK_MSM_LPS: A/B runs
     int lps = count >= 2 ? 8 : 16;
     // 2^17 buckets (r04): a quarter of the sums — 8 lanes per sum left half of the chip idle behind 18 dependent additions
     // (0.64 ms per group of four, profiles/r04d); lanes per sum so that a launch has about the chip's 2^17 lane slots
@@ -1422,7 +1449,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   if (bit_sums && tail_quad) {
     // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
     FINE_BEGIN(4);
-    static const int rcwv_env = [] { const char* e = getenv("PLONK_MSM_RCWV"); return e ? atoi(e) : 0; }();   // A/B runs: waves per sum for groups of 1 / 2 / >= 3 commitments as a 3-digit number, e.g. 421
+    const int rcwv_env = c->cfg.rcwv;   // PLONK_MSM_RCWV, A/B runs: waves per sum for groups of 1 / 2 / >= 3 commitments as a 3-digit number, e.g. 421
     int wv = count >= 3 ? 1 : (count == 2 ? 2 : 4);
     if (rcwv_env >= 111) wv = count >= 3 ? rcwv_env % 10 : (count == 2 ? (rcwv_env / 10) % 10 : rcwv_env / 100);
     if (wv == 1) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
@@ -1459,8 +1486,8 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
 #if PLONK_MSM_NB_BITS == 15   // ---- shared: buffers, variant choice, single-result entry points ----
 // upper bound of the slice count over every m <= cap and either bucket count: 2^15 buckets use slices of 4..32 entries
 // (MSM_W * m / ksl(m) <= 16 * 2^15 below 2^20), 2^19 buckets slices of 32; + one partial slice per bucket
-static uint64_t msm_slice_cap(uint64_t cap) {
-  if (const char* e = getenv("PLONK_MSM_KSL")) { const int f = atoi(e); if (f >= 4) return (uint64_t)MSM_W * cap / f + MSM_NB_MAX + 1; }
+static uint64_t msm_slice_cap(const Ctx* c, uint64_t cap) {
+  if (c->cfg.ksl >= 4) return (uint64_t)MSM_W * cap / c->cfg.ksl + MSM_NB_MAX + 1;
   const uint64_t nb15 = 1ull << 15;
   const uint64_t small = (uint64_t)MSM_W * cap / 4 < (uint64_t)MSM_W * nb15 ? (uint64_t)MSM_W * cap / 4 : (uint64_t)MSM_W * nb15;
   const uint64_t large = (uint64_t)MSM_W * cap / MSM_KSL;
@@ -1518,13 +1545,56 @@ int msm_reserve(Ctx* c, uint64_t m) {
     }
     HIP_TRY(hipMalloc((void**)&w.tmp_words, sizeof(uint64_t) * MSM_W * cap * KB));  // words grouped by coarse bin (two planes for tables above 2^27 entries)
     HIP_TRY(hipMalloc((void**)&w.entries, sizeof(uint32_t) * MSM_W * cap * KB));    // entries grouped by bucket
-    w.cap_slices = msm_slice_cap(cap);
+    w.cap_slices = msm_slice_cap(c, cap);
     HIP_TRY(hipMalloc((void**)&w.partial, sizeof(G1RSlot) * w.cap_slices * KB));
     w.cap_segs = w.cap_slices / 128 + MSM_NB_MAX + 1;   // sum over heavy buckets of ceil(slices / HEAVY_SEG)
     HIP_TRY(hipMalloc((void**)&w.seg_sum, sizeof(G1RSlot) * w.cap_segs * KB));
     w.cap_m = cap;
   }
   return PLONK_OK;
+}
+
+// The choices msm_batch_device makes for a group, in one place — the launcher follows it, plonk_ctx_describe_msm /
+// plonk_ctx_last_msm report it (the variant tests assert it: a switch that is silently ignored fails a test).
+// Bucket count by the number of terms: more than 2^18 terms 2^19 buckets, else 2^15.  Round 4 moved the crossover down from
+// 2^19 (same box, 2^19 gates: window rows 19.94 ms, bit-position rows over 2^15 / 2^17 / 2^19 buckets 21.31 / 19.99 / 19.20;
+// 2^18 gates: 10.94 / 10.92 / 11.01 / 11.44 — profiles/r04h) — a rank of a 2-GPU job at 2^20 gates or of an 8-GPU job at
+// 2^22 holds 2^19 points.  plonk_gpu_config.msm_bucket_bits (PLONK_MSM_BUCKETS=15 / 19) forces one wherever it is possible
+// (19 needs bit-position or half-density rows and the bit-sum tail; 17: the opt-in A/B build with the 2^17-bucket variant).
+void msm_plan(const Ctx* c, uint32_t table_rows, uint64_t table_n, uint64_t mmax, int count, bool bit_sums, plonk_msm_plan_internal* out) {
+  (void)count;
+  const int buckets_env = c->cfg.bucket_bits;
+  const bool can_large = (table_rows == MSM_ROWS_BITPOS || table_rows == MSM_ROWS_HALFPOS) && bit_sums && !c->cfg.tail_serial && !c->cfg.acc_lds;
+  int nb_bits = 15;
+  if (can_large) {
+    if (buckets_env == 17 || buckets_env == 19) nb_bits = buckets_env;
+    else if (buckets_env > 15) nb_bits = 19;
+    else if (buckets_env != 15) nb_bits = mmax > (1ull << 18) + 64 ? 19 : 15;
+  }
+#ifndef PLONK_MSM_WITH_MEDIUM
+  if (nb_bits == 17) nb_bits = 19;
+#endif
+  plonk_msm_plan_internal p;
+  p.table_rows = table_rows;
+  p.bucket_bits = (uint32_t)nb_bits;
+  p.digit_width = table_rows == MSM_ROWS_WINDOW ? 16u : (table_rows == MSM_ROWS_BITPOS ? (uint32_t)nb_bits + 2u : (uint32_t)nb_bits + 1u);
+  p.terms = mmax;
+  bool ordered;
+  if (nb_bits == 19) { p.slice_entries = nbl::msm_ksl(c, mmax); ordered = nbl::msm_acc_ordered(c, p.slice_entries); p.wide_words = nbl::msm_needs_wide_words(table_rows, table_n); }
+#ifdef PLONK_MSM_WITH_MEDIUM
+  else if (nb_bits == 17) { p.slice_entries = nbm::msm_ksl(c, mmax); ordered = nbm::msm_acc_ordered(c, p.slice_entries); p.wide_words = nbm::msm_needs_wide_words(table_rows, table_n); }
+#endif
+  else { p.slice_entries = nb15::msm_ksl(c, mmax); ordered = nb15::msm_acc_ordered(c, p.slice_entries); p.wide_words = nb15::msm_needs_wide_words(table_rows, table_n); }
+  p.ordered_lanes = ordered && !c->cfg.acc_lds;
+  static const char* const names[3][3] = {
+      {"nb15::msm_accumulate_kernel", "nb15::msm_accumulate_ordered_kernel", "nb15::msm_accumulate_lds_kernel"},
+      {"nbm::msm_accumulate_kernel", "nbm::msm_accumulate_ordered_kernel", "nbm::msm_accumulate_lds_kernel"},
+      {"nbl::msm_accumulate_kernel", "nbl::msm_accumulate_ordered_kernel", "nbl::msm_accumulate_lds_kernel"}};
+  const uint64_t avg_slices = (MSM_W * mmax) / (p.slice_entries ? p.slice_entries : 1) / (1ull << nb_bits);
+  p.flags = (c->cfg.tail_serial ? PLONK_PLAN_TAIL_SERIAL : 0u) | (c->cfg.acc_lds ? PLONK_PLAN_ACCUMULATE_LDS : 0u) |
+            ((c->cfg.bsum_lane || c->cfg.tail_serial || avg_slices > 8 || (nb_bits > 15 && p.ordered_lanes)) ? PLONK_PLAN_BUCKET_SUM_LANE : 0u);
+  p.kernel = names[nb_bits == 19 ? 2 : (nb_bits == 17 ? 1 : 0)][c->cfg.acc_lds ? 2 : (p.ordered_lanes ? 1 : 0)];
+  *out = p;
 }
 
 // `count` (<= MSM_MAX_BATCH) independent MSMs over the same bases, launched together: the
@@ -1569,20 +1639,10 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
     bt.tail[k] = tail_dev ? tail_dev[k] : nullptr;
     bt.split[k] = (tail_dev && split) ? split[k] : ~0ull;
   }
-  static const int buckets_env = [] { const char* e = getenv("PLONK_MSM_BUCKETS"); return e ? atoi(e) : 0; }();
-  static const bool tail_quad = [] { const char* e = getenv("PLONK_MSM_TAIL"); return !(e && e[0] == 's'); }();
-  static const bool acc_lds = [] { const char* e = getenv("PLONK_MSM_ACC"); return e && e[0] == 'l'; }();
-  // bucket count by the number of terms: more than 2^18 terms 2^19 buckets, else 2^15.  Round 4 moved the crossover down from
-  // 2^19 (same box, 2^19 gates: window rows 19.94 ms, bit-position rows over 2^15 / 2^17 / 2^19 buckets 21.31 / 19.99 / 19.20;
-  // 2^18 gates: 10.94 / 10.92 / 11.01 / 11.44 — profiles/r04h) — a rank of a 2-GPU job at 2^20 gates or of an 8-GPU job at
-  // 2^22 holds 2^19 points.  PLONK_MSM_BUCKETS=15 / 19 forces one (17: the opt-in A/B build with the 2^17-bucket variant)
-  const bool can_large = (table_rows == MSM_ROWS_BITPOS || table_rows == MSM_ROWS_HALFPOS) && bit_sums && tail_quad && !acc_lds;
-  int nb_bits = 15;
-  if (can_large) {
-    if (buckets_env == 17 || buckets_env == 19) nb_bits = buckets_env;
-    else if (buckets_env > 15) nb_bits = 19;
-    else if (buckets_env != 15) nb_bits = mmax > (1ull << 18) + 64 ? 19 : 15;
-  }
+  plonk_msm_plan_internal plan;
+  msm_plan(c, table_rows, table_n, mmax, count, bit_sums, &plan);
+  c->last_plan = plan;
+  const int nb_bits = (int)plan.bucket_bits;
   if (nb_bits == 19) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums);
 #ifdef PLONK_MSM_WITH_MEDIUM
   if (nb_bits == 17) return nbm::msm_batch_device_v(c, bt, mmax, bit_sums);

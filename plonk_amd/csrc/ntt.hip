@@ -496,7 +496,7 @@ int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
   // Direct inter-pass twiddles (one Fr product less per element in passes A and B, ~15 % of a transform's multiplications):
   // N + N / R1 slots of 48 B — 0.2 GB at 2^22, 0.8 GB at 2^24 per direction.  PLONK_NTT_DIRECT=0 keeps the two-level tables
   // (A/B runs); above 2^NTT_DIRECT_MAX_LOG, or when the tables would take more than 1/8 of the free memory, likewise.
-  static const bool direct_on = [] { const char* e = getenv("PLONK_NTT_DIRECT"); return !(e && e[0] == '0'); }();
+  const bool direct_on = c->cfg.ntt_direct;
   if (direct_on && L > 10 && L <= (uint32_t)NTT_DIRECT_MAX_LOG) {
     int r[3], np;
     ntt_plan(L, r, &np);
@@ -538,7 +538,7 @@ static void launch_pass(Ctx* c, const NttPass& p, bool transpose, uint64_t cols)
 // Elements per lane of the pass kernels (log2): PLONK_NTT_ELOG=2|3 forces either, else the caller's hint (prover.hip), else
 // the default; a radix of 2^9 always runs with 8 elements (a 1024-element tile would be two columns wide: 64-byte runs).
 static int ntt_elog(const Ctx* c, int rlog) {
-  static const int forced = [] { const char* e = getenv("PLONK_NTT_ELOG"); return e && (e[0] == '2' || e[0] == '3') ? e[0] - '0' : 0; }();
+  const int forced = c->cfg.ntt_elog;   // plonk_gpu_config.ntt_elements_log2 / PLONK_NTT_ELOG
   if (rlog >= 9) return 3;
   if (forced) return forced;
   return c->ntt_elog_hint == 2 || c->ntt_elog_hint == 3 ? c->ntt_elog_hint : NTT_ELOG_DEFAULT;

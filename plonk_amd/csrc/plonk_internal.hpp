@@ -130,8 +130,51 @@ struct MsmWork {   // per-context scratch, grown on demand
   uint64_t cap_stage = 0;
 };
 
+// Effective configuration of a context: plonk_gpu_config with defaults resolved, then the environment overrides applied —
+// ONCE, at plonk_ctx_create[_ex] / plonk_ctx_set_config (capi.hip config_resolve).  No other file of the library reads the
+// environment for a behaviour switch (round 4 had 22 getenv sites, most of them latched in function statics at first use).
+struct Config {
+  // public fields (include/plonk_hip.h)
+  uint64_t table_budget = 0;        // bytes all point tables of the context may take together (resolved: never 0)
+  int table_mode = 0;               // 0 auto, else MSM_ROWS_WINDOW / _HALFPOS / _BITPOS
+  int bucket_bits = 0;              // 0 by the number of terms, 15, 17 (A/B build), 19
+  int quotient_domain = 4;          // 4 or 8
+  int wire_commit_coeff = 0;        // 1: coefficient-form wire commitments
+  int shard_quotient = 0;           // 0 default, 1 on, -1 off
+  int shard_z = 0;
+  int shard_side = 0;
+  int ntt_elog = 0;                 // 0 default, 2, 3
+  int comm_timeout_ms = 120000;
+  int side_cus = 0;                 // CUs reserved for the side stream (0 = none)
+  // kernel-tuning switches of the A/B scripts: environment only (DESIGN.md section 2 lists them)
+  int ksl = 0;                      // PLONK_MSM_KSL: forced slice length
+  bool prof_fine = false;           // PLONK_PROF_FINE=1: per-phase hipEvent slots
+  bool acc_lds = false;             // PLONK_MSM_ACC=lds
+  int order = -1;                   // PLONK_MSM_ORDER=0/1
+  bool tail_serial = false;         // PLONK_MSM_TAIL=serial
+  bool bsum_lane = false;           // PLONK_MSM_BSUM=lane
+  bool rc_lane_tree = false;        // PLONK_MSM_RCTREE=lane
+  int lps = 0;                      // PLONK_MSM_LPS
+  int rcwv = 0;                     // PLONK_MSM_RCWV
+  int sort13 = -1;                  // PLONK_MSM_SORT13=0/1: 13-digit staging of the 2^19-bucket partition (round 5)
+  int rc_affine = -1;               // PLONK_MSM_RCAFFINE=0/1: affine buckets in the row / column sums (round 5)
+  bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
+  int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
+  int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
+};
+
+struct plonk_msm_plan_internal {   // what msm_batch_device chose (mirrors plonk_msm_plan)
+  uint32_t table_rows = 0, bucket_bits = 0, digit_width = 0, slice_entries = 0, ordered_lanes = 0, wide_words = 0, flags = 0;
+  uint64_t terms = 0;
+  const char* kernel = "";
+};
+
 struct Ctx {
   int device = 0;
+  Config cfg;
+  uint64_t srs_table_alloc = 0;        // bytes of srs_table
+  uint64_t table_bytes = 0;            // bytes of point tables this context holds (commit key + Lagrange-basis keys of its provers)
+  plonk_msm_plan_internal last_plan;   // of the last msm_batch_device call (plonk_ctx_last_msm)
   hipStream_t stream = nullptr;    // every launch goes to this stream (prover.hip swaps it for side work)
   hipStream_t main_stream = nullptr;
   hipStream_t side_stream = nullptr;   // low priority: challenge-independent NTTs overlapped with MSM phases
@@ -161,7 +204,10 @@ struct Ctx {
   void* nccl_comm = nullptr;
   uint8_t* comm_send = nullptr;
   uint8_t* comm_recv = nullptr;
+  uint8_t* comm_send_host = nullptr;   // pinned twins of the two staging buffers: the host legs of a small all-gather never block
+  uint8_t* comm_recv_host = nullptr;   // inside hipMemcpyAsync behind a collective (comm.hip comm_allgather_host)
   int comm_rank = 0, comm_world = 1;
+  bool comm_poisoned = false;      // comm_sync timed out and the stream never drained: sharded proofs and new communicators are refused
   bool comm_loopback = false;      // measurement only: collectives return the rank's own contribution (plonk_comm_measure_loopback)
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
@@ -219,7 +265,9 @@ static constexpr int MSM_BIT_SUMS = 12 + 9;          // slots per commitment (th
   int msm_order_slices(Ctx* c, const MsmBatch& bt);                                                                      \
   int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax);                                                         \
   bool msm_needs_wide_words(uint32_t rows, uint64_t table_n);                                                            \
-  int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums);
+  int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums);                                            \
+  uint32_t msm_ksl(const Ctx* c, uint64_t m);                                                                            \
+  bool msm_acc_ordered(const Ctx* c, uint32_t ksl);
 namespace nb15 { PLONK_MSM_VARIANT_DECLS }
 #ifdef PLONK_MSM_WITH_MEDIUM
 namespace nbm { PLONK_MSM_VARIANT_DECLS int msm_buckets_bits(); }
@@ -232,9 +280,16 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
                      const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr, uint32_t table_rows = 0);
 // rows of the tables of an n-point key: 256 (one per bit position) when they fit comfortably in the free HBM, else
 // the 16 window rows; PLONK_MSM_TABLE=window|bitpos forces either
-uint32_t msm_table_rows(uint64_t n);
+// last_key: the key is built after everything else the context needs (a prover's Lagrange-basis key) and may take what is
+// left of the budget; the commit key (false) leaves room for what follows
+uint32_t msm_table_rows(const Ctx* c, uint64_t n, bool last_key);
+uint64_t msm_table_bytes(uint32_t rows, uint64_t n);
+// what msm_batch_device would choose for `count` sets of at most mmax terms over a key of table_rows rows / table_n points
+void msm_plan(const Ctx* c, uint32_t table_rows, uint64_t table_n, uint64_t mmax, int count, bool bit_sums, plonk_msm_plan_internal* out);
+void config_resolve(const plonk_gpu_config* user, int device, Config* out);   // capi.hip
 // tables for n points given as G1Affine (caller frees *table_out with hipFree); *rows_out = rows chosen
 int srs_table_build(Ctx* c, const G1Affine* pts_dev, uint64_t n, void** table_out, uint32_t* rows_out);
+void srs_table_release(Ctx* c, void* table, uint32_t rows, uint64_t n);   // frees a srs_table_build table and returns its bytes to the budget
 // [L_i(tau)] G for the size-n domain (n = 2^L) from the context's commit key (needs n + 2 points), followed by the
 // two blinding points [tau^n] G - G and [tau^(n+1)] G - [tau] G: n + 2 affine points (an EC inverse FFT)
 int lagrange_points_device(Ctx* c, uint32_t L, G1Affine* out_dev);

@@ -1013,7 +1013,7 @@ int poly_batch_inverse(Ctx* c, Fr* v, uint64_t n, bool twiddle_form) {
   // barrier (2^16 gates: -27 us on the critical path of round 2, 2^12: -25 us); above, 256 x 16 does 16x fewer inversions
   // (2^20: 32.81 against 33.06 ms).  Same results either way; PLONK_BI_CFG=0..3 forces one geometry (A/B runs,
   // profiles/r04/SUMMARY.md section 8).
-  static const int cfg_env = [] { const char* e = getenv("PLONK_BI_CFG"); return e ? atoi(e) : -1; }();
+  const int cfg_env = c->cfg.bi_cfg;
   const int cfg = cfg_env >= 0 && cfg_env <= 3 ? cfg_env : (n <= (1ull << 17) ? 1 : 0);
 #define BI_LAUNCH(T, E)                                                                                                              \
   do {                                                                                                                               \

@@ -288,7 +288,8 @@ static void prover_free(Prover* p) {
                   p->tparts, p->agg, p->wit, p->wit2, p->scratch, p->totals, p->evpart, p->evout, p->res, p->len_dev,
                   p->flag_dev, p->pi_idx_dev, p->pi_val_dev};
   for (void* b : bufs) if (b) (void)hipFree(b);
-  for (void* b : {(void*)p->fold, (void*)p->Fbuf, (void*)p->send, (void*)p->recv, (void*)p->agg2, (void*)p->scratch2, p->lag_table, (void*)p->wscal}) if (b) (void)hipFree(b);
+  for (void* b : {(void*)p->fold, (void*)p->Fbuf, (void*)p->send, (void*)p->recv, (void*)p->agg2, (void*)p->scratch2, (void*)p->wscal}) if (b) (void)hipFree(b);
+  srs_table_release(p->c, p->lag_table, p->lag_rows, p->lag_n);   // gives the bytes back to the context's table budget
   for (void* b : {(void*)p->wire_idx, (void*)p->wit_vals}) if (b) (void)hipFree(b);
   for (int k = 0; k < 8; ++k) { ntt_coset_free(&p->cs_fwd[k]); ntt_coset_free(&p->cs_inv[k]); }
   if (p->ev_ready) (void)hipEventDestroy(p->ev_ready);
@@ -390,8 +391,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
   while (n < d->constraints) { n <<= 1; ++L; }   // constraints.next_power_of_two() (compiler.rs:141)
   if (L + 3 >= 28) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   {
-    const char* qd = getenv("PLONK_QUOTIENT_DOMAIN");
-    const bool force8 = qd && qd[0] == '8';
+    const bool force8 = c->cfg.quotient_domain == 8;   // plonk_gpu_config.quotient_domain / PLONK_QUOTIENT_DOMAIN
     p->qf = (n >= 8 && !force8) ? 4 : 8;
     p->lq = p->qf == 4 ? 2 : 3;
   }
@@ -417,8 +417,8 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
   if (p->world > 1 && !c->nccl_comm && !d->allgather)
     return (plonk::set_last_error("invalid argument", "sharded prover needs plonk_comm_init on the context or an all-gather callback", __FILE__, __LINE__), PLONK_ERR_ARG);
   {
-    const char* sq = getenv("PLONK_SHARD_QUOTIENT");   // "0": shard only the MSMs (every rank runs the whole quotient)
-    p->sharded = (p->world == 2 || p->world == 4 || p->world == 8) && n >= 64 && !(sq && sq[0] == '0');
+    // plonk_gpu_config.shard_quotient = -1 (PLONK_SHARD_QUOTIENT=0): shard only the MSMs (every rank runs the whole quotient)
+    p->sharded = (p->world == 2 || p->world == 4 || p->world == 8) && n >= 64 && c->cfg.shard_quotient >= 0;
     if (p->sharded) {
       p->Q = p->world == 8 ? 8 : 4;
       p->cpr = p->Q / (uint32_t)p->world;
@@ -586,8 +586,8 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
     PTRY(fetch_commitments(p, 0, 15, p->vk));
   }
   {
-    const char* wc = getenv("PLONK_WIRE_COMMIT");   // "coeff": commit to the coefficient form like the reference (A/B, fallback)
-    if (p->world == 1 && !(wc && wc[0] == 'c') && c->srs_n >= n + 2 && n >= 2) {
+    // plonk_gpu_config.wire_commit = 1 (PLONK_WIRE_COMMIT=coeff): commit to the coefficient form like the reference (A/B, fallback)
+    if (p->world == 1 && !c->cfg.wire_commit_coeff && c->srs_n >= n + 2 && n >= 2) {
       if (d->lagrange_xy96 && d->lagrange_count != n + 2)
         return (plonk::set_last_error("invalid argument", "lagrange_count is not size + 2", __FILE__, __LINE__), PLONK_ERR_ARG);
       G1Affine* lag_pts = nullptr;
@@ -612,7 +612,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
         PTRY(check_lagrange_key(p, L));
       }
       HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
-    } else if (p->world > 1 && !(wc && wc[0] == 'c') && d->lagrange_xy96) {
+    } else if (p->world > 1 && !c->cfg.wire_commit_coeff && d->lagrange_xy96) {
       // multi-GPU: the rank's slice [shard_lo, shard_lo + count) of the (n + 2)-point Lagrange key, computed where the whole
       // commit key was available (plonk_lagrange_key)
       const uint64_t lhi = p->shard_lo + p->per < n + 2 ? p->shard_lo + p->per : n + 2;
@@ -736,6 +736,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
 
 static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, const Fr* pi_val, uint64_t pi_count,
                         const Fr* bl, uint8_t proof[1008]) {
+  if (p->c->comm_poisoned) return (set_last_error("context unusable", "a collective timed out and its stream never drained (comm_sync): destroy the context", __FILE__, __LINE__), PLONK_ERR_STATE);
   if (p->sharded) return prover_prove_sharded(p, wires_dev, pi_idx, pi_val, pi_count, bl, proof);
   Ctx* c = p->c;
   // the commit key of the context was replaced after this prover was built (plonk_srs_load /
@@ -792,7 +793,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // its accumulation and fill the latency-bound tail.  Same-box A/B (r02e): waiting wins up to 2^18 gates (2^16: 5.19 vs
   // 5.33 ms) and on the widget workload (38.1 vs 38.5 ms) but loses on the dense 2^20 headline (37.2-37.4 vs 36.6-36.8 ms:
   // z's transform no longer fits between its commitment and the quotient), so it follows the size.  PLONK_SIDE_DEFER=0/1 forces it.
-  static const int side_defer_env = [] { const char* e = getenv("PLONK_SIDE_DEFER"); return e ? (e[0] == '1' ? 1 : e[0] == '2' ? 2 : 0) : -1; }();
+  const int side_defer_env = c->cfg.side_defer;
   const bool side_defer = side_defer_env >= 0 ? side_defer_env >= 1 : L <= 18;          // round 1: a, b, c, d (+ PI)
   const bool side_defer_z = side_defer_env >= 0 ? side_defer_env == 1 : L <= 18;         // round 2: z ("2" = round 1 only)
   auto side_round1 = [&]() -> int {
@@ -1159,7 +1160,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   // reduction tail (W = 8 at 2^20: 1.4 of the rank's 7.7 ms were these transforms in front of the commitment).  The side
   // work starts after the group's accumulation (side_defer) while the rank's share is small; PLONK_SHARD_SIDE=0 restores
   // the round-3 order.
-  static const bool shard_side_env = [] { const char* e = getenv("PLONK_SHARD_SIDE"); return !(e && e[0] == '0'); }();
+  const bool shard_side_env = c->cfg.shard_side >= 0;   // plonk_gpu_config.shard_side_stream = -1 / PLONK_SHARD_SIDE=0 restores the round-3 order
   const uint64_t rank_pts = hi - lo;
   const bool polys_on_side = lag && shard_side_env && rank_pts <= (1ull << 18) + 64;   // (2^19 points per rank: 19.2 -> 19.4 ms, the accumulation owns the VALU)
   const bool side_defer = shard_side_env && rank_pts <= (1ull << 18) + 64;
@@ -1247,7 +1248,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     // range by the product of the ranges before it, and the z evaluations are all-gathered in place (32 n / W bytes per
     // rank; 0.5 MB per peer link at 2^20 gates and W = 8) for the one replicated step left, z's inverse transform.
     // PLONK_SHARD_Z=0 / 1 forces either (the multi-rank tests run small circuits through both).
-    static const int shard_z_env = [] { const char* e = getenv("PLONK_SHARD_Z"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const int shard_z_env = c->cfg.shard_z > 0 ? 1 : (c->cfg.shard_z < 0 ? 0 : -1);   // plonk_gpu_config.shard_grand_product / PLONK_SHARD_Z
     // rank alone, loop-back collectives (profiles/r04): W = 8 at 2^20 gates 7.41 -> 7.01 ms, at 2^22 21.9 -> 20.1; W = 2 at 2^20
     // 19.05 -> 19.27 (half of 0.5 ms of work against two more host round trips): from four ranks on
     const bool shard_z = (shard_z_env >= 0 ? shard_z_env == 1 : (L >= 19 && W >= 4)) && n % W == 0 && n / W >= 2;

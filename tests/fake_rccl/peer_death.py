@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Peer failure inside a sharded proof, on ONE GPU, through the stand-in transport (test infrastructure).
+
+  python tests/fake_rccl/peer_death.py WORLD LOG_GATES DIE_RANK DIE_AT        e.g.  2 12 1 alltoall:2
+
+Starts WORLD ranks that share device 0.  Every rank brings up a communicator on libfakerccl.so, runs the library's
+self-test (all-gather #1, all-to-all #1 of the transport), builds its shard of the bench prover and proves.  The
+stand-in makes rank DIE_RANK _exit(17) when it enters the collective DIE_AT names (`alltoall:2` = the quotient
+all-to-all of the first proof), i.e. in the middle of a proof whose other ranks are already inside — or about to enter —
+the same collective.  The survivors must come back from plonk_prover_prove_dev with PLONK_ERR_STATE after about
+PLONK_COMM_TIMEOUT_MS (comm.hip comm_sync: poll, ncclCommAbort, bounded drain) instead of hanging.
+
+The launcher prints one JSON line: {"ranks": [{"rank", "exit", "rc", "seconds", "error"} ...]}.
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl", "libfakerccl.so")
+TIMEOUT_MS = 4000
+
+
+def rank_main(rank: int, world: int, log_n: int, uid_path: str) -> int:
+    sys.path.insert(0, ROOT)
+    os.environ["PLONK_BENCH_SHARE_GPU"] = "1"
+    import bench
+    import plonk_amd
+    plonk_amd.Context.comm_set_library(FAKE)
+    if rank == 0:
+        uid = plonk_amd.Context.comm_unique_id()
+        with open(uid_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(uid_path + ".tmp", uid_path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(uid_path):
+            if time.time() - t0 > 120:
+                return 5
+            time.sleep(0.01)
+        uid = open(uid_path, "rb").read()
+    ctx = plonk_amd.Context(0)
+    ctx.comm_init(uid, rank, world)
+    ctx.comm_selftest()
+    prover, wbuf, _ = bench.build_prover(ctx, log_n, rank, world, None, "dense")
+    blinders = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % plonk_amd.Q for i in range(14)])
+    t0 = time.perf_counter()
+    out = {"rank": rank, "rc": 0, "error": ""}
+    try:
+        prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+    except plonk_amd.PlonkError as e:
+        out["rc"], out["error"] = e.code, str(e)[:300]
+    out["seconds"] = round(time.perf_counter() - t0, 2)
+    # a second proof on the context that lost its communicator must be refused at once, not hang
+    t0 = time.perf_counter()
+    try:
+        prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+        out["rc_second"] = 0
+    except plonk_amd.PlonkError as e:
+        out["rc_second"] = e.code
+    out["seconds_second"] = round(time.perf_counter() - t0, 2)
+    print("RANKJSON " + json.dumps(out), flush=True)
+    os._exit(0)   # no teardown through a communicator whose peer is gone
+
+
+def main() -> int:
+    if "PEER_DEATH_RANK" in os.environ:
+        return rank_main(int(os.environ["PEER_DEATH_RANK"]), int(sys.argv[1]), int(sys.argv[2]), os.environ["PEER_DEATH_UID"])
+    world, log_n, die_rank, die_at = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    with tempfile.TemporaryDirectory() as td:
+        uid_path = os.path.join(td, "uid")
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, PEER_DEATH_RANK=str(r), PEER_DEATH_UID=uid_path, HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       FAKE_RCCL_DIE_RANK=str(die_rank), FAKE_RCCL_DIE_AT=die_at, PLONK_COMM_TIMEOUT_MS=str(TIMEOUT_MS),
+                       FAKE_RCCL_KERNEL_TIMEOUT_S="60")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:3]], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        ranks = []
+        for r, p in enumerate(procs):
+            try:
+                so, se = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                so, se = p.communicate()
+                ranks.append({"rank": r, "exit": "timeout", "stderr": se[-600:]})
+                continue
+            rec = {"rank": r, "exit": p.returncode}
+            for line in so.splitlines():
+                if line.startswith("RANKJSON "):
+                    rec.update(json.loads(line[9:]))
+            if p.returncode not in (0, 17):
+                rec["stderr"] = se[-600:]
+            ranks.append(rec)
+    print(json.dumps({"world": world, "log_gates": log_n, "die_rank": die_rank, "die_at": die_at,
+                      "timeout_ms": TIMEOUT_MS, "ranks": ranks}))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

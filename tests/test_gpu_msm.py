@@ -39,6 +39,25 @@ def test_basic_sizes(ctx, srs300):
         assert ctx.msm(sc) == E.msm_pippenger(srs300, sc), m
 
 
+def test_basic_plan_is_the_variant_that_was_asked_for(ctx, srs300):
+    """What the library reports it ran (plonk_ctx_last_msm) against what the switches of this process ask for:
+    tests/test_gpu_msm_variants.py passes the expectation of its variant as JSON in PLONK_TEST_EXPECT_PLAN, so a switch
+    that is silently ignored fails here instead of re-testing the default kernels.  Without the variable: the defaults of a
+    300-point key (window rows, 2^15 buckets, 4-entry slices, unordered lanes, a quad per bucket sum)."""
+    import json
+    import os
+    ctx.srs_load(srs300)
+    sc = [random.Random(5).randrange(Q) for _ in range(300)]
+    assert ctx.msm(sc) == E.msm_pippenger(srs300, sc)
+    plan = ctx.last_msm()
+    want = json.loads(os.environ.get("PLONK_TEST_EXPECT_PLAN") or
+                      '{"table_rows": 16, "bucket_bits": 15, "digit_width": 16, "slice_entries": 4, "ordered_lanes": 0, '
+                      '"flags": 0, "accumulate_kernel": "nb15::msm_accumulate_kernel"}')
+    assert {k: plan[k] for k in want} == want, plan
+    assert plan["terms"] == 300 and ctx.describe_msm(300) == plan     # the prediction is the same function
+    assert ctx.table_rows() == plan["table_rows"]
+
+
 def test_edge_scalars(ctx, srs300):
     """Digit-recoding boundaries (16-bit signed windows), 0, 1, q-1."""
     ctx.srs_load(srs300)

@@ -16,21 +16,32 @@ def run_variant(env_extra, select=SELECT, marker="gpu", target="tests/test_gpu_m
                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
+# (switches, what plonk_ctx_last_msm must report for a 300-term MSM under them): the child's
+# test_basic_plan_is_the_variant_that_was_asked_for compares — a switch the library ignores fails there
+K15, K15O, K15L = "nb15::msm_accumulate_kernel", "nb15::msm_accumulate_ordered_kernel", "nb15::msm_accumulate_lds_kernel"
+KL, KLO = "nbl::msm_accumulate_kernel", "nbl::msm_accumulate_ordered_kernel"
+VARIANTS = [
+    ({"PLONK_MSM_ORDER": "1"}, {"ordered_lanes": 1, "accumulate_kernel": K15O}),     # lanes of msm_accumulate in order of slice length
+    ({"PLONK_MSM_ACC": "lds"}, {"flags": 4, "accumulate_kernel": K15L}),             # three waves per SIMD, table entries prefetched into LDS
+    ({"PLONK_MSM_TAIL": "serial"}, {"flags": 1 | 2, "accumulate_kernel": K15}),      # one lane per addition in the reduction tail
+    ({"PLONK_MSM_TABLE": "window"}, {"table_rows": 16, "digit_width": 16, "bucket_bits": 15}),   # 16 window rows, signed 16-bit windows (the default below 2^18 points)
+    ({"PLONK_MSM_TABLE": "bitpos"}, {"table_rows": 256, "digit_width": 17, "bucket_bits": 15, "accumulate_kernel": K15}),   # a row per bit position, width-17 NAF digits
+    ({"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"},                        # width-21 NAF digits over 2^19 buckets (the default above 2^18 terms)
+     {"table_rows": 256, "digit_width": 21, "bucket_bits": 19, "slice_entries": 32, "ordered_lanes": 1, "accumulate_kernel": KLO}),
+    ({"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_ORDER": "0"},
+     {"table_rows": 256, "bucket_bits": 19, "ordered_lanes": 0, "accumulate_kernel": KL}),
+    ({"PLONK_MSM_BSUM": "lane"}, {"flags": 2, "accumulate_kernel": K15}),            # one lane per bucket in msm_bucket_sum instead of a quad (small MSMs)
+    ({"PLONK_MSM_TABLE": "halfpos"}, {"table_rows": 128, "digit_width": 16, "bucket_bits": 15}),   # round 4: a row for every second bit position, even-position digits
+    ({"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},                       # ... width-20 digits over 2^19 buckets (keys whose 256 rows do not fit)
+     {"table_rows": 128, "digit_width": 20, "bucket_bits": 19, "accumulate_kernel": KLO}),
+]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [
-    {"PLONK_MSM_ORDER": "1"},      # lanes of msm_accumulate in order of slice length
-    {"PLONK_MSM_ACC": "lds"},      # three waves per SIMD, table entries prefetched into LDS
-    {"PLONK_MSM_TAIL": "serial"},  # one lane per addition in the reduction tail
-    {"PLONK_MSM_TABLE": "window"},                               # 16 window rows, signed 16-bit windows (the default below 2^17 points)
-    {"PLONK_MSM_TABLE": "bitpos"},                               # a table row per bit position, width-17 NAF digits, 2^15 buckets
-    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"},    # width-21 NAF digits over 2^19 buckets (the default above 2^19 terms)
-    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_ORDER": "0"},
-    {"PLONK_MSM_BSUM": "lane"},    # one lane per bucket in msm_bucket_sum instead of a quad (small MSMs)
-    {"PLONK_MSM_TABLE": "halfpos"},                              # round 4: a table row for every second bit position, width-16 even-position digits
-    {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},   # ... width-20 digits over 2^19 buckets (keys whose 256 rows do not fit)
-], ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
-def test_variant_matches_the_oracle_on_the_edge_cases(variant):
-    r = run_variant(variant)
+@pytest.mark.parametrize("variant,plan", VARIANTS, ids=[",".join(f"{k}={x}" for k, x in v.items()) for v, _ in VARIANTS])
+def test_variant_matches_the_oracle_on_the_edge_cases(variant, plan):
+    import json
+    r = run_variant(dict(variant, PLONK_TEST_EXPECT_PLAN=json.dumps(plan)))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 
