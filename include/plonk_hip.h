@@ -250,6 +250,20 @@ void plonk_prover_destroy(plonk_prover* p);
  * Error::UnsupportedProvingVersion in the reference).  Applies to the proofs made after the call. */
 int plonk_prover_set_version(plonk_prover* p, int version);
 int plonk_prover_vk(plonk_prover* p, uint8_t out[15 * 48]);
+/* What the prover was BUILT as — the configuration of its context at plonk_prover_create / plonk_compile, resolved: tests assert
+ * it so that a configuration switch the library ignores cannot pass for the variant it names. */
+typedef struct plonk_prover_info {
+  uint64_t size;                 /* domain size n */
+  uint32_t quotient_domain;      /* 4: quotient interpolated on the 4n coset and de-aliased; 8: the reference's 8n evaluation */
+  uint32_t wire_commit_values;   /* 1: wire commitments from the wire VALUES over a Lagrange-basis key; 0: coefficient form */
+  uint32_t lagrange_table_rows;  /* rows of that key's tables (16 / 128 / 256), 0 without one */
+  uint32_t shard_world, shard_rank;
+  uint32_t sharded_quotient;     /* 1: quotient by residue class, rounds 4-5 by coefficient range; 0: only the MSMs are sharded */
+  uint32_t quotient_classes;     /* Q: 4, or 8 for eight ranks (0 when the quotient is not sharded) */
+  uint32_t reserved;
+  uint64_t lagrange_points;      /* points of the Lagrange-basis key (or of this rank's slice) */
+} plonk_prover_info;
+int plonk_prover_describe(plonk_prover* p, plonk_prover_info* out);
 uint64_t plonk_prover_size(plonk_prover* p);
 /* diagnostic: read `count` Fr at `offset` of internal array `which` (0 wire polys, 1 z poly,
  * 2 pi poly, 3 coset evals z|a|b|c|d|pi, 4 quotient, 5 t_low|t_mid|t_high, 6 lin. comb., 7 opening

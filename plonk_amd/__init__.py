@@ -54,7 +54,7 @@ EXPORTS = [
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_info", "plonk_comm_selftest", "plonk_comm_destroy",
     "plonk_comm_measure_loopback", "plonk_prover_set_version", "plonk_comm_set_library", "plonk_comm_library",
     "plonk_ctx_create_ex", "plonk_ctx_get_config", "plonk_ctx_set_config", "plonk_ctx_describe_msm", "plonk_ctx_last_msm",
-    "plonk_ctx_table_bytes",
+    "plonk_ctx_table_bytes", "plonk_prover_describe",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
     "plonk_compile", "plonk_prover_prove_witnesses", "plonk_prover_to_bytes", "plonk_verifier_to_bytes",
     "plonk_public_parameters_check", "plonk_srs_load_public_parameters",
@@ -93,6 +93,13 @@ class _MsmPlan(ctypes.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["accumulate_kernel"] = d["accumulate_kernel"].decode()
         return d
+
+
+class _ProverInfo(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_uint64), ("quotient_domain", ctypes.c_uint32), ("wire_commit_values", ctypes.c_uint32),
+                ("lagrange_table_rows", ctypes.c_uint32), ("shard_world", ctypes.c_uint32), ("shard_rank", ctypes.c_uint32),
+                ("sharded_quotient", ctypes.c_uint32), ("quotient_classes", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("lagrange_points", ctypes.c_uint64)]
 
 
 class _ProverDesc(ctypes.Structure):
@@ -234,6 +241,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_ctx_describe_msm.argtypes = [vp, u64, ci, ci, u32, u64, ctypes.POINTER(_MsmPlan)]
     lib.plonk_ctx_last_msm.argtypes = [vp, ctypes.POINTER(_MsmPlan)]
     lib.plonk_ctx_table_bytes.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.plonk_prover_describe.argtypes = [vp, ctypes.POINTER(_ProverInfo)]
     lib.plonk_comm_set_library.argtypes = [ctypes.c_char_p]
     lib.plonk_comm_library.argtypes = [vp, u64]
     lib.plonk_prover_set_version.argtypes = [vp, ci]
@@ -636,6 +644,12 @@ class Prover:
         ctx._provers.add(self)
         self.size = ctx.lib.plonk_prover_size(h)
         self._keep = None
+
+    def describe(self) -> dict:
+        """what the prover was built as (plonk_prover_describe): quotient domain, wire-commitment mode, sharding"""
+        info = _ProverInfo()
+        self.ctx._check(self.ctx.lib.plonk_prover_describe(self.handle, ctypes.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_ if k != "reserved"}
 
     @classmethod
     def from_bytes(cls, ctx: Context, blob: bytes) -> "Prover":

@@ -322,11 +322,14 @@ int plonk_ctx_set_config(plonk_ctx* ctx, const plonk_gpu_config* config) {
 }
 
 int plonk_ctx_table_bytes(plonk_ctx* ctx, uint64_t* in_use, uint64_t* budget) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   if (in_use) *in_use = ctx->c.table_bytes;
   if (budget) *budget = ctx->c.cfg.table_budget;
   return PLONK_OK;
+  });
 }
 
 static void plan_out(const plonk_msm_plan_internal& p, plonk_msm_plan* out) {
@@ -352,11 +355,14 @@ int plonk_ctx_describe_msm(plonk_ctx* ctx, uint64_t m, int count, int bit_sum_ta
 }
 
 int plonk_ctx_last_msm(plonk_ctx* ctx, plonk_msm_plan* out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !out) return PLONK_ERR_ARG;
   std::lock_guard<std::mutex> lk(ctx->c.mu);
   if (!ctx->c.last_plan.table_rows) return (set_last_error("plonk_ctx_last_msm", "no MSM has run on this context", __FILE__, __LINE__), PLONK_ERR_STATE);
   plan_out(ctx->c.last_plan, out);
   return PLONK_OK;
+  });
 }
 
 void plonk_ctx_destroy(plonk_ctx* ctx) {

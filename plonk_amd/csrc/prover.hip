@@ -1634,6 +1634,26 @@ int plonk_prover_vk(plonk_prover* pr, uint8_t out[15 * 48]) {
 
 uint64_t plonk_prover_size(plonk_prover* pr) { return pr ? pr->p->n : 0; }
 
+int plonk_prover_describe(plonk_prover* pr, plonk_prover_info* out) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!pr || !out) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  const plonk::Prover* p = pr->p;
+  memset(out, 0, sizeof(*out));
+  out->size = p->n;
+  out->quotient_domain = p->qf;
+  out->wire_commit_values = p->lag_table ? 1u : 0u;
+  out->lagrange_table_rows = p->lag_table ? p->lag_rows : 0u;
+  out->lagrange_points = p->lag_table ? p->lag_n : 0u;
+  out->shard_world = (uint32_t)(p->world > 1 ? p->world : 1);
+  out->shard_rank = (uint32_t)p->rank;
+  out->sharded_quotient = p->sharded ? 1u : 0u;
+  out->quotient_classes = p->sharded ? p->Q : 0u;
+  return PLONK_OK;
+  });
+}
+
 // Test/diagnostic hook: copy `count` Fr starting at `offset` of an internal device array.
 int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t count, uint64_t* out) {
   const char* const api_fn = __func__;

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: longer CPU oracle case")
 
 
+def configure(ctx, **fields):
+    """plonk_ctx_set_config on top of the context's effective configuration (the library no longer reads switches from the
+    environment after a context exists: tests that used monkeypatch.setenv on a live context now say what they mean)"""
+    g = ctx.get_config()
+    for k, v in fields.items():
+        assert hasattr(g, k), k
+        setattr(g, k, v)
+    ctx.set_config(g)
+
+
 @pytest.fixture(scope="session")
 def kat_setup():
     """SRS + compiled MinimalCircuit of the reference KAT (prover.rs:1132-1147)."""

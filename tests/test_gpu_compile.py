@@ -37,10 +37,8 @@ def compiled(ctx, comp, label, **kw):
 @pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
 def test_kat_circuit_compiled_on_the_device(ctx, kat_setup, monkeypatch, domain):
     import plonk_amd
-    if domain == "quotient-8n":
-        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
-    else:
-        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    from conftest import configure
+    configure(ctx, quotient_domain=8 if domain == "quotient-8n" else 4)
     _, oprover, circuit = kat_setup
     ctx.srs_load(oprover.ck)
     comp = circuit()

@@ -49,10 +49,10 @@ def test_same_budget_same_layout_whatever_the_neighbours_hold():
     """Round 4 chose a key's rows from hipMemGetInfo's "free right now": a second context on the device saw less free memory and
     silently took another layout.  The rule now reads the context's budget and its own tables only."""
     import plonk_amd
-    big = plonk_amd.GpuConfig(table_budget_bytes=16 << 30)      # bit-position rows of the key (8.6 GB) are within 60 % of it
+    big = plonk_amd.GpuConfig(table_budget_bytes=24 << 30)      # bit-position rows of the key (8.6 GB + 3.2 GB of build scratch) are within 60 % of it
     a = plonk_amd.Context(0, big)
     _load_key(a)
-    assert a.table_rows() == 256 and a.table_bytes() == (BITPOS_BYTES, 16 << 30)
+    assert a.table_rows() == 256 and a.table_bytes() == (BITPOS_BYTES, 24 << 30)
     ballast = a.alloc(150 << 30)                                # a neighbour that takes most of the device
     b = plonk_amd.Context(0, big)
     _load_key(b)

@@ -14,6 +14,7 @@ import hashlib
 
 import pytest
 
+from conftest import configure
 from oracle import cbind
 from tests import circuits as C
 
@@ -43,11 +44,16 @@ def case_for(log_n):
     return _cases[log_n]
 
 
-def gpu_proof(ctx, case, srs, blinders_mont, vk=None):
+def gpu_proof(ctx, case, srs, blinders_mont, vk=None, expect=None):
+    """expect: fields of plonk_prover_describe the prover must report (the switch under test was honoured)"""
     import plonk_amd
     ctx.srs_load_bytes(srs, len(srs) // 96)
     gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], vk)
     try:
+        info = gp.describe()
+        assert info["quotient_domain"] == ctx.get_config().quotient_domain
+        for k, v in (expect or {}).items():
+            assert info[k] == v, (k, info)
         got_vk = gp.vk_commitments()
         wbuf = ctx.alloc(4 * 32 * case["size"])
         for k in range(4):
@@ -62,10 +68,7 @@ def gpu_proof(ctx, case, srs, blinders_mont, vk=None):
 @pytest.mark.parametrize("domain", ["quotient-4n", "quotient-8n"])
 @pytest.mark.parametrize("log_n", [12, 13, 16])
 def test_proof_bytes_equal_c_oracle(ctx, monkeypatch, log_n, domain):
-    if domain == "quotient-8n":
-        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
-    else:
-        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    configure(ctx, quotient_domain=8 if domain == "quotient-8n" else 4, wire_commit=0)
     case, srs, cp = case_for(log_n)
     for name in ("q_range", "q_logic", "q_fixed_group_add", "q_variable_group_add"):
         assert case["polys"][name], name          # every selector family is active
@@ -81,10 +84,7 @@ def test_unsatisfied_witness_is_circuit_unsatisfied_exactly(ctx, monkeypatch, do
     """reference quotient_poly.rs:132 returns Error::CircuitUnsatisfied and nothing else; the shim maps
     PLONK_ERR_UNSAT to it.  One corrupted wire value in a widget row and one in an arithmetic row."""
     import plonk_amd
-    if domain == "quotient-8n":
-        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
-    else:
-        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    configure(ctx, quotient_domain=8 if domain == "quotient-8n" else 4, wire_commit=0)
     case, srs, cp = case_for(12)
     ctx.srs_load_bytes(srs, len(srs) // 96)
     gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], cp.vk())
@@ -119,8 +119,7 @@ def test_side_workloads_equal_c_oracle_2p20(ctx, monkeypatch, profile):
     digits of a real witness; `prove_ms_all_widgets_pi`: every widget family + public inputs): the whole proof against the
     C oracle at the size that is timed, not only at 2^13 / 2^17."""
     import bench_circuits as BC
-    monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
-    monkeypatch.delenv("PLONK_WIRE_COMMIT", raising=False)
+    configure(ctx, quotient_domain=4, wire_commit=0)
     log_n = 20
     n = 1 << log_n
     _cases.clear()
@@ -153,10 +152,7 @@ def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     whole 1008-byte proof against the C oracle run on the host cores (about a minute)."""
     import bench
     import plonk_amd
-    if domain == "quotient-8n":
-        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
-    else:
-        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    configure(ctx, quotient_domain=8 if domain == "quotient-8n" else 4, wire_commit=0)
     log_n = 20
     n = 1 << log_n
     key = ("bench", log_n)
@@ -186,7 +182,7 @@ def test_proof_bytes_equal_c_oracle_at_the_layout_crossover(ctx, monkeypatch, lo
     per bucket; 2^19 gates run bit-position rows and 2^19 buckets with ~12 entries per bucket.  bench.py's dense circuit, the
     whole proof against the C oracle."""
     import bench
-    monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    configure(ctx, quotient_domain=4, wire_commit=0)
     n = 1 << log_n
     _cases.clear()
     wires, cols, trivial = bench.synth_circuit(log_n)
@@ -211,7 +207,7 @@ def test_wire_commitment_modes_agree_with_each_other_and_the_oracle(ctx, monkeyp
     must reproduce the C oracle's proof bytes on bench.py's workloads, including the skewed `bench-like` witness."""
     import bench_circuits as BC
     import plonk_amd
-    monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    configure(ctx, quotient_domain=4, wire_commit=0)
     n = 1 << log_n
     if profile == "widgets":
         wires, cols, pi = BC.widget_circuit(log_n)
@@ -231,9 +227,9 @@ def test_wire_commitment_modes_agree_with_each_other_and_the_oracle(ctx, monkeyp
     expected = cp.prove(wires, idx, case["pi_val"], bl)
     want_vk = cp.vk()
     cp.close()
-    monkeypatch.delenv("PLONK_WIRE_COMMIT", raising=False)
-    lag, vk = gpu_proof(ctx, case, srs, bl)
-    monkeypatch.setenv("PLONK_WIRE_COMMIT", "coeff")
-    coeff, vk2 = gpu_proof(ctx, case, srs, bl)
+    lag, vk = gpu_proof(ctx, case, srs, bl, expect={"wire_commit_values": 1})
+    configure(ctx, wire_commit=1)
+    coeff, vk2 = gpu_proof(ctx, case, srs, bl, expect={"wire_commit_values": 0})
+    configure(ctx, wire_commit=0)
     assert vk == vk2 == want_vk
     assert lag == expected and coeff == expected

@@ -33,7 +33,9 @@ def gpu_prover(ctx, oprover, vk=False):
     vkb = None
     if vk:
         vkb = b"".join(E.g1_compress(oprover.vk[name]) for name in plonk_amd.POLY_ORDER)
-    return plonk_amd.Prover(ctx, oprover.constraints, oprover.label, oprover.pk.polys, vkb)
+    p = plonk_amd.Prover(ctx, oprover.constraints, oprover.label, oprover.pk.polys, vkb)
+    assert p.describe()["quotient_domain"] == (ctx.get_config().quotient_domain if p.size >= 8 else 8)   # the switch was honoured
+    return p
 
 
 def wires_of(composer, size):
@@ -65,13 +67,13 @@ def ctx():
 
 
 @pytest.fixture(autouse=True, params=["quotient-4n", "quotient-8n"])
-def quotient_domain(request, monkeypatch):
+def quotient_domain(request, ctx):
     """Every test runs on both quotient domains: the default 4n (+ de-aliasing by the low
-    coefficients, prover.hip quotient_low) and the reference-shaped 8n (quotient_poly.rs:96-137)."""
-    if request.param == "quotient-8n":
-        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
-    else:
-        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
+    coefficients, prover.hip quotient_low) and the reference-shaped 8n (quotient_poly.rs:96-137) —
+    plonk_gpu_config.quotient_domain of the module's context (provers built afterwards follow it;
+    gpu_prover asserts that they did)."""
+    from conftest import configure
+    configure(ctx, quotient_domain=8 if request.param == "quotient-8n" else 4)
     return request.param
 
 

@@ -52,17 +52,14 @@ def test_oracle_accepts_semantic_witnesses_and_rejects_corrupted_ones():
 def test_hip_prover_bit_exact_on_semantic_widget_circuits(monkeypatch, domain, seed):
     import plonk_amd
     from test_gpu_prover import FixedBlinders, wires_of
-    if domain == "quotient-8n":
-        monkeypatch.setenv("PLONK_QUOTIENT_DOMAIN", "8")
-    else:
-        monkeypatch.delenv("PLONK_QUOTIENT_DOMAIN", raising=False)
     build, prover, pp, tau = _setup(seed)
     rec = FixedBlinders(StdRng.seed_from_u64(100 + seed))
     comp = build()
     expected, _ = O.prove(prover, rec, comp, msm=E.msm_pippenger)
-    ctx = plonk_amd.Context(0)
+    ctx = plonk_amd.Context(0, plonk_amd.GpuConfig(quotient_domain=8 if domain == "quotient-8n" else 4))
     ctx.srs_load(prover.ck)
     gp = plonk_amd.Prover(ctx, prover.constraints, prover.label, prover.pk.polys)
+    assert gp.describe()["quotient_domain"] == (8 if domain == "quotient-8n" else 4)
     got = gp.prove(wires_of(comp, prover.size), dict(comp.public_inputs), rec.drawn)
     assert got == expected
     # a corrupted quad inside the logic gadget must be refused by the device prover as well
