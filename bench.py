@@ -91,7 +91,10 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
         full.free()
         key = ctx.lagrange_key(log_n)
         llo, lhi = min(lo, n + 2), min(hi, n + 2)
-        lag_slice = key[96 * llo:96 * lhi]
+        # PLONK_BENCH_WIRE_SPLIT=commitment (2 / 4 ranks): every rank takes the WHOLE Lagrange-basis key and commits to whole
+        # wire columns instead of a point range of every column (prover.hip lag_whole)
+        build_prover.wire_split = "commitment" if (world in (2, 4) and os.environ.get("PLONK_BENCH_WIRE_SPLIT", "range") == "commitment") else "range"
+        lag_slice = key if build_prover.wire_split == "commitment" else key[96 * llo:96 * lhi]
         del key
     # the rank's slice of the commit key is produced once (on the device: the reference's setup is O(n * 255)
     # group operations), parked in PINNED HOST memory like a key read from disk, and then STREAMED into the
@@ -311,6 +314,87 @@ def ntt_roofline(ctx, log_n, qd8):
                     "MSM pipeline use the 8-elements-per-lane kernels (DESIGN.md 4.1)", "transforms": out}
 
 
+def micro_scalars(m: int, profile: str, seed: int) -> bytes:
+    """m scalars as Montgomery limb bytes: `uniform` (below 2^254, i.e. uniform field elements for every purpose of an MSM) or
+    `bench-like` (half of the values < 4 — Montgomery forms of 0 .. 3 — half uniform)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(m, 32), dtype=np.uint8)
+    a[:, 31] &= 0x3F
+    if profile == "bench-like":
+        table = np.array([list(int.to_bytes(v * (1 << 256) % Q, 32, "little")) for v in range(4)], dtype=np.uint8)
+        small = rng.random(m) < 0.5
+        a[small] = table[rng.integers(0, 4, size=m)[small]]
+    return a.tobytes()
+
+
+def msm_micro_rows(ctx, log_m: int, reps: int = 3):
+    """SURVEY 8(d) "MSM micro": m = 2^log_m + 6 scalars against the commit key the context holds, batches of 1 and 4 over the
+    same bases, `uniform` and `bench-like` scalars.  Called through plonk_msm_batch on pinned host scalars; `device_ms` is the
+    time of the MSM kernels between hipEvents on the library's stream (slots 1 + 2: sort, accumulation, reduction — no PCIe),
+    `wall_ms` the whole call (scalar upload and the host's finish of the bit sums included)."""
+    import ctypes
+    m = (1 << log_m) + 6
+    lib, h, vp = ctx.lib, ctx.handle, ctypes.c_void_p
+    rows = []
+    for prof in ("uniform", "bench-like"):
+        bufs = [plonk_amd.PinnedBuffer(32 * m) for _ in range(4)]
+        for k, b in enumerate(bufs):
+            b.write(micro_scalars(m, prof, 0x5EED0100 + 16 * log_m + k))
+        arr = (vp * 4)(*[vp(b.ptr) for b in bufs])
+        ms = (ctypes.c_uint64 * 4)(*[m] * 4)
+        res = ctypes.create_string_buffer(4 * 97)
+        for batch in (1, 4):
+            ctx._check(lib.plonk_msm_batch(h, arr, ms, batch, res))      # warm-up: work buffers, staging
+            ctx.profile(True)
+            ctx.profile_reset()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx._check(lib.plonk_msm_batch(h, arr, ms, batch, res))
+            wall = (time.perf_counter() - t0) * 1e3 / reps
+            acc, _ = ctx.profile_read(1)
+            oth, _ = ctx.profile_read(2)
+            ctx.profile(False)
+            plan = ctx.last_msm()
+            dev = (acc + oth) / reps
+            rows.append({"m": m, "batch": batch, "scalars": prof, "device_ms": round(dev, 3), "accumulate_ms": round(acc / reps, 3),
+                         "wall_ms_pinned_host_scalars": round(wall, 3), "mscalar_per_s": round(batch * m / max(dev, 1e-9) / 1e3, 1),
+                         "algorithmic_gb_per_s": round((32 * batch + 96) * m / max(dev, 1e-9) / 1e6, 1),
+                         "kernel": plan["accumulate_kernel"], "table_rows": plan["table_rows"], "bucket_bits": plan["bucket_bits"],
+                         "digit_width": plan["digit_width"]})
+        for b in bufs:
+            b.free()
+    return rows
+
+
+def ntt_micro(ctx):
+    """SURVEY 8(d) "NTT micro": N = 2^12 .. 2^25, forward / inverse / coset-forward, device-resident, wall clock around back-to-back
+    launches (timing does not depend on the data).  Algorithmic bytes 64 N per transform."""
+    rows = []
+    for L in (12, 16, 20, 22, 23, 25):
+        N = 1 << L
+        src, dst, tmp = ctx.alloc(32 * N), ctx.alloc(32 * N), ctx.alloc(32 * N)
+        src.upload(bytes(32 * min(N, 1 << 16)))
+        for name, inv, coset in (("forward", False, False), ("inverse", True, False), ("coset_forward", False, True)):
+            ctx.ntt_dev(src.ptr, dst.ptr, tmp.ptr, L, inv, coset, N)
+            ctx.sync()
+            iters = 20 if L <= 20 else (8 if L <= 23 else 4)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                ctx.ntt_dev(src.ptr, dst.ptr, tmp.ptr, L, inv, coset, N)
+            ctx.sync()
+            ms = (time.perf_counter() - t0) * 1e3 / iters
+            npass = 1 if L <= 10 else (2 if L <= 18 else 3)
+            issue = valu_issue((N // 2 * L * 290 + N * (npass - 1) * 150) / 64, ms)
+            rows.append({"log_size": L, "transform": name, "ms": round(ms, 4), "melem_per_s": round(N / ms / 1e3, 1),
+                         "hbm_gb_per_s": round(64 * N / ms / 1e6, 1), "hbm_frac": round(64 * N / ms / 1e6 / HBM_PEAK_GBS, 4),
+                         "valu_issue_frac": issue["frac"], "passes": npass})
+        for b in (src, dst, tmp):
+            b.free()
+    return rows
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -319,6 +403,20 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def cpu_baseline_small(ctx, log_n: int, blinders):
+    """The same port at another size north_star names (2^16, 2^12): one whole prove() on the host cores, and the SAME circuit,
+    key and blinders proved on the GPU for the byte comparison."""
+    dg = {}
+    prover, wbuf, _ = build_prover(ctx, log_n, 0, 1, None, "dense")
+    gpu_proof = prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+    vk48 = prover.vk_commitments()
+    prover.close()
+    wbuf.free()
+    rec, cpu_proof = cpu_baseline(log_n, vk48)
+    rec["proof_matches_gpu"] = bool(cpu_proof == gpu_proof)
+    return rec
 
 
 def cpu_baseline(log_n: int, vk48: bytes):
@@ -613,7 +711,8 @@ def main():
                               (" — per rank: the coset transforms as size-n transforms on its residue classes" if world in (2, 4, 8) else ""),
                        "msm": "11 x ~n terms",
                        "parallelism": ("1 GPU" if world == 1 else
-                                       "x%d: MSM by SRS point range; quotient by coset residue class; rounds 4-5 by coefficient range" % world
+                                       ("x%d: MSM by SRS point range%s; quotient by coset residue class; rounds 4-5 by coefficient range" % (
+                                           world, " (wire commitments by whole column)" if getattr(build_prover, "wire_split", "") == "commitment" else ""))
                                        if world in (2, 4, 8) else "x%d: MSM by SRS point range" % world),
                        "srs": "rank's point range streamed from pinned host memory in 2^18-point chunks (upload of chunk k+1 under "
                               "the window-table build of chunk k): %d points in %.2f s" % (min(per, srs_total), build_prover.srs_stream_s),
@@ -642,8 +741,12 @@ def main():
                    "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
                    "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
                    "launch_groups_per_prove": list(groups),
-                   "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound; `traffic` (PMC, HBM bytes per launch) is one "
-                           "128-B table gather per non-zero digit by design; see DESIGN.md"}),
+                   "frac_vs_guide_valu_rate": round(valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"] / 2, 4),
+                   "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound.  `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles: the "
+                           "MEASURED issue class of v_mad_u64_u32 and the carry adds around it (4.4-4.9 cycles per wave-instruction, "
+                           "profiles/r01/valu_issue_rates_gfx950.txt) — not the guide's generic VALU rate of one wave-instruction per 2 cycles, "
+                           "against which the same kernel is at `frac_vs_guide_valu_rate`.  `traffic` (PMC, HBM bytes per launch) is one "
+                           "128-B table gather per non-zero digit by design; see DESIGN.md 4.2 / 6"}),
             # the pass of a proof that comes closest to HBM: quotient_kernel over the quotient-domain points
             "roofline_quotient": quotient_roofline(prover, n, 8 if qd8 else 4, bool(pi), args.profile, q_ms / max(q_n, 1)),
             "kernel_ms_per_prove": {"msm_accumulate": round(acc_ms / args.steps, 3),
@@ -676,6 +779,9 @@ def main():
                    # profiles/r03b/ntt_batch_overlap_bisect.txt — variant C = prover.close() before the call)
                 out["roofline_ntt"] = ntt_roofline(ctx, log_n, qd8)
                 out["leaf_ms"] = leaf_costs(ctx, log_n)
+                out["ntt_micro"] = ntt_micro(ctx)
+                if log_n >= 16:   # SURVEY 8(d) MSM micro rows at this size (the context still holds the timed run's commit key)
+                    out["msm_micro"] = msm_micro_rows(ctx, log_n)
             except Exception as e:   # noqa: BLE001
                 out["leaf_error"] = repr(e)
         prover.close()
@@ -691,6 +797,12 @@ def main():
                         dg = {}
                         out["prove_ms_2p%d" % lg] = time_profile(ctx, lg, "dense", reps, blinders, dg)
                         out["proof_blake2b_2p%d" % lg] = dg.get("proof_blake2b")
+                if log_n != 16:   # MSM micro at 2^16 + 6 terms: a key of that size (window rows, 2^15 buckets)
+                    pts = ctx.alloc(96 * ((1 << 16) + 7))
+                    ctx.srs_generate_dev(TAU, G_SCALAR, (1 << 16) + 7, pts.ptr)
+                    ctx.srs_load_dev(pts.ptr, (1 << 16) + 7)
+                    pts.free()
+                    out["msm_micro"] = msm_micro_rows(ctx, 16, 10) + out.get("msm_micro", [])
                 out["compile"] = compile_costs(ctx, log_n if log_n <= 20 else 20, blinders)
                 if log_n <= 20:   # same circuit, key and blinders as the timed run, built the other way
                     out["compile"]["proof_matches_timed_run"] = bool(out["compile"]["proof_blake2b"] == out["proof_blake2b"])
@@ -702,6 +814,7 @@ def main():
                 dg = {}
                 out["prove_ms_2p22"] = time_profile(ctx, 22, "dense", 3, blinders, dg)
                 out["proof_blake2b_2p22"] = dg.get("proof_blake2b")
+                out["msm_micro"] = out.get("msm_micro", []) + msm_micro_rows(ctx, 22, 2)   # the 2^22 + 7-point key is still loaded
                 out["prove_2p22_setup_and_run_s"] = round(time.perf_counter() - t22, 1)
             except Exception as e:   # noqa: BLE001
                 out["prove_2p22_error"] = repr(e)
@@ -714,6 +827,10 @@ def main():
                 out["cpu_baseline"], cpu_proof = cpu_baseline(log_n, vk48)
                 if log_n <= 20:   # same SRS, circuit, witness and blinders: the CPU port must produce the same bytes
                     out["cpu_baseline"]["proof_matches_gpu"] = bool(cpu_proof == proof)
+                if not args.no_extras:   # north_star: "prove-time at 2^16 .. 2^22 ... next to the CPU path": the port at the small sizes too
+                    for lg in (16, 12):
+                        if lg != log_n:
+                            out["cpu_baseline_2p%d" % lg] = cpu_baseline_small(ctx, lg, blinders)
             except Exception as e:  # the baseline is a report, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "ms", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         json_out.write(json.dumps(out) + "\n")

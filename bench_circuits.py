@@ -87,7 +87,41 @@ def _arith_chunk(args):
     return [_bytes(col) for col in (a, b, c, d, qm, ql, qr, qf, qc)]
 
 
+def _cached(kind: str, log_n: int, profile: str, make):
+    """PLONK_CIRCUIT_CACHE=<directory> (the test suite sets it): the generated circuit of (kind, size, profile) is written
+    once and re-read by every later caller — the same deterministic bytes either way.  A 2^20-gate circuit is ~12 s of
+    pure-Python big-integer work and a GPU test session used to regenerate it a dozen times (every rank of every
+    multi-rank child included); generation is serialised by a file lock so that eight ranks starting together produce it
+    once.  Nothing is cached below 2^15 gates or without the variable (bench.py as the driver runs it)."""
+    import os
+    root = os.environ.get("PLONK_CIRCUIT_CACHE")
+    if not root or log_n < 15:
+        return make()
+    import fcntl
+    import pickle
+    os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, f"{kind}_{profile}_2p{log_n}_v1.pkl")
+    with open(path + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(path):
+                with open(path, "rb") as f:
+                    return pickle.load(f)
+            out = make()
+            tmp = path + f".tmp{os.getpid()}"
+            with open(tmp, "wb") as f:
+                pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
+            os.replace(tmp, path)
+            return out
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 def arithmetic_circuit(log_n: int, profile: str = "dense", workers: int = 0):
+    return _cached("arith", log_n, profile, lambda: _arithmetic_circuit(log_n, profile, workers))
+
+
+def _arithmetic_circuit(log_n: int, profile: str = "dense", workers: int = 0):
     """Chains of arithmetic gates: the output of gate i is wired to input a of gate i + 1 (sigma_1, sigma_3
     non-trivial), q_O = -1, q_arith = 1.  `dense`: random selectors, the output follows.  `bench-like`: the
     wire values are drawn first (half of them < 4), q_C is solved for so that each gate holds.
@@ -278,6 +312,12 @@ def _widget_layout(log_n, blk_log, pool):
 
 
 def widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
+    if blk_log == 8 and pool == 64:
+        return _cached("widget", log_n, "widgets", lambda: _widget_circuit(log_n, blk_log, pool))
+    return _widget_circuit(log_n, blk_log, pool)
+
+
+def _widget_circuit(log_n: int, blk_log: int = 8, pool: int = 64):
     """n = 2^log_n rows: tiles of 2^blk_log rows drawn at random from a pool of `pool` different blocks (different
     witnesses), so no column is periodic and every polynomial is dense.  Position (column, row) of a tile is
     copy-constrained to the same position of the next tile built from the same block (equal values by

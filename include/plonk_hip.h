@@ -98,7 +98,8 @@ typedef struct plonk_gpu_config {
   int32_t shard_side_stream;     /* multi-GPU: 0 / 1 = replicated transforms on the side stream under the commitments, -1 = off */
   int32_t ntt_elements_log2;     /* 0 = default (2: four elements per lane; side-stream transforms under a busy MSM: 3), 2, 3 */
   int32_t comm_timeout_ms;       /* 0 = 120000: how long a wait behind a collective polls before the communicator is aborted */
-  int32_t side_stream_cus;       /* 0 = default; > 0: compute units reserved for the side stream (CU masks on both streams); -1 = none */
+  int32_t side_stream_cus;       /* 0 = none; k > 0: the side stream (challenge-independent transforms under the commitments) is confined
+                                    to k compute units by a CU mask and uses the four-wave NTT kernels there; the main stream keeps all */
 } plonk_gpu_config;
 int plonk_ctx_create_ex(plonk_ctx** out, int device, const plonk_gpu_config* config /* NULL = defaults */);
 int plonk_ctx_get_config(plonk_ctx* ctx, plonk_gpu_config* out /* struct_size set by the caller */);

@@ -1591,7 +1591,7 @@ void msm_plan(const Ctx* c, uint32_t table_rows, uint64_t table_n, uint64_t mmax
       {"nbm::msm_accumulate_kernel", "nbm::msm_accumulate_ordered_kernel", "nbm::msm_accumulate_lds_kernel"},
       {"nbl::msm_accumulate_kernel", "nbl::msm_accumulate_ordered_kernel", "nbl::msm_accumulate_lds_kernel"}};
   const uint64_t avg_slices = (MSM_W * mmax) / (p.slice_entries ? p.slice_entries : 1) / (1ull << nb_bits);
-  p.flags = (c->cfg.tail_serial ? PLONK_PLAN_TAIL_SERIAL : 0u) | (c->cfg.acc_lds ? PLONK_PLAN_ACCUMULATE_LDS : 0u) |
+  p.flags = ((nb_bits > 15 && c->cfg.sort13 == 1) ? PLONK_PLAN_SORT13 : 0u) | (c->cfg.tail_serial ? PLONK_PLAN_TAIL_SERIAL : 0u) | (c->cfg.acc_lds ? PLONK_PLAN_ACCUMULATE_LDS : 0u) |
             ((c->cfg.bsum_lane || c->cfg.tail_serial || avg_slices > 8 || (nb_bits > 15 && p.ordered_lanes)) ? PLONK_PLAN_BUCKET_SUM_LANE : 0u);
   p.kernel = names[nb_bits == 19 ? 2 : (nb_bits == 17 ? 1 : 0)][c->cfg.acc_lds ? 2 : (p.ordered_lanes ? 1 : 0)];
   *out = p;

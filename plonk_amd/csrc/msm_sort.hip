@@ -306,6 +306,116 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
   }
 }
 
+#if PLONK_MSM_NB_BITS > 15
+// ---- level 1c, round 5 variant: two partition workgroups per CU -----------------------------------------------------
+// The partition pass above stages a tile of 2048 scalars x 16 digit slots: 128 KiB of the CU's 160 KiB of LDS, i.e. ONE
+// workgroup per CU — while it scans its histogram (20 barriers) or drains its runs to HBM nothing else on that CU issues.
+// Over 2^19 buckets a scalar has at most 13 digits (width 21: ceil(256 / 21); half-density width 20: 13), so a tile of 1024
+// scalars needs 1024 x 13 words = 52 KiB + the three 8 KiB bin arrays = 76 KiB: TWO workgroups of 512 threads per CU (four
+// waves per SIMD at <= 128 VGPRs), one in its memory phase while the other computes.  The price: a tile contributes ~6
+// words to a coarse bin instead of ~12, so the runs written to HBM are half as long.  Selected by PLONK_MSM_SORT13=1 (A/B;
+// the measurement decides the default: profiles/r05/SUMMARY.md section 2).  Same words, same order-insensitive result.
+static constexpr uint32_t P2_TILE = 1024, P2_T = 512, P2_W = 13, P2_PER = P2_TILE / P2_T, P2_BPT = COARSE / P2_T;
+static constexpr size_t PARTITION2_LDS = ((size_t)P2_TILE * P2_W + 3 * COARSE) * sizeof(uint32_t);
+static_assert(P2_PER * 9 * P2_T <= P2_TILE * P2_W, "the parked scalars fit the staging area");
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_p2(uint32_t v, uint32_t* sh /* P2_T */, uint32_t* total) {
+  const uint32_t t = threadIdx.x;
+  sh[t] = v;
+  __syncthreads();
+  for (uint32_t d = 1; d < P2_T; d <<= 1) {
+    const uint32_t x = t >= d ? sh[t - d] : 0;
+    __syncthreads();
+    sh[t] += x;
+    __syncthreads();
+  }
+  const uint32_t incl = sh[t];
+  *total = sh[P2_T - 1];
+  __syncthreads();
+  return incl - v;
+}
+
+template <int MODE, class WordT>
+__global__ void __launch_bounds__(P2_T, 4) msm_partition2_kernel(MsmBatch bt, uint64_t srs_n,
+                                                                  const uint32_t* __restrict__ coarse_off_all,
+                                                                  uint32_t* __restrict__ coarse_cur_all,
+                                                                  void* __restrict__ tmp_all) {
+  static_assert(MODE != 0, "bit-position / half-density recodings only");
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* stage = lds;                          // P2_TILE * P2_W
+  uint32_t* hist = lds + P2_TILE * P2_W;          // COARSE
+  uint32_t* loff = hist + COARSE;
+  uint32_t* gbase = loff + COARSE;
+  __shared__ uint32_t sh[P2_T];
+  const int kb = blockIdx.y;
+  const uint64_t m = bt.m[kb];
+  const uint64_t base = (uint64_t)blockIdx.x * P2_TILE;
+  if (base >= m) return;
+  const uint32_t t = threadIdx.x;
+#pragma unroll
+  for (uint32_t j = 0; j < P2_BPT; ++j) hist[t + j * P2_T] = 0;
+  __syncthreads();
+  uint32_t word[P2_PER][P2_W], where[P2_PER][P2_W];
+#pragma unroll
+  for (uint32_t k = 0; k < P2_PER; ++k) {
+#pragma unroll
+    for (uint32_t w = 0; w < P2_W; ++w) where[k][w] = 0xffffffffu;
+    const uint64_t i = base + t + (uint64_t)k * P2_T;
+    if (i < m) {
+      const Fr s = scalar_canonical(ld_scalar_at(bt, kb, i));
+      auto put = [&](int w, uint32_t row, uint32_t bucket, uint32_t sign) {   // w = digit slot (static after unrolling), < 13 by the digit widths
+        if (w < (int)P2_W) {
+          const uint32_t bin = bucket >> FINE_BITS;
+          const uint32_t rank = atomicAdd(&hist[bin], 1u);          // < P2_TILE * P2_W < 2^14
+          where[k][w] = (bin << 16) | rank;
+          word[k][w] = ((bucket & ((1u << FINE_BITS) - 1)) << 20) | (sign << 19) | (row << 11) | (t + k * P2_T);
+        }
+      };
+      uint32_t* park = stage + k * (9 * P2_T);   // the canonical scalar, limb-major; only this lane reads it back
+#pragma unroll
+      for (int j = 0; j < 8; ++j) park[j * P2_T + t] = s.l[j];
+      park[8 * P2_T + t] = 0;
+      if (MODE == 2) for_each_digit_even<MSM_EVEN_WIDTH>(StridedLimbs{park + t, P2_T}, put);
+      else for_each_digit_naf<MSM_NAF_WIDTH>(StridedLimbs{park + t, P2_T}, put);
+    }
+  }
+  __syncthreads();   // (also: every parked scalar has been read before the staging area is written below)
+  {
+    uint32_t cnt[P2_BPT], sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < P2_BPT; ++j) { cnt[j] = hist[P2_BPT * t + j]; sum += cnt[j]; }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan_p2(sum, sh, &total);
+    const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
+    uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)kb * COARSE;
+#pragma unroll
+    for (uint32_t j = 0; j < P2_BPT; ++j) {
+      const uint32_t bin = P2_BPT * t + j;
+      loff[bin] = run;
+      run += cnt[j];
+      gbase[bin] = cnt[j] ? coff[bin] + atomicAdd(&cur[bin], cnt[j]) : 0;
+    }
+  }
+  __syncthreads();
+  const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
+#pragma unroll
+  for (uint32_t k = 0; k < P2_PER; ++k)
+#pragma unroll
+    for (uint32_t w = 0; w < P2_W; ++w)
+      if (where[k][w] != 0xffffffffu) stage[loff[where[k][w] >> 16] + (where[k][w] & 0xffffu)] = word[k][w];
+  __syncthreads();
+  // write the runs: 8 lanes per bin (a run is ~6 words), 64 bins per sweep of the workgroup
+  const uint32_t sub = t & 7;
+  for (uint32_t bin = t >> 3; bin < COARSE; bin += P2_T / 8) {
+    const uint32_t cnt = hist[bin], lo = loff[bin], gb = gbase[bin];
+    for (uint32_t j = sub; j < cnt; j += 8) {
+      const uint32_t lw = stage[lo + j];
+      tmp.st(gb + j, SortWord<WordT>::make(lw >> 20, (lw >> 19) & 1u, (uint64_t)((lw >> 11) & 0xffu) * srs_n + base + (lw & 0x7ffu)));
+    }
+  }
+}
+#endif
+
 // ---- level 2: fine buckets inside a coarse bin ----------------------------------------------------
 #ifndef PLONK_FINE_T
 #define PLONK_FINE_T 512
@@ -695,9 +805,23 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
   hipLaunchKernelGGL(msm_hist_kernel<MODE>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
-  smem_opt_in(c, (const void*)msm_partition_kernel<MODE, WordT>, PARTITION_LDS);
-  hipLaunchKernelGGL((msm_partition_kernel<MODE, WordT>), dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
-                     w.coarse_off, w.coarse_cur, tmp);
+#if PLONK_MSM_NB_BITS > 15
+  if constexpr (MODE != 0) {
+    if (c->cfg.sort13 == 1) {   // round 5 A/B: two half-size partition workgroups per CU (13 digit slots of 1024 scalars)
+      const uint32_t tiles2 = (uint32_t)((mmax + P2_TILE - 1) / P2_TILE);
+      smem_opt_in(c, (const void*)msm_partition2_kernel<MODE, WordT>, PARTITION2_LDS);
+      hipLaunchKernelGGL((msm_partition2_kernel<MODE, WordT>), dim3(tiles2, bt.count), dim3(P2_T), PARTITION2_LDS, st, bt, bt.table_n,
+                         w.coarse_off, w.coarse_cur, tmp);
+    }
+  }
+  if (MODE == 0 || c->cfg.sort13 != 1) {
+#else
+  {
+#endif
+    smem_opt_in(c, (const void*)msm_partition_kernel<MODE, WordT>, PARTITION_LDS);
+    hipLaunchKernelGGL((msm_partition_kernel<MODE, WordT>), dim3(tiles, bt.count), dim3(SORT_T), PARTITION_LDS, st, bt, bt.table_n,
+                       w.coarse_off, w.coarse_cur, tmp);
+  }
   hipLaunchKernelGGL(msm_fine_kernel<WordT>, dim3(COARSE, bt.count), dim3(FINE_T), 0, st, bt, w.coarse_off, tmp,
                      w.entries, w.offsets);
   {   // oversized bins (skewed digits): upper bound of the chunk count known on the host, surplus workgroups exit at once

@@ -161,6 +161,7 @@ struct Config {
   bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
+  int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
 };
 
 struct plonk_msm_plan_internal {   // what msm_batch_device chose (mirrors plonk_msm_plan)

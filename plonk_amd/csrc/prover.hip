@@ -104,6 +104,7 @@ struct Prover {
   uint64_t lag_n = 0;              // points in lag_table
   uint32_t lag_rows = 0;           // its rows: 256 (a row per bit position) or 16 (window rows)
   bool lag_on = false;             // wire commitments over the Lagrange key (lag_n may be 0 for a rank without a slice)
+  bool lag_whole = false;          // sharded prover holding the WHOLE Lagrange key: the wire group is split by commitment, not by point range
   Fr* wscal = nullptr;             // [8] the wire blinders on the device (tail scalars of the four Lagrange-key MSMs)
   Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
   Fr* scratch2 = nullptr;          // [np + 1]
@@ -148,7 +149,9 @@ struct SideScope {
     (void)hipEventRecord(wait_for, c->main_stream);
     (void)hipStreamWaitEvent(c->side_stream, wait_for, 0);
     c->stream = c->side_stream;
-    c->ntt_elog_hint = 3;
+    // side stream confined to CUs of its own by a CU mask (plonk_gpu_config.side_stream_cus, round 5): the four-wave kernels
+    // can no longer spread over the chip and tax the critical path, so they keep ntt.hip's default geometry
+    c->ntt_elog_hint = c->cfg.side_cus > 0 ? 0 : 3;
   }
   ~SideScope() { c->stream = c->main_stream; c->ntt_elog_hint = 0; }
 };
@@ -160,8 +163,12 @@ struct SideScopeAfter {
   SideScopeAfter(Ctx* ctx, hipEvent_t recorded) : c(ctx) {
     (void)hipStreamWaitEvent(c->side_stream, recorded, 0);
     c->stream = c->side_stream;
+    // the deferred scope starts under the latency-bound TAIL of a group, not under its accumulation; which pass
+    // geometry suits it is measured, not assumed (PLONK_SIDE_AFTER_ELOG=2|3 for the A/B; default: ntt.hip's own choice,
+    // the state the round-4 numbers were taken in — profiles/r05/SUMMARY.md section 3 has the same-box comparison)
+    c->ntt_elog_hint = c->cfg.side_after_elog;
   }
-  ~SideScopeAfter() { c->stream = c->main_stream; }
+  ~SideScopeAfter() { c->stream = c->main_stream; c->ntt_elog_hint = 0; }
 };
 struct AccMark {   // msm_batch_device records `ev` after its accumulate launch while this is alive
   Ctx* c;
@@ -616,9 +623,16 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
       // multi-GPU: the rank's slice [shard_lo, shard_lo + count) of the (n + 2)-point Lagrange key, computed where the whole
       // commit key was available (plonk_lagrange_key)
       const uint64_t lhi = p->shard_lo + p->per < n + 2 ? p->shard_lo + p->per : n + 2;
-      const uint64_t want = lhi > p->shard_lo ? lhi - p->shard_lo : 0;
+      uint64_t want = lhi > p->shard_lo ? lhi - p->shard_lo : 0;
+      // Round 5 ("by commitment"): a rank of 2 or 4 handed the WHOLE key (size + 2 points) commits to whole wire
+      // columns — rank r of 2 to columns 2r, 2r + 1, rank r of 4 to column r — instead of a quarter / half of every column:
+      // the same additions, but one or two commitments' worth of sort / bucket / row-column / bit-sum tails instead of four.
+      // Every rank holds all wire values anyway; the price is the whole table on every rank (32 GiB of bit-position rows
+      // at 2^20 gates, taken from the context's table budget like any other key).
+      p->lag_whole = p->sharded && (p->world == 2 || p->world == 4) && d->lagrange_count == n + 2 && want != n + 2;
+      if (p->lag_whole) want = n + 2;
       if (!p->sharded || d->lagrange_count != want)
-        return (plonk::set_last_error("invalid argument", "lagrange_count is not this rank's slice of the size + 2 points", __FILE__, __LINE__), PLONK_ERR_ARG);
+        return (plonk::set_last_error("invalid argument", "lagrange_count is neither this rank's slice of the size + 2 points nor all of them", __FILE__, __LINE__), PLONK_ERR_ARG);
       if (want) {
         G1Affine* lag_pts = nullptr;
         HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * want));
@@ -1194,7 +1208,27 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   }
   {
     AccMark mark(c, side_defer ? p->ev_acc : nullptr);
-    if (lag) {
+    if (lag && p->lag_whole) {
+      // by commitment (round 5): this rank's whole columns over the whole Lagrange-basis key, exactly the single-GPU launch
+      // for those columns; the slots of the columns it does not own hold the identity (all-zero bit sums), so the all-gather
+      // + add of fetch_commitments needs no change
+      const int per_rank = 4 / (int)W, first = per_rank * p->rank;
+      for (int k = 0; k < 4; ++k)
+        if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));
+      HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(hipMemsetAsync(p->res, 0, (size_t)RES_STRIDE * 4, c->stream));
+      for (int k = 0; k < 4; ++k) { p->res_bitpos[k] = false; p->res_rowbits[k] = 8; }
+      const Fr* sc[2];
+      const Fr* tl[2];
+      uint64_t ms[2], sp[2];
+      for (int j = 0; j < per_rank; ++j) {
+        sc[j] = wires_dev + (uint64_t)(first + j) * n;
+        tl[j] = p->wscal + 2 * (first + j);
+        ms[j] = n + 2;
+        sp[j] = n;
+      }
+      PTRY(msm_group(p, sc, ms, per_rank, first, p->lag_table, p->lag_n, tl, sp));
+    } else if (lag) {
       // wire commitments from the wire VALUES over this rank's slice of the Lagrange-basis key (see prover_prove): values
       // [lo_L, hi_L) of each column in place, the column's two blinders for the slice that reaches indices n, n + 1
       const uint64_t lo_l = p->shard_lo, hi_l = p->shard_lo + p->lag_n;       // hi_l <= n + 2

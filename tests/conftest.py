@@ -8,6 +8,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# generated bench circuits are written once per session and shared by every test and every rank of every child process
+# (bench_circuits._cached); a fresh directory per session, removed at exit
+import atexit  # noqa: E402
+import shutil  # noqa: E402
+import tempfile  # noqa: E402
+
+if "PLONK_CIRCUIT_CACHE" not in os.environ:
+    _cache_dir = tempfile.mkdtemp(prefix="plonk_circuits_")
+    os.environ["PLONK_CIRCUIT_CACHE"] = _cache_dir
+    atexit.register(shutil.rmtree, _cache_dir, True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "slow: longer CPU oracle case")

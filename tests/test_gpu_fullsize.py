@@ -29,6 +29,12 @@ def test_bench_proof_verifies(log_n):
     p1b = prover.prove_dev(wbuf.ptr, {}, bl1)
     p2 = prover.prove_dev(wbuf.ptr, {}, bl2)
     assert p1 == p1b and p1 != p2
+    # bl1 are bench.py's blinders: this is the proof `python bench.py --log-gates N` prints the digest of — hand it to the
+    # multi-rank tests of this session instead of building the same prover again in a child process
+    import hashlib
+    from session_cache import SINGLE
+    SINGLE[(log_n, "dense")] = {"n_gpus": 1, "proof_blake2b": hashlib.blake2b(p1).hexdigest()[:32],
+                                "config": {"prover_built_by": "plonk_prover_create (coefficient forms)", "collective": None}}
     n = 1 << log_n
     for p in (p1, p2):
         assert verify_with_tau(p, vk, b"bench", n, {}, tau, srs_g)

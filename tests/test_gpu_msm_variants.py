@@ -30,6 +30,10 @@ VARIANTS = [
      {"table_rows": 256, "digit_width": 21, "bucket_bits": 19, "slice_entries": 32, "ordered_lanes": 1, "accumulate_kernel": KLO}),
     ({"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_ORDER": "0"},
      {"table_rows": 256, "bucket_bits": 19, "ordered_lanes": 0, "accumulate_kernel": KL}),
+    ({"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"},   # round 5: two half-size partition workgroups per CU (13 digit slots)
+     {"table_rows": 256, "bucket_bits": 19, "flags": 8 | 2, "accumulate_kernel": KLO}),
+    ({"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"},
+     {"table_rows": 128, "bucket_bits": 19, "flags": 8 | 2, "accumulate_kernel": KLO}),
     ({"PLONK_MSM_BSUM": "lane"}, {"flags": 2, "accumulate_kernel": K15}),            # one lane per bucket in msm_bucket_sum instead of a quad (small MSMs)
     ({"PLONK_MSM_TABLE": "halfpos"}, {"table_rows": 128, "digit_width": 16, "bucket_bits": 15}),   # round 4: a row for every second bit position, even-position digits
     ({"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},                       # ... width-20 digits over 2^19 buckets (keys whose 256 rows do not fit)
@@ -48,7 +52,8 @@ def test_variant_matches_the_oracle_on_the_edge_cases(variant, plan):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"},
-                                     {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"}],
+                                     {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},
+                                     {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"}],
                          ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
 def test_prover_parity_holds_with_every_table_and_bucket_layout(variant):
     """whole proofs (reference KAT digest, random circuits, widget circuits vs the C oracle at 2^12 / 2^13) with the table /

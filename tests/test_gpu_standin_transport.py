@@ -40,7 +40,8 @@ def test_standin_library_exports_what_comm_hip_resolves():
         assert hasattr(lib, name), name
 
 
-@pytest.mark.parametrize("ranks,log_gates,profile", [(2, 13, "widgets"), (4, 13, "widgets"), (8, 13, "widgets"), (4, 16, "dense")])
+@pytest.mark.parametrize("ranks,log_gates,profile", [(2, 13, "widgets"), (4, 13, "widgets"), (8, 13, "widgets"), (4, 16, "dense"),
+                                                      (2, 12, "bench-like")])
 def test_sharded_quotient_prove_through_device_collectives(ranks, log_gates, profile):
     """world in {2, 4, 8}: MSM partial sums through comm_allgather_host's staging, the class-sharded quotient through
     comm_alltoall_dev, rounds 4-5 through three more small all-gathers — all as nccl* calls on the library's stream"""
@@ -65,6 +66,24 @@ def test_compiled_prover_through_device_collectives():
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
+@pytest.mark.parametrize("ranks,log_gates,profile", [(2, 13, "widgets"), (4, 13, "widgets"), (4, 16, "dense"), (2, 16, "bench-like")])
+def test_wire_group_split_by_commitment(ranks, log_gates, profile):
+    """Round 5: ranks of 2 / 4 that hold the WHOLE Lagrange-basis key commit to whole wire columns (rank r of 2: columns 2r,
+    2r + 1; of 4: column r) and contribute the identity for the others — prover.rs:187-210's four commitments split by
+    commitment instead of by point range.  Same proof bytes."""
+    s = single(log_gates, profile)
+    m = standin(ranks, log_gates, profile, {"PLONK_BENCH_WIRE_SPLIT": "commitment"})
+    assert "by whole column" in m["config"]["parallelism"]
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
+@pytest.mark.slow
+def test_wire_group_split_by_commitment_at_2p20():
+    s = single(20, "dense")
+    m = standin(2, 20, "dense", {"PLONK_BENCH_WIRE_SPLIT": "commitment"})
+    assert "by whole column" in m["config"]["parallelism"] and m["proof_blake2b"] == s["proof_blake2b"]
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("ranks", [2, 8])
 def test_sharded_prove_at_2p20_through_device_collectives(ranks):
@@ -72,6 +91,17 @@ def test_sharded_prove_at_2p20_through_device_collectives(ranks):
     4 MiB-per-peer all-to-all and the 4 MiB z slices going through device pointers"""
     s = single(20, "dense")
     m = standin(ranks, 20, "dense")
+    assert m["proof_blake2b"] == s["proof_blake2b"]
+
+
+@pytest.mark.slow
+def test_sharded_prove_at_2p22_through_device_collectives():
+    """BASELINE config 5's shape: 2^22 gates over W = 8 ranks (Q = 8 classes; 2^19 + 1 commit-key points per rank, each rank
+    streaming only its own range from pinned host memory; 16 MiB per peer in the all-to-all, 16 MiB z slices in the in-place
+    all-gather).  The eight ranks share this box's one GPU; the sharded proof must be the single-GPU proof byte for byte —
+    whose bytes tests/test_gpu_fullsize.py compares with the C oracle."""
+    s = single(22, "dense")
+    m = standin(8, 22, "dense", extra=["--warmup", "0"])
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 

@@ -52,7 +52,9 @@ def run(log_n, world, rank, steps):
         slots[name] = round(total / steps, 3)
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
     out = {"log_gates": log_n, "world": world, "rank": rank, "points": hi - lo, "prove_ms_rank_alone": round(ms, 3), "kernel_ms": slots,
-           "table_rows": ctx.table_rows() if hasattr(ctx, "table_rows") else None, "callback_calls": calls[0]}
+           "table_rows": ctx.table_rows() if hasattr(ctx, "table_rows") else None, "callback_calls": calls[0],
+           "wire_split": getattr(bench.build_prover, "wire_split", "range") if world > 1 else None,   # PLONK_BENCH_WIRE_SPLIT=commitment
+           "lagrange_points": prover.describe()["lagrange_points"]}
     prover.close()
     wbuf.free()
     ctx.close()
