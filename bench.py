@@ -91,9 +91,10 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
         full.free()
         key = ctx.lagrange_key(log_n)
         llo, lhi = min(lo, n + 2), min(hi, n + 2)
-        # PLONK_BENCH_WIRE_SPLIT=commitment (2 / 4 ranks): every rank takes the WHOLE Lagrange-basis key and commits to whole
-        # wire columns instead of a point range of every column (prover.hip lag_whole)
-        build_prover.wire_split = "commitment" if (world in (2, 4) and os.environ.get("PLONK_BENCH_WIRE_SPLIT", "range") == "commitment") else "range"
+        # 2 / 4 ranks: every rank takes the WHOLE Lagrange-basis key and commits to whole wire columns instead of a point range
+        # of every column (prover.hip lag_whole; DESIGN.md section 5: rank alone at 2^20, same box, 18.34 -> 17.98 ms for W = 2,
+        # 9.08 -> 8.68 for W = 4; 32 GiB of table per rank).  PLONK_BENCH_WIRE_SPLIT=range restores the split by point range.
+        build_prover.wire_split = "commitment" if (world in (2, 4) and os.environ.get("PLONK_BENCH_WIRE_SPLIT", "commitment") == "commitment") else "range"
         lag_slice = key if build_prover.wire_split == "commitment" else key[96 * llo:96 * lhi]
         del key
     # the rank's slice of the commit key is produced once (on the device: the reference's setup is O(n * 255)

@@ -46,8 +46,8 @@ def test_sharded_quotient_prove_through_device_collectives(ranks, log_gates, pro
     """world in {2, 4, 8}: MSM partial sums through comm_allgather_host's staging, the class-sharded quotient through
     comm_alltoall_dev, rounds 4-5 through three more small all-gathers — all as nccl* calls on the library's stream"""
     s = single(log_gates, profile)
-    m = standin(ranks, log_gates, profile)
-    assert "residue class" in m["config"]["parallelism"]
+    m = standin(ranks, log_gates, profile, {"PLONK_BENCH_WIRE_SPLIT": "range"})   # every commitment by point range (the by-column split: below)
+    assert "residue class" in m["config"]["parallelism"] and "by whole column" not in m["config"]["parallelism"]
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
@@ -78,10 +78,12 @@ def test_wire_group_split_by_commitment(ranks, log_gates, profile):
 
 
 @pytest.mark.slow
-def test_wire_group_split_by_commitment_at_2p20():
+def test_wire_group_split_by_point_range_at_2p20():
+    """the round-4 split (a point range of every wire column per rank) at BASELINE config 4's size; the by-column split is what
+    test_sharded_prove_at_2p20_through_device_collectives[2] and the gloo W = 4 case now run by default"""
     s = single(20, "dense")
-    m = standin(2, 20, "dense", {"PLONK_BENCH_WIRE_SPLIT": "commitment"})
-    assert "by whole column" in m["config"]["parallelism"] and m["proof_blake2b"] == s["proof_blake2b"]
+    m = standin(2, 20, "dense", {"PLONK_BENCH_WIRE_SPLIT": "range"})
+    assert "by whole column" not in m["config"]["parallelism"] and m["proof_blake2b"] == s["proof_blake2b"]
 
 
 @pytest.mark.slow
@@ -91,6 +93,7 @@ def test_sharded_prove_at_2p20_through_device_collectives(ranks):
     4 MiB-per-peer all-to-all and the 4 MiB z slices going through device pointers"""
     s = single(20, "dense")
     m = standin(ranks, 20, "dense")
+    assert ("by whole column" in m["config"]["parallelism"]) == (ranks == 2)     # default for 2 / 4 ranks since round 5
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 

@@ -70,23 +70,38 @@ if acc in pm["FETCH_SIZE"]:
                "table row per digit position is gathered (~12.1 x 128 B per term with bit-position tables and 2^19 buckets, 14.7 with 2^15 buckets, 16 x 128 B with window tables) so that all digits "
                "share one bucket set; the kernel is integer-VALU bound, not HBM bound.")
     import json
-    valu = None
+    valu = valu_res = waves = None
     try:
+        # Units (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"): SQ_WAVE_CYCLES and SQ_ACTIVE_INST_VALU count QUAD-cycles
+        # summed over waves; SQ_BUSY_CYCLES counts cycles summed over the chip's 32 shader engines (check: srs_generate_kernel,
+        # BUSY / (32 x its duration) = 2.35 GHz).  The chip has 1024 SIMDs, so a kernel's SIMD time in quad-cycles is
+        # 1024 x (BUSY / 32) / 4 = 8 x BUSY, and
+        #     resident waves per SIMD = WAVE_CYCLES / (8 BUSY)         VALU busy = ACTIVE_INST_VALU / (8 BUSY).
+        # Round 4 divided by a CONSTANT number of waves per SIMD instead (2 for every kernel): right for the accumulation
+        # while all its waves are resident, wrong for the four-wave NTT passes (the printed 0.56 was off by
+        # the occupancy).  The per-kernel occupancy now comes from the counters themselves.
+        def occ(k):
+            v = agg[k]
+            return v["SQ_WAVE_CYCLES"] / (8 * v["SQ_BUSY_CYCLES"]), v["SQ_ACTIVE_INST_VALU"] / (8 * v["SQ_BUSY_CYCLES"])
         a = agg[acc]
-        # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES both count quad-cycles summed over waves (MI355X_MICROARCH.md,
-        # "s_memtime tick vs SQ PMC units"); the kernel runs 2 waves per SIMD (216 VGPRs), so SIMD time =
-        # WAVE_CYCLES / 2 and VALU-busy = ACTIVE_INST_VALU / (WAVE_CYCLES / 2).
-        valu_raw = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
-        valu = min(valu_raw, 1.0)   # waves that retire early make the 2-waves-per-SIMD denominator a slight underestimate
-        out.append(f"\n## VALU utilisation of `{acc}`\n\nSQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD) = **{valu_raw:.2f}** — "
-                   "the integer VALU pipe is saturated; only fewer instructions per point addition make this kernel faster.")
-        nk = max((k for k in agg if "ntt_pass_kernel" in k), key=lambda k: agg[k]["SQ_WAVE_CYCLES"])
-        b = agg[nk]
-        out.append(f"Same ratio for `{nk}` (2 workgroups x 4 waves per CU = 2 waves per SIMD): {b['SQ_ACTIVE_INST_VALU'] / (b['SQ_WAVE_CYCLES'] / 2):.2f}.")
+        waves, valu = occ(acc)
+        valu_res = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / max(waves, 1e-9))   # = valu by construction; kept explicit below
+        valu_two = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
+        out.append(f"\n## VALU utilisation (occupancy derived from the counters)\n\n| kernel | resident waves per SIMD = WAVE_CYCLES / (8 BUSY) | VALU busy = ACTIVE_INST_VALU / (8 BUSY) |\n|---|---|---|")
+        shown = [acc] + sorted((k for k in agg if "ntt_pass_kernel" in k or "quotient_kernel" in k or "msm_rowcol" in k or "msm_partition" in k or "msm_fine" in k),
+                               key=lambda k: -agg[k]["SQ_WAVE_CYCLES"])[:8]
+        for k in shown:
+            w_, v_ = occ(k)
+            out.append(f"| `{k}` | {w_:.2f} | {v_:.2f} |")
+        out.append(f"\n`{acc}`: {waves:.2f} waves per SIMD on average over the launch (2 while every lane still has entries: the lanes are ordered by "
+                   f"length and retire at different times) and VALU busy **{valu:.2f}** of all SIMD time; while two waves are resident "
+                   f"(round 4's figure, ACTIVE / (WAVE_CYCLES / 2)) {min(valu_two, 1.0):.2f}.  Either way only fewer instructions per point addition make it faster.")
     except Exception as e:  # noqa
         out.append(f"\n(VALU utilisation unavailable: {e})")
     json.dump({"kernel": acc, "workload": "bench.py 2^20 gates, 1 GPU", "fetch_size_kib_per_launch": fa,
-               "valu_busy_frac": valu, "valu_busy_formula": "SQ_ACTIVE_INST_VALU / (SQ_WAVE_CYCLES / 2 waves per SIMD), quad-cycle units",
+               "valu_busy_frac": valu, "resident_waves_per_simd": waves,
+               "valu_busy_formula": "SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES): quad-cycles over 1024 SIMDs x (BUSY / 32 shader engines) / 4; "
+                                    "resident waves per SIMD = SQ_WAVE_CYCLES / (8 x SQ_BUSY_CYCLES)",
                "write_size_kib_per_launch": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
                "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KiB -> bytes"},
               open(dst + "pmc.json", "w"), indent=1)
