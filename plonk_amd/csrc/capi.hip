@@ -168,6 +168,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   g.lps = env_int("PLONK_MSM_LPS", 0);
   g.rcwv = env_int("PLONK_MSM_RCWV", 0);
   if (const char v = env_chr("PLONK_MSM_SORT13")) g.sort13 = v == '1' ? 1 : 0;
+  g.acc_wg = env_int("PLONK_MSM_ACC_WG", 0);
   if (const char v = env_chr("PLONK_MSM_RCAFFINE")) g.rc_affine = v == '1' ? 1 : 0;
   g.ntt_direct = env_chr("PLONK_NTT_DIRECT") != '0';
   g.bi_cfg = env_int("PLONK_BI_CFG", -1);

@@ -304,6 +304,21 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
   const uint32_t nfull = full_off[MSM_NB], npart = part_list[MSM_NB];
   // only the lanes of FULL slices search for their bucket; a workgroup that holds none (with 2^19 buckets: almost all of
   // them, a bucket being one partial slice) skips the staging of the search table
+#if PLONK_MSM_NB_BITS > 15
+  // 2^19 buckets: a bucket is one PARTIAL slice (~24 of 64 entries), full slices only exist for skewed digits — their lanes
+  // search full_off in global memory (19 dependent loads, rare) and the workgroup carries no LDS: round 5 removed the 32 KiB
+  // staging table every workgroup of this variant reserved for a search almost none of them ran
+  if (s >= nfull + npart) return;
+  uint32_t b, q, end;
+  if (s < nfull) {
+    uint32_t lo = 0, hi = MSM_NB / 64 - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      if (full_off[mid * 64] <= s) lo = mid; else hi = mid - 1;
+    }
+    lo *= 64;
+    hi = lo + 63;
+#else
   __shared__ uint32_t coarse[MSM_NB / 64];
   if (blockIdx.x * blockDim.x < nfull) {   // uniform per workgroup
     for (uint32_t j = threadIdx.x; j < MSM_NB / 64; j += blockDim.x) coarse[j] = full_off[j * 64];
@@ -319,6 +334,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
     }
     lo *= 64;
     hi = lo + 63;
+#endif
     while (lo < hi) {
       const uint32_t mid = (lo + hi + 1) >> 1;
       if (full_off[mid] <= s) lo = mid; else hi = mid - 1;
@@ -1364,7 +1380,8 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   if (acc_ordered && !acc_lds) {
     rc = msm_order_slices(c, bt);
     if (rc) return rc;
-    hipLaunchKernelGGL(msm_accumulate_ordered_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,
+    const uint32_t acc_wg = c->cfg.acc_wg == 64 ? 64u : 128u;   // PLONK_MSM_ACC_WG=64: one wave per workgroup (A/B, round 5)
+    hipLaunchKernelGGL(msm_accumulate_ordered_kernel, dim3((uint32_t)((max_slices + acc_wg - 1) / acc_wg), count), dim3(acc_wg), 0, st,
                        (const G1AffineR*)table, bt, w.entries, w.offsets, w.slice_off, w.full_off, w.part_list, (G1RSlot*)w.partial, (G1RSlot*)w.buckets);
   } else if (acc_lds)
     hipLaunchKernelGGL(msm_accumulate_lds_kernel, dim3((uint32_t)((max_slices + 127) / 128), count), dim3(128), 0, st,

@@ -157,6 +157,7 @@ struct Config {
   int lps = 0;                      // PLONK_MSM_LPS
   int rcwv = 0;                     // PLONK_MSM_RCWV
   int sort13 = -1;                  // PLONK_MSM_SORT13=0/1: 13-digit staging of the 2^19-bucket partition (round 5)
+  int acc_wg = 0;                   // PLONK_MSM_ACC_WG=64: threads per workgroup of the ordered accumulation (A/B)
   int rc_affine = -1;               // PLONK_MSM_RCAFFINE=0/1: affine buckets in the row / column sums (round 5)
   bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry

@@ -77,3 +77,26 @@ def test_python_binding_destroys_provers_before_their_context():
     provers[0].close()
     ctx.close()
     assert calls == [("prover_destroy", 333), ("prover_destroy", 222), ("ctx_destroy", 111)]
+
+
+def test_struct_layouts_of_the_binding_match_the_c_header(tmp_path):
+    """plonk_gpu_config / plonk_msm_plan / plonk_prover_info as a C99 compiler lays them out (sizeof + the offset of the last
+    field) against the ctypes mirrors the tests drive the library through — and against the Rust `#[repr(C)]` block of
+    INTEGRATION.md section 2, which lists the same fields in the same order."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "plonk_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(plonk_gpu_config), offsetof(plonk_gpu_config, side_stream_cus),\n'
+                   '  sizeof(plonk_msm_plan), offsetof(plonk_msm_plan, accumulate_kernel), sizeof(plonk_prover_info), offsetof(plonk_prover_info, lagrange_points));\n'
+                   '  return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    G, M, P = plonk_amd.GpuConfig, plonk_amd._MsmPlan, plonk_amd._ProverInfo
+    assert got == [ctypes.sizeof(G), G.side_stream_cus.offset, ctypes.sizeof(M), M.accumulate_kernel.offset,
+                   ctypes.sizeof(P), P.lagrange_points.offset]
+    assert plonk_amd.GpuConfig().struct_size == ctypes.sizeof(G) == 56
+    # the Rust block names every field of the config struct
+    rust = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, _ in G._fields_:
+        assert "pub " + name + ":" in rust, name

@@ -12,7 +12,7 @@ SELECT = "basic or edge or skew or small_scalars or doubling"
 
 def run_variant(env_extra, select=SELECT, marker="gpu", target="tests/test_gpu_msm.py"):
     env = dict(os.environ, **env_extra)
-    return subprocess.run([sys.executable, "-m", "pytest", target, "-x", "-q", "-m", marker, "-k", select],
+    return subprocess.run([sys.executable, "-m", "pytest", *target.split(), "-x", "-q", "-m", marker, "-k", select],
                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
@@ -58,10 +58,8 @@ def test_variant_matches_the_oracle_on_the_edge_cases(variant, plan):
 def test_prover_parity_holds_with_every_table_and_bucket_layout(variant):
     """whole proofs (reference KAT digest, random circuits, widget circuits vs the C oracle at 2^12 / 2^13) with the table /
     bucket layouts that the size rules would only pick for large circuits"""
-    r = run_variant(variant, select="kat or random_arithmetic or proof_bytes_equal_c_oracle and not 16 and not 2p20",
-                    marker="gpu and not slow", target="tests/test_gpu_prover.py tests/test_gpu_prove_sizes.py".split()[0])
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    r = run_variant(variant, select="proof_bytes_equal_c_oracle and not 16 and not 2p20", marker="gpu and not slow", target="tests/test_gpu_prove_sizes.py")
+    r = run_variant(variant, select="deterministic_v3 or random_arithmetic or (proof_bytes_equal_c_oracle and not 16 and not 2p20)",
+                    marker="gpu and not slow", target="tests/test_gpu_prover.py tests/test_gpu_prove_sizes.py")   # one child, both files
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 

@@ -116,15 +116,24 @@ def test_rejects_bad_log_n(ctx):
 
 @pytest.mark.parametrize("L", [19, 20])
 def test_three_pass_vs_oracle(ctx, L):
-    r = random.Random(300 + L)
+    """three-pass plans against the C restatement of best_fft (oracle/c, which tests/test_oracle_c.py pins to the big-int
+    oracle and the reference's closed forms): the Python oracle takes 10-20 s per transform at these sizes, and this test runs
+    three times per session (default kernels, PLONK_NTT_DIRECT=0, PLONK_NTT_ELOG=3).  Bytes in, bytes out."""
+    import numpy as np
+    from oracle import cbind
     N = 1 << L
-    a = [r.randrange(Q) for _ in range(N)]
-    d = EvaluationDomain(N)
-    assert ctx.ntt(a, L) == d.fft(a)
+    raw = np.random.default_rng(300 + L).integers(0, 256, size=(N, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x3F                                      # Montgomery limbs below 2^254 < q
+    a = raw.tobytes()
+    assert ctx.ntt_bytes(a, L, False, False, N) == cbind.ntt_bytes(a, L, False, False, N)
     il = N // 8 + 3
-    got = ctx.ntt(a[:il], L, coset=True)
-    assert got == d.coset_fft(a[:il])
-    assert ctx.ntt(got, L, inverse=True, coset=True) == a[:il] + [0] * (N - il)
+    got = ctx.ntt_bytes(a[:32 * il], L, False, True, il)
+    assert got == cbind.ntt_bytes(a[:32 * il], L, False, True, il)
+    back = ctx.ntt_bytes(got, L, True, True, N)
+    assert back == cbind.ntt_bytes(got, L, True, True, N) and back[32 * il:] == bytes(32 * (N - il))
+    # the inverse of the coset transform returns the coefficients in canonical Montgomery form: compare as field elements
+    import plonk_amd
+    assert plonk_amd.fr_from_bytes_mont(back[:32 * 64]) == plonk_amd.fr_from_bytes_mont(a[:32 * 64])
 
 
 @pytest.mark.parametrize("L", [23])

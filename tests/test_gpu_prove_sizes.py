@@ -140,6 +140,12 @@ def test_side_workloads_equal_c_oracle_2p20(ctx, monkeypatch, profile):
     bl = C.blinders(2021)
     got, vk = gpu_proof(ctx, case, srs, bl)
     cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk, threads=threads)
+    # the oracle takes its eleven commitments from the key's trapdoor — [g p(tau)] G is the group element the MSM over
+    # [g tau^i] G returns (tests/test_oracle_c_prove.py::test_trapdoor_commitments_are_the_msm_commitments), as the 2^22 test
+    # does: transforms, quotient and every O(n) pass remain the oracle's own.  The CPU MSMs (14 of its 22 s) run in full in
+    # test_proof_bytes_equal_c_oracle_2p20 on the dense workload and at 2^12 … 2^19 above.
+    tau, g = 0x5EED0000 * 0x9E3779B97F4A7C15 % C.Q, 0xA5A5A5A5DEADBEEF      # = tests/circuits.py synthetic_srs
+    cp.set_trapdoor(C.fr_bytes([tau]), C.fr_bytes([g]))
     expected = cp.prove(wires, idx, case["pi_val"], bl)
     cp.close()
     assert got == expected
