@@ -667,7 +667,7 @@ def main():
         achieved = alg_bytes_per_prove / (acc_ms_per_prove * 1e-3) / 1e9 if acc_ms_per_prove > 0 else 0.0
         # HBM traffic / VALU utilisation of the same kernel come from PMC passes (rocprofv3 --pmc, separate runs):
         # NOT measured by this run — the latest committed profile is quoted with its source
-        valu_busy = traffic = pmc_src = None
+        valu_busy = traffic = pmc_src = pmc_clock = None
         if world == 1 and log_n == 20:
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json"))):
@@ -675,6 +675,7 @@ def main():
                     pj = json.load(open(f))
                     traffic = round(pj["traffic_bytes_per_launch"])
                     valu_busy = pj.get("valu_busy_frac")
+                    pmc_clock = pj.get("shader_clock_ghz_under_kernel")
                     pmc_src = os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of an earlier run, not this run)"
                 except Exception:   # noqa: BLE001
                     pass
@@ -742,6 +743,11 @@ def main():
                    "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
                    "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
                    "launch_groups_per_prove": list(groups),
+                   # the shader clock the counters show under this kernel (power-limited, from the same committed PMC passes) and the issue
+                   # fraction at THAT clock instead of the 2.4 GHz `peak` is quoted at
+                   "shader_clock_ghz_under_kernel": None if pmc_clock is None else round(pmc_clock, 2),
+                   "frac_at_measured_clock": None if not pmc_clock else round(
+                       valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"] * 2.4 / pmc_clock, 4),
                    "frac_vs_guide_valu_rate": round(valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"] / 2, 4),
                    "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound.  `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles: the "
                            "MEASURED issue class of v_mad_u64_u32 and the carry adds around it (4.4-4.9 cycles per wave-instruction, "
