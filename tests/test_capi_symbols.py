@@ -100,3 +100,20 @@ def test_struct_layouts_of_the_binding_match_the_c_header(tmp_path):
     rust = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name, _ in G._fields_:
         assert "pub " + name + ":" in rust, name
+
+
+def test_integration_doc_accounts_for_every_entry_point():
+    """every symbol of the header is either declared in the Rust `extern "C"` block or named in the
+    paragraph that lists what the shim leaves out — a new entry point cannot be added without telling the maintainer of the
+    reference-side binding about it."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index('extern "C" {'):doc.index("Error codes →")]
+    bound = set(re.findall(r"pub fn (plonk_[a-z0-9_]+)", block))
+    rest = doc[doc.index("Error codes →"):doc.index("## 3. Call-site patches")]
+    for name in header_symbols():
+        if name in bound:
+            continue
+        stem = name[len("plonk_"):]
+        # the paragraph abbreviates families: `plonk_dev_alloc / _free / _h2d / _d2h / _sync`, `plonk_profile_enable / _read / _reset`
+        family_tail = "_" + stem.split("_", 1)[1] if "_" in stem else ""
+        assert name in rest or (family_tail and family_tail in rest), name

@@ -1,10 +1,10 @@
 """GPU, several ranks on ONE device: the multi-GPU prove() of prover.hip (prover_prove_sharded) must output
 the same Proof bytes as the single-GPU run — MSMs sharded by SRS point range, the quotient by residue
 class of the coset, rounds 4-5 by coefficient range.  The exchanges go through the library's host-callback
-transport over gloo here (RCCL refuses two ranks on one device); the driver's 2/4/8-GPU runs use the
-RCCL transport inside the library, which differs only in how the same buffers travel.  The RCCL code
-path itself (dlopen, communicator, both collectives on the library's stream) is exercised with a
-one-rank communicator."""
+transport over gloo here (RCCL refuses two ranks on one device): the fallback a context without a communicator takes.
+The transport a multi-GPU node takes — nccl* collectives on device pointers inside the library — runs with real peers in
+tests/test_gpu_standin_transport.py (round 5; most of this file's matrix moved there), and with the real librccl and a
+one-rank communicator below (dlopen, communicator, both collectives on the library's stream)."""
 import json
 import os
 import subprocess
