@@ -752,7 +752,9 @@ def main():
                    "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound.  `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles: the "
                            "MEASURED issue class of v_mad_u64_u32 and the carry adds around it (4.4-4.9 cycles per wave-instruction, "
                            "profiles/r01/valu_issue_rates_gfx950.txt) — not the guide's generic VALU rate of one wave-instruction per 2 cycles, "
-                           "against which the same kernel is at `frac_vs_guide_valu_rate`.  `traffic` (PMC, HBM bytes per launch) is one "
+                           "against which the same kernel is at `frac_vs_guide_valu_rate`.  `frac_at_measured_clock` rescales `frac` from the 2.4 GHz of "
+                           "`peak` to the shader clock the committed PMC passes show under this kernel (power-limited); a value slightly above 1 "
+                           "means the instruction mix issues a little faster than one per 4 cycles (its carry additions are 2-cycle class).  `traffic` (PMC, HBM bytes per launch) is one "
                            "128-B table gather per non-zero digit by design; see DESIGN.md 4.2 / 6"}),
             # the pass of a proof that comes closest to HBM: quotient_kernel over the quotient-domain points
             "roofline_quotient": quotient_roofline(prover, n, 8 if qd8 else 4, bool(pi), args.profile, q_ms / max(q_n, 1)),
