@@ -179,10 +179,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   if (g.ntt_elog != 2 && g.ntt_elog != 3) g.ntt_elog = 0;
   if (g.side_cus < 0) g.side_cus = 0;
   if (g.table_budget == 0) {
-    size_t total = 0;
-    int cur = -1;
-    (void)hipGetDevice(&cur);
-    if (cur != device) (void)hipSetDevice(device);
+    size_t total = 0;   // (takes the device ordinal: the calling thread's current device is left alone)
     if (hipDeviceTotalMem(&total, device) != hipSuccess || total == 0) total = 256ull << 30;
     g.table_budget = (uint64_t)total / 10 * 8;
   }

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
   }
 }
 
-#if PLONK_MSM_NB_BITS > 15
+#if PLONK_MSM_NB_BITS >= 19   // (13 digit slots need digits at least 20 bits apart: the 2^19-bucket build only)
 // ---- level 1c, round 5 variant: two partition workgroups per CU -----------------------------------------------------
 // The partition pass above stages a tile of 2048 scalars x 16 digit slots: 128 KiB of the CU's 160 KiB of LDS, i.e. ONE
 // workgroup per CU — while it scans its histogram (20 barriers) or drains its runs to HBM nothing else on that CU issues.
@@ -318,6 +318,9 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
 static constexpr uint32_t P2_TILE = 1024, P2_T = 512, P2_W = 13, P2_PER = P2_TILE / P2_T, P2_BPT = COARSE / P2_T;
 static constexpr size_t PARTITION2_LDS = ((size_t)P2_TILE * P2_W + 3 * COARSE) * sizeof(uint32_t);
 static_assert(P2_PER * 9 * P2_T <= P2_TILE * P2_W, "the parked scalars fit the staging area");
+// consecutive digits of either recoding are at least their width apart, so a 256-bit scalar has at most ceil(256 / width)
+// of them: the 13 slots can never overflow (the `w < P2_W` test in `put` only keeps the unrolled indices static)
+static_assert((MSM_NAF_WIDTH) * P2_W >= 256 && (MSM_EVEN_WIDTH) * P2_W >= 256, "13 digit slots cover a scalar");
 
 __device__ __forceinline__ uint32_t block_exclusive_scan_p2(uint32_t v, uint32_t* sh /* P2_T */, uint32_t* total) {
   const uint32_t t = threadIdx.x;
@@ -805,7 +808,7 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
   hipLaunchKernelGGL(msm_hist_kernel<MODE>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
   hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
-#if PLONK_MSM_NB_BITS > 15
+#if PLONK_MSM_NB_BITS >= 19
   if constexpr (MODE != 0) {
     if (c->cfg.sort13 == 1) {   // round 5 A/B: two half-size partition workgroups per CU (13 digit slots of 1024 scalars)
       const uint32_t tiles2 = (uint32_t)((mmax + P2_TILE - 1) / P2_TILE);

@@ -123,3 +123,13 @@ def test_a_rank_that_dies_inside_a_proof_fails_the_others_within_the_timeout(die
     assert alive["exit"] == 0 and alive["rc"] == -7, rep
     assert 3.0 <= alive["seconds"] <= 30.0, rep
     assert alive["rc_second"] == -7 and alive["seconds_second"] < 2.0, rep
+
+
+@pytest.mark.parametrize("ranks,log_gates,env", [(3, 13, {}), (2, 12, {"PLONK_SHARD_QUOTIENT": "0"})])
+def test_msm_only_sharding_through_device_collectives(ranks, log_gates, env):
+    """world sizes other than 2 / 4 / 8 (and PLONK_SHARD_QUOTIENT=0): only the MSMs are sharded — every exchange is one of
+    comm_allgather_host's small staged all-gathers, here with an ODD number of peers"""
+    s = single(log_gates, "dense")
+    m = standin(ranks, log_gates, "dense", env)
+    assert "residue class" not in m["config"]["parallelism"] or env
+    assert m["proof_blake2b"] == s["proof_blake2b"]
