@@ -55,7 +55,6 @@ struct alignas(128) Slot {
 struct Segment {
   uint32_t magic;
   uint32_t world;
-  uint64_t mailbox_bytes;
   Slot slot[MAX_RANKS];
 };
 
@@ -155,6 +154,10 @@ ncclResult_t exchange(Comm* c, const void* send, size_t mine, void* recv, size_t
   if (mine > c->mailbox_bytes) {
     fprintf(stderr, "[fake_rccl] message of %zu bytes exceeds the %zu-byte mailbox (FAKE_RCCL_MAILBOX_MB)\n", mine, c->mailbox_bytes);
     return ncclInvalidArgument;
+  }
+  if (__atomic_load_n(c->timed_out, __ATOMIC_ACQUIRE)) {   // an earlier collective's kernel gave up on its own: its data was garbage
+    fprintf(stderr, "[fake_rccl] rank %d: a collective timed out on the device (a peer never arrived); refusing further collectives\n", c->rank);
+    return ncclRemoteError;
   }
   c->last_stream = st;
   const uint32_t k = ++c->seq;
@@ -328,6 +331,7 @@ const char* ncclGetErrorString(ncclResult_t r) {
     case ncclUnhandledCudaError: return "fake-rccl: HIP call failed";
     case ncclSystemError: return "fake-rccl: system error (shared memory / peers did not join)";
     case ncclInvalidArgument: return "fake-rccl: invalid argument";
+    case ncclRemoteError: return "fake-rccl: a peer never arrived (device-side time-out of an earlier collective)";
     default: return "fake-rccl: error";
   }
 }
