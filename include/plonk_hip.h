@@ -179,10 +179,10 @@ int plonk_dev_h2d(plonk_ctx* ctx, void* dst_dev, const void* src_host, uint64_t 
 int plonk_dev_d2h(plonk_ctx* ctx, void* dst_host, const void* src_dev, uint64_t bytes);
 int plonk_dev_sync(plonk_ctx* ctx);
 void* plonk_ctx_stream(plonk_ctx* ctx); /* the hipStream_t of the context's main stream (prove() also uses a private side stream) */
-/* Rows of the commit-key tables the context holds: 256 = one row per bit position (2^r * P_i; chosen for keys of more than
- * 2^19 points when 32 KiB per point fit in half of the free HBM: NAF digits over 2^19 buckets, ~12.1 additions per scalar),
- * 16 = window rows (2^(16 w) * P_i, 16 additions per scalar), 0 = no key loaded.  Same results either way;
- * PLONK_MSM_TABLE=window|bitpos forces one, PLONK_MSM_BUCKETS=15|19 the bucket count of bit-position MSMs. */
+/* Rows of the commit-key tables the context holds: 256 = one row per bit position (2^r * P_i: NAF digits over 2^19 buckets,
+ * ~12.1 additions per scalar), 128 = a row for every second position (12.8), 16 = window rows (2^(16 w) * P_i, 16 additions
+ * per scalar), 0 = no key loaded.  Chosen from the context's table budget (plonk_gpu_config above) for keys of more than
+ * 2^18 + 64 points; same results whichever; plonk_gpu_config.table_mode / .msm_bucket_bits force a layout / bucket count. */
 int plonk_ctx_table_rows(plonk_ctx* ctx);
 
 /* ---- device-resident Prover::prove (V3) -------------------------------------------

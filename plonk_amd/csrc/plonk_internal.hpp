@@ -280,8 +280,8 @@ namespace nbl { PLONK_MSM_VARIANT_DECLS int msm_buckets_bits(); }
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
                      bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0,
                      const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr, uint32_t table_rows = 0);
-// rows of the tables of an n-point key: 256 (one per bit position) when they fit comfortably in the free HBM, else
-// the 16 window rows; PLONK_MSM_TABLE=window|bitpos forces either
+// rows of the tables of an n-point key — 256 (one per bit position), 128 (every second) or the 16 window rows — from the
+// context's table budget and what it already holds (msm.hip); Config::table_mode forces one
 // last_key: the key is built after everything else the context needs (a prover's Lagrange-basis key) and may take what is
 // left of the budget; the commit key (false) leaves room for what follows
 uint32_t msm_table_rows(const Ctx* c, uint64_t n, bool last_key);

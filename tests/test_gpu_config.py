@@ -18,12 +18,13 @@ def _load_key(ctx, n=N_KEY):
 
 def test_defaults_and_round_trip():
     import plonk_amd
-    import torch
     ctx = plonk_amd.Context(0, plonk_amd.GpuConfig())
     g = ctx.get_config()
-    total = torch.cuda.get_device_properties(0).total_memory
     assert g.quotient_domain == 4 and g.wire_commit == 0 and g.table_mode == plonk_amd.TABLE_AUTO and g.comm_timeout_ms == 120000
-    assert abs(g.table_budget_bytes - total // 10 * 8) < (1 << 30)
+    # default budget: 80 % of the device's total memory — an MI355X reports 287.98 GiB (no torch here: a second HIP runtime in
+    # the process, torch's bundled one, is not something this test should depend on)
+    assert 0.79 * 288 * 2**30 <= g.table_budget_bytes <= 0.80 * 288 * 2**30
+    assert ctx.table_bytes() == (0, g.table_budget_bytes)
     g.table_mode, g.quotient_domain, g.comm_timeout_ms = plonk_amd.TABLE_WINDOW, 8, 5000
     ctx.set_config(g)
     h = ctx.get_config()
