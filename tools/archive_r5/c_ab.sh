@@ -5,7 +5,7 @@ exec > gpurun_out/r5c/log.txt 2>&1
 set -x
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 python __graft_entry__.py
-Q="python tools/r5/quick.py"
+Q="python tools/archive_r5/quick.py"
 O=gpurun_out/r5c/ab.jsonl
 QUICK_BENCH=build/r4tree/bench.py $Q r4tree --steps 10 --warmup 2 >> $O
 $Q r5 --steps 10 --warmup 2 >> $O

@@ -9,9 +9,9 @@ mkdir -p gpurun_out/prof_r05x
 python __graft_entry__.py > gpurun_out/prof_r05x/build.log 2>&1
 ( time timeout 1500 python -m pytest tests -q -m gpu --durations=30 ) > gpurun_out/prof_r05x/gpu_suite.txt 2>&1
 tail -45 gpurun_out/prof_r05x/gpu_suite.txt
-python tools/r5/quick.py acc_wg_128 --steps 10 --warmup 2 > gpurun_out/prof_r05x/ab_acc_wg.jsonl
-PLONK_MSM_ACC_WG=64 python tools/r5/quick.py acc_wg_64 --steps 10 --warmup 2 >> gpurun_out/prof_r05x/ab_acc_wg.jsonl
-python tools/r5/quick.py acc_wg_128_again --steps 10 --warmup 2 >> gpurun_out/prof_r05x/ab_acc_wg.jsonl
+python tools/archive_r5/quick.py acc_wg_128 --steps 10 --warmup 2 > gpurun_out/prof_r05x/ab_acc_wg.jsonl
+PLONK_MSM_ACC_WG=64 python tools/archive_r5/quick.py acc_wg_64 --steps 10 --warmup 2 >> gpurun_out/prof_r05x/ab_acc_wg.jsonl
+python tools/archive_r5/quick.py acc_wg_128_again --steps 10 --warmup 2 >> gpurun_out/prof_r05x/ab_acc_wg.jsonl
 cat gpurun_out/prof_r05x/ab_acc_wg.jsonl
 bash tools/profile_bench.sh r05x --no-extras > gpurun_out/prof_r05x.log 2>&1
 python tools/timeline.py gpurun_out/prof_r05x/trace/bench_kernel_trace.csv > gpurun_out/prof_r05x/timeline_2p20.txt 2>&1; head -1 gpurun_out/prof_r05x/timeline_2p20.txt

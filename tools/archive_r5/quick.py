@@ -1,4 +1,4 @@
-"""one short line per bench run: python tools/r5/quick.py <tag> [bench.py args...] (environment selects the variant)"""
+"""one short line per bench run: python tools/archive_r5/quick.py <tag> [bench.py args...] (environment selects the variant)"""
 import json
 import os
 import subprocess
