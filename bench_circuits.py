@@ -131,10 +131,11 @@ def _arithmetic_circuit(log_n: int, profile: str = "dense", workers: int = 0):
     n = 1 << log_n
     seed0 = {"dense": 0x5EED0001, "bench-like": 0x5EED0002}[profile]
     seg = min(n, 1 << 20)
-    jobs = [(profile, seed0 + 0x10000 * k, seg) for k in range(n // seg)]
+    jobs = [(profile, seed0 + 0x10000 * k, seg, log_n, k * seg) for k in range(n // seg)]
     if workers > 1 and len(jobs) > 1:
         # plain subprocesses of this file (no multiprocessing: nothing depends on the caller's __main__, no fork of a
-        # process that holds a GPU context); each writes its nine columns to a file
+        # process that holds a GPU context); each writes its eleven columns (nine gate columns + its rows of sigma_1 / sigma_3:
+        # round 5 — the permutation columns used to be 15 s of serial work in the parent at 2^22 gates) to a file
         import os
         import subprocess
         import sys
@@ -145,28 +146,38 @@ def _arithmetic_circuit(log_n: int, profile: str = "dense", workers: int = 0):
             running = []
             while pending or running:
                 while pending and len(running) < workers:
-                    k, (prof, seed, cnt) = pending.pop(0)
+                    k, (prof, seed, cnt, lg, first) = pending.pop(0)
                     path = os.path.join(tmp, f"chunk{k}.bin")
-                    running.append((k, path, subprocess.Popen([sys.executable, os.path.abspath(__file__), prof, str(seed), str(cnt), path])))
+                    running.append((k, path, subprocess.Popen([sys.executable, os.path.abspath(__file__), prof, str(seed), str(cnt), path,
+                                                               str(lg), str(first)])))
                 k, path, proc = running.pop(0)
                 if proc.wait(timeout=900) != 0:
                     raise RuntimeError("circuit chunk generator failed")
                 raw = open(path, "rb").read()
-                step = len(raw) // 9
-                parts[k] = [raw[i * step:(i + 1) * step] for i in range(9)]
+                step = len(raw) // 11
+                parts[k] = [raw[i * step:(i + 1) * step] for i in range(11)]
     else:
-        parts = [_arith_chunk(j) for j in jobs]
-    col = [b"".join(p[k] for p in parts) for k in range(9)]
+        parts = [_arith_chunk(j[:3]) + _sigma_chunk(j[3], j[4], j[2]) for j in jobs]
+    col = [b"".join(p[k] for p in parts) for k in range(11)]
     wires = col[:4]
-    T = _omega_table(log_n)
-    # inside a chain: sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_3[i] = w^(i+1) (Left(i+1)); chain ends map to themselves
-    s1 = [T[i] if i % seg == 0 else K2 * T[i - 1] % Q for i in range(n)]
-    s3 = [K2 * T[i] % Q if i % seg == seg - 1 else T[i + 1] for i in range(n)]
-    cols = {"s_sigma_1": _bytes(s1), "s_sigma_3": _bytes(s3)}
+    cols = {"s_sigma_1": col[9], "s_sigma_3": col[10]}
     for name, k in (("q_m", 4), ("q_l", 5), ("q_r", 6), ("q_f", 7), ("q_c", 8)):
         cols[name] = col[k]
     trivial = {"q_o": [Q - 1], "q_arith": [1], "s_sigma_2": [0, K1], "s_sigma_4": [0, K3]}
     return wires, cols, trivial
+
+
+def _sigma_chunk(log_n: int, first: int, cnt: int):
+    """sigma_1 / sigma_3 (evaluation form, Montgomery bytes) of the gate chain that occupies rows [first, first + cnt):
+    inside a chain sigma_1[i] = K2 w^(i-1) (Output(i-1)), sigma_3[i] = w^(i+1) (Left(i+1)); the chain's ends map to themselves."""
+    omega = pow(ROOT_OF_UNITY, 1 << (32 - log_n), Q)
+    t, T = R * pow(omega, first, Q) % Q, [0] * cnt          # T[j] = w^(first + j) * R
+    for j in range(cnt):
+        T[j] = t
+        t = t * omega % Q
+    s1 = [T[j] if j == 0 else K2 * T[j - 1] % Q for j in range(cnt)]
+    s3 = [K2 * T[j] % Q if j == cnt - 1 else T[j + 1] for j in range(cnt)]
+    return [_bytes(s1), _bytes(s3)]
 
 
 # ---- JubJub (the widgets only need the curve equation, not the subgroup) -----------------------------
@@ -409,9 +420,9 @@ def widget_columns(log_n: int, blk_log: int = 8, pool: int = 64) -> dict:
                 values=vals, columns=wires, public_inputs=pi)
 
 
-if __name__ == "__main__":   # chunk worker of arithmetic_circuit: <profile> <seed> <count> <output file>
+if __name__ == "__main__":   # chunk worker of arithmetic_circuit: <profile> <seed> <count> <output file> <log_n> <first row>
     import sys
     _prof, _seed, _cnt, _out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     with open(_out, "wb") as _f:
-        for _col in _arith_chunk((_prof, _seed, _cnt)):
+        for _col in _arith_chunk((_prof, _seed, _cnt)) + _sigma_chunk(int(sys.argv[5]), int(sys.argv[6]), _cnt):
             _f.write(_col)

@@ -58,9 +58,14 @@ def test_chunk_workers_equal_the_in_process_generator():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, "c.bin")
-        subprocess.check_call([sys.executable, BC.__file__, args[0], str(args[1]), str(args[2]), path])
+        subprocess.check_call([sys.executable, BC.__file__, args[0], str(args[1]), str(args[2]), path, "8", "64"])   # rows 64 .. 127 of a 2^8 domain
         raw = open(path, "rb").read()
-    assert raw == b"".join(direct)
+    assert raw == b"".join(direct + BC._sigma_chunk(8, 64, 64))      # nine gate columns + the chunk's rows of sigma_1 / sigma_3 (round 5)
+    # a chain of its own: sigma_1 maps the chain's first row to itself, sigma_3 its last row
+    T = BC._omega_table(8)
+    s1, s3 = BC._sigma_chunk(8, 64, 64)
+    assert s1[:32] == BC._bytes([T[64]]) and s1[32:64] == BC._bytes([BC.K2 * T[64] % BC.Q])
+    assert s3[-32:] == BC._bytes([BC.K2 * T[127] % BC.Q]) and s3[:32] == BC._bytes([T[65]])
     # the headline circuit is one chain from one stream: its digest is part of the bench line's stability
     w, c, t = BC.arithmetic_circuit(8, "dense")
     assert hashlib.blake2b(b"".join(w)).hexdigest()[:16] == hashlib.blake2b(b"".join(BC.arithmetic_circuit(8, "dense")[0])).hexdigest()[:16]
