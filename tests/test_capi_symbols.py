@@ -117,3 +117,20 @@ def test_integration_doc_accounts_for_every_entry_point():
         # the paragraph abbreviates families: `plonk_dev_alloc / _free / _h2d / _d2h / _sync`, `plonk_profile_enable / _read / _reset`
         family_tail = "_" + stem.split("_", 1)[1] if "_" in stem else ""
         assert name in rest or (family_tail and family_tail in rest), name
+
+
+def test_standin_transport_builds_and_exports_the_entry_points_comm_hip_resolves():
+    """tests/fake_rccl (test infrastructure): the nine nccl* symbols plonk_amd/csrc/comm.hip looks up with dlsym, by the same
+    names — read from comm.hip itself, so that a tenth symbol resolved there cannot be forgotten here."""
+    import subprocess
+    fake_dir = os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.check_call(["make", "-s", "-C", fake_dir])
+    wanted = set(re.findall(r'dlsym\(h, "(nccl\w+)"\)', open(os.path.join(ROOT, "plonk_amd", "csrc", "comm.hip")).read()))
+    assert len(wanted) == 9
+    lib = ctypes.CDLL(os.path.join(fake_dir, "libfakerccl.so"))
+    for name in wanted:
+        assert hasattr(lib, name), name
+    # and the product never names the stand-in: it is selected by path, by the tests
+    for f in os.listdir(os.path.join(ROOT, "plonk_amd", "csrc")):
+        assert "libfakerccl" not in open(os.path.join(ROOT, "plonk_amd", "csrc", f), errors="ignore").read(), f
+    assert "fakerccl" not in open(os.path.join(ROOT, "plonk_amd", "__init__.py")).read()
