@@ -99,19 +99,32 @@ def _cached(kind: str, log_n: int, profile: str, make):
         return make()
     import fcntl
     import pickle
-    os.makedirs(root, exist_ok=True)
     path = os.path.join(root, f"{kind}_{profile}_2p{log_n}_v1.pkl")
-    with open(path + ".lock", "w") as lock:
+    try:
+        os.makedirs(root, exist_ok=True)
+        lock = open(path + ".lock", "w")
+    except OSError:                      # cache directory unusable: generate as if there were none
+        return make()
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if os.path.exists(path):
-                with open(path, "rb") as f:
-                    return pickle.load(f)
+            try:
+                if os.path.exists(path):
+                    with open(path, "rb") as f:
+                        return pickle.load(f)
+            except (OSError, EOFError, pickle.UnpicklingError):
+                pass                     # unreadable entry: regenerate (and overwrite it below)
             out = make()
             tmp = path + f".tmp{os.getpid()}"
-            with open(tmp, "wb") as f:
-                pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
-            os.replace(tmp, path)
+            try:
+                with open(tmp, "wb") as f:
+                    pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
+                os.replace(tmp, path)
+            except OSError:              # disk full / read-only: the caller still gets its circuit
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
             return out
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
