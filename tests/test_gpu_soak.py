@@ -1,7 +1,7 @@
 """GPU: a short run of the randomized differential soak (tools/soak_parity.py): random circuits with every widget
 family and public inputs, random sizes 2^9..2^13 with constraint counts that are not powers of two, random
 blinders, alternating quotient domains, some witnesses corrupted — HIP prover and C restatement of the reference
-must agree on every proof byte and on every CircuitUnsatisfied.  (profiles/r02c + r02d soak_parity.txt: 1860 circuits over round 2, no disagreement.)"""
+must agree on every proof byte and on every CircuitUnsatisfied.  (profiles/r02c + r02d soak_parity.txt: 1860 circuits over round 2, profiles/r05/soak_parity.txt: 1050 on the round-5 library, no disagreement.)"""
 import os
 import subprocess
 import sys

@@ -28,10 +28,6 @@ for it in range(N):
     log_n = rnd.choice((9, 10, 11, 12, 12, 13))
     n = 1 << log_n
     domain8 = bool(it & 1)
-    if domain8:
-        os.environ["PLONK_QUOTIENT_DOMAIN"] = "8"
-    else:
-        os.environ.pop("PLONK_QUOTIENT_DOMAIN", None)
     ngates = rnd.randrange(n // 2 + 9, n + 1)          # constraints need not be a power of two
     comp = C.big_widget_circuit(ngates, seed=rnd.getrandbits(32))()
     case = C.compile_fast(comp, b"soak-%d" % it)
@@ -39,7 +35,7 @@ for it in range(N):
     if log_n not in srs_cache:
         srs_cache[log_n] = C.synthetic_srs(n + 7)
     srs = srs_cache[log_n]
-    ctx = plonk_amd.Context(0)
+    ctx = plonk_amd.Context(0, plonk_amd.GpuConfig(quotient_domain=8 if domain8 else 4))   # plonk_gpu_config, not the environment
     ctx.srs_load_bytes(srs, n + 7)
     cp = cbind.CProver(case["constraints"], case["label"], case["polys"], srs)
     cols = C.circuit_columns(comp) if from_circuit else None
@@ -48,6 +44,7 @@ for it in range(N):
     else:
         gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], None)
     assert gp.vk_commitments() == cp.vk(), ("vk", it)
+    assert gp.describe()["quotient_domain"] == (8 if domain8 else 4), ("quotient domain not honoured", it)
     bl = C.blinders(rnd.getrandbits(32))
     wires = list(case["wires"])
     corrupt = rnd.random() < 0.15
