@@ -94,8 +94,14 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
         # 2 / 4 ranks: every rank takes the WHOLE Lagrange-basis key and commits to whole wire columns instead of a point range
         # of every column (prover.hip lag_whole; DESIGN.md section 5: rank alone at 2^20, same box, 18.34 -> 17.98 ms for W = 2,
         # 9.08 -> 8.68 for W = 4; 32 GiB of table per rank).  PLONK_BENCH_WIRE_SPLIT=range restores the split by point range.
-        build_prover.wire_split = "commitment" if (world in (2, 4) and os.environ.get("PLONK_BENCH_WIRE_SPLIT", "commitment") == "commitment") else "range"
+        # (tests only: a comma-separated list gives every rank its own split — ranks that DISAGREE must be refused by the library)
+        split = os.environ.get("PLONK_BENCH_WIRE_SPLIT", "commitment").split(",")
+        build_prover.wire_split = "commitment" if (world in (2, 4) and split[rank % len(split)] == "commitment") else "range"
         lag_slice = key if build_prover.wire_split == "commitment" else key[96 * llo:96 * lhi]
+        if os.environ.get("PLONK_BENCH_CORRUPT_LAGRANGE") == str(rank) and len(lag_slice) >= 192:
+            # (tests only) two points of this rank's key swapped: every point is still on the curve and in the subgroup, but the
+            # key is no longer the Lagrange-basis form of the commit key — the check at prover creation must say so
+            lag_slice = lag_slice[96:192] + lag_slice[:96] + lag_slice[192:]
         del key
     # the rank's slice of the commit key is produced once (on the device: the reference's setup is O(n * 255)
     # group operations), parked in PINNED HOST memory like a key read from disk, and then STREAMED into the

@@ -99,7 +99,9 @@ typedef struct plonk_gpu_config {
   int32_t ntt_elements_log2;     /* 0 = default (2: four elements per lane; side-stream transforms under a busy MSM: 3), 2, 3 */
   int32_t comm_timeout_ms;       /* 0 = 120000: how long a wait behind a collective polls before the communicator is aborted */
   int32_t side_stream_cus;       /* 0 = none; k > 0: the side stream (challenge-independent transforms under the commitments) is confined
-                                    to k compute units by a CU mask and uses the four-wave NTT kernels there; the main stream keeps all */
+                                    to k compute units by a CU mask and uses the four-wave NTT kernels there; the main stream keeps all.
+                                    The masked stream (hipExtStreamCreateWithCUMask) has DEFAULT priority and blocking semantics
+                                    against the NULL stream — not the low priority / non-blocking flags of the stream it replaces */
 } plonk_gpu_config;
 int plonk_ctx_create_ex(plonk_ctx** out, int device, const plonk_gpu_config* config /* NULL = defaults */);
 int plonk_ctx_get_config(plonk_ctx* ctx, plonk_gpu_config* out /* struct_size set by the caller */);
@@ -111,7 +113,7 @@ int plonk_ctx_set_config(plonk_ctx* ctx, const plonk_gpu_config* config);
  * 2^19-bucket kernels have), 0: as plonk_msm_dev (final sum on the device, 2^15 buckets) — and what the LAST one did run as
  * (plonk_ctx_last_msm).  The variant tests assert these, so a switch that is silently
  * ignored fails a test. */
-enum { PLONK_PLAN_TAIL_SERIAL = 1, PLONK_PLAN_BUCKET_SUM_LANE = 2, PLONK_PLAN_ACCUMULATE_LDS = 4, PLONK_PLAN_SORT13 = 8, PLONK_PLAN_ROWCOL_AFFINE = 16 };
+enum { PLONK_PLAN_TAIL_SERIAL = 1, PLONK_PLAN_BUCKET_SUM_LANE = 2, PLONK_PLAN_ACCUMULATE_LDS = 4, PLONK_PLAN_SORT13 = 8 };
 typedef struct plonk_msm_plan {
   uint32_t table_rows;           /* 16 window rows / 128 / 256 bit-position rows of the key */
   uint32_t bucket_bits;          /* 15 or 19 (17: opt-in A/B build) */
@@ -367,13 +369,21 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  * plonk_comm_library writes the path of what was actually loaded (NUL-terminated, truncated to cap); a host program that
  * reports which collective a measurement used must take it from here (bench.py prints "rccl" only for a librccl file).
  * After a time-out whose abort did not drain the stream (or a transport without ncclCommAbort) the context is UNUSABLE:
- * sharded proofs and plonk_comm_init return PLONK_ERR_STATE; destroy it. */
+ * every entry point that queues work on the context or waits for it (transforms, commitments, key loads, copies, provers,
+ * plonk_comm_init) returns PLONK_ERR_STATE at once instead of queueing behind the dead collective; destroy it.  The destroy
+ * calls (plonk_prover_destroy, plonk_comm_destroy, plonk_ctx_destroy) poll the streams for at most 2 s and, if they are still
+ * busy, ABANDON the context's device memory, streams and pinned buffers instead of freeing them — hipFree and
+ * hipStreamSynchronize would wait for the dead kernel for ever; plonk_comm_destroy then returns PLONK_ERR_STATE.  A host that
+ * wants the memory back resets the device (hipDeviceReset) or exits.
+ * plonk_comm_warning: the note plonk_comm_init left on this context when it SUCCEEDED with something to say (today: the
+ * dmabuf IPC variable missing from the environment), "" otherwise — a successful call never writes plonk_last_error(). */
 int plonk_comm_set_library(const char* path);
 int plonk_comm_library(char* out, uint64_t cap);
 int plonk_comm_measure_loopback(plonk_ctx* ctx, int on);
 int plonk_comm_unique_id(uint8_t out[128]);
 int plonk_comm_init(plonk_ctx* ctx, const uint8_t unique_id[128], int rank, int world);
 int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world);
+int plonk_comm_warning(plonk_ctx* ctx, char* out, uint64_t cap);
 int plonk_comm_selftest(plonk_ctx* ctx);
 int plonk_comm_destroy(plonk_ctx* ctx);
 

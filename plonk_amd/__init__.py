@@ -52,7 +52,7 @@ EXPORTS = [
     "plonk_prover_prove", "plonk_prover_prove_dev", "plonk_prover_peek",
     "plonk_prover_blob_check", "plonk_prover_from_bytes", "plonk_srs_validate",
     "plonk_comm_unique_id", "plonk_comm_init", "plonk_comm_info", "plonk_comm_selftest", "plonk_comm_destroy",
-    "plonk_comm_measure_loopback", "plonk_prover_set_version", "plonk_comm_set_library", "plonk_comm_library",
+    "plonk_comm_measure_loopback", "plonk_comm_warning", "plonk_prover_set_version", "plonk_comm_set_library", "plonk_comm_library",
     "plonk_ctx_create_ex", "plonk_ctx_get_config", "plonk_ctx_set_config", "plonk_ctx_describe_msm", "plonk_ctx_last_msm",
     "plonk_ctx_table_bytes", "plonk_prover_describe",
     "plonk_host_alloc", "plonk_host_free", "plonk_lagrange_key",
@@ -65,7 +65,7 @@ POLY_ORDER = ["q_m", "q_l", "q_r", "q_o", "q_f", "q_c", "q_arith", "q_range", "q
 
 
 TABLE_AUTO, TABLE_WINDOW, TABLE_HALFPOS, TABLE_BITPOS = 0, 16, 128, 256
-PLAN_TAIL_SERIAL, PLAN_BUCKET_SUM_LANE, PLAN_ACCUMULATE_LDS, PLAN_SORT13, PLAN_ROWCOL_AFFINE = 1, 2, 4, 8, 16
+PLAN_TAIL_SERIAL, PLAN_BUCKET_SUM_LANE, PLAN_ACCUMULATE_LDS, PLAN_SORT13 = 1, 2, 4, 8
 
 
 class GpuConfig(ctypes.Structure):
@@ -234,6 +234,7 @@ def load_library() -> ctypes.CDLL:
     lib.plonk_comm_selftest.argtypes = [vp]
     lib.plonk_comm_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.plonk_comm_destroy.argtypes = [vp]
+    lib.plonk_comm_warning.argtypes = [vp, vp, u64]
     lib.plonk_comm_measure_loopback.argtypes = [vp, ci]
     lib.plonk_ctx_create_ex.argtypes = [ctypes.POINTER(vp), ci, ctypes.POINTER(GpuConfig)]
     lib.plonk_ctx_get_config.argtypes = [vp, ctypes.POINTER(GpuConfig)]
@@ -590,6 +591,12 @@ class Context:
         r, w = ctypes.c_int(-1), ctypes.c_int(-1)
         self._check(self.lib.plonk_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w)))
         return r.value, w.value
+
+    def comm_warning(self) -> str:
+        """The note plonk_comm_init left on this context ("" = none); a successful call never writes the last-error text."""
+        out = ctypes.create_string_buffer(512)
+        self._check(self.lib.plonk_comm_warning(self.handle, out, 512))
+        return out.value.decode()
 
     def comm_selftest(self):
         self._check(self.lib.plonk_comm_selftest(self.handle))

@@ -1,7 +1,9 @@
 // C-ABI of libplonk_hip.so (see include/plonk_hip.h for the contract and the
 // reference interfaces each entry point replaces).
+#include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "plonk_internal.hpp"
 #include "hostg1.hpp"
@@ -15,6 +17,27 @@ void set_last_error(const char* what, const char* detail, const char* file, int 
 }
 
 int srs_generate_device(Ctx* c, const Fr& tau, const Fr& g_scalar, uint64_t n, G1Affine* out_dev);
+
+int ctx_refuse_poisoned(const char* api_fn) {
+  set_last_error(api_fn, "context unusable: a collective timed out and its stream never drained (comm_sync); destroy the context", __FILE__, __LINE__);
+  return PLONK_ERR_STATE;
+}
+
+// Destroy paths of a poisoned context: hipStreamSynchronize, hipFree (an implicit device-wide wait) and
+// hipStreamDestroy would all block behind the dead collective — the hang comm_sync's bounded drain exists to prevent.  Poll
+// both streams for at most 2 s; if they are still busy the caller LEAKS the context's device memory, streams and pinned
+// buffers (the process is expected to exit or hipDeviceReset; a leak is recoverable, a hung destructor is not).
+bool ctx_abandon(Ctx* c) {
+  if (!c->comm_poisoned) return false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const bool busy = (c->main_stream && hipStreamQuery(c->main_stream) == hipErrorNotReady) ||
+                      (c->side_stream && hipStreamQuery(c->side_stream) == hipErrorNotReady);
+    if (!busy) return false;   // drained after all: the ordinary teardown is safe
+    if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) return true;
+    std::this_thread::sleep_for(std::chrono::microseconds(500));
+  }
+}
 
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]) {
   G1Affine a;
@@ -52,6 +75,11 @@ static void prof_release(Ctx* c) {   // plonk_ctx_destroy: the context's event p
   }
   for (hipEvent_t e : ps->pool) (void)hipEventDestroy(e);
   delete ps;
+}
+static void prof_forget(Ctx* c) {    // abandoned context: drop the bookkeeping, leave the events alone
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  auto it = g_prof.find(c);
+  if (it != g_prof.end()) { delete it->second; g_prof.erase(it); }
 }
 static hipEvent_t prof_event(ProfState* ps) {
   if (ps->used == ps->pool.size()) {
@@ -169,7 +197,6 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   g.rcwv = env_int("PLONK_MSM_RCWV", 0);
   if (const char v = env_chr("PLONK_MSM_SORT13")) g.sort13 = v == '1' ? 1 : 0;
   g.acc_wg = env_int("PLONK_MSM_ACC_WG", 0);
-  if (const char v = env_chr("PLONK_MSM_RCAFFINE")) g.rc_affine = v == '1' ? 1 : 0;
   g.ntt_direct = env_chr("PLONK_NTT_DIRECT") != '0';
   g.bi_cfg = env_int("PLONK_BI_CFG", -1);
   if (const char v = env_chr("PLONK_SIDE_DEFER")) g.side_defer = v == '1' ? 1 : (v == '2' ? 2 : 0);
@@ -219,6 +246,10 @@ static int side_stream_partition(Ctx* c) {
     if ((int64_t)i * k / ncu != (int64_t)(i + 1) * k / ncu) side[i / 32] |= 1u << (i % 32);
   hipStream_t ss = nullptr;
   if (hipExtStreamCreateWithCUMask(&ss, (uint32_t)words, side.data()) != hipSuccess) return (set_last_error("hipExtStreamCreateWithCUMask", "side stream", __FILE__, __LINE__), PLONK_ERR_HIP);
+  // NOTE: hipExtStreamCreateWithCUMask takes neither flags nor a priority — the masked stream has DEFAULT priority and is a
+  // blocking stream (it synchronises with the NULL stream), unlike the low-priority non-blocking side stream it replaces.
+  // The library never uses the NULL stream, and the option is an A/B switch that measured slower at every mask size
+  // (DESIGN.md 7.5), so this is documented (include/plonk_hip.h, side_stream_cus) rather than compensated.
   (void)hipStreamDestroy(c->side_stream);
   c->side_stream = ss;
   return PLONK_OK;
@@ -303,12 +334,12 @@ int plonk_ctx_set_config(plonk_ctx* ctx, const plonk_gpu_config* config) {
   if (!ctx) return PLONK_ERR_ARG;
   { const int rc = config_check(config, api_fn); if (rc) return rc; }
   std::lock_guard<std::mutex> lk(ctx->c.mu);
-  const int cus_before = ctx->c.cfg.side_cus;
-  config_resolve(config, ctx->c.device, &ctx->c.cfg);
-  if (ctx->c.cfg.side_cus != cus_before) {   // streams are created once: the partition of the CUs is fixed at creation
-    ctx->c.cfg.side_cus = cus_before;
+  // resolve into a temporary, validate, THEN commit (a rejected call used to leave every other field replaced)
+  Config next;
+  config_resolve(config, ctx->c.device, &next);
+  if (next.side_cus != ctx->c.cfg.side_cus)   // streams are created once: the partition of the CUs is fixed at creation
     return (set_last_error("plonk_ctx_set_config", "side_stream_cus can only be chosen at plonk_ctx_create_ex", __FILE__, __LINE__), PLONK_ERR_STATE);
-  }
+  ctx->c.cfg = next;
   return PLONK_OK;
   });
 }
@@ -362,6 +393,11 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   (void)plonk_comm_destroy(ctx);
   Ctx& c = ctx->c;
   (void)hipSetDevice(c.device);
+  if (ctx_abandon(&c)) {   // poisoned and still busy: every wait / hipFree / hipStreamDestroy below would hang — leak the device side
+    prof_forget(&c);
+    delete ctx;
+    return;
+  }
   (void)hipStreamSynchronize(c.stream);
   for (auto& kv : c.ntt_tables) {
     NttTables* t = kv.second;
@@ -404,7 +440,7 @@ int plonk_dev_free(plonk_ctx* ctx, void* p) {
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   HIP_TRY(hipFree(p));
@@ -415,7 +451,7 @@ int plonk_dev_h2d(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->c.main_stream));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
@@ -426,7 +462,7 @@ int plonk_dev_d2h(plonk_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!dst && bytes) || (!src && bytes)) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->c.main_stream));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
@@ -437,7 +473,7 @@ int plonk_dev_sync(plonk_ctx* ctx) {
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   HIP_TRY(hipStreamSynchronize(ctx->c.main_stream));
   return PLONK_OK;
@@ -451,7 +487,7 @@ int plonk_ntt_dev(plonk_ctx* ctx, const void* src, void* dst, void* tmp, uint32_
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !src || !dst || log_n >= 28) return PLONK_ERR_ARG;
   if (log_n > 10 && !tmp) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   prof_begin(&ctx->c, 0);
   int rc = ntt_device(&ctx->c, (const Fr*)src, (Fr*)dst, (Fr*)tmp, log_n, inverse != 0, coset != 0, in_len);
@@ -465,7 +501,7 @@ int plonk_ntt(plonk_ctx* ctx, uint64_t* a, uint32_t log_n, int inverse, int cose
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !a || log_n >= 28) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   const uint64_t n = 1ull << log_n;
   if (in_len > n) in_len = n;
@@ -493,7 +529,7 @@ int plonk_ntt_batch(plonk_ctx* ctx, uint64_t* const* a, int count, uint32_t log_
   for (int i = 0; i < count; ++i) if (!a[i]) return PLONK_ERR_ARG;
   if (count == 0) return PLONK_OK;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   const uint64_t n = 1ull << log_n;
   int rc = ensure_ntt_staging(&c, n);
@@ -540,7 +576,7 @@ int plonk_srs_load_dev(plonk_ctx* ctx, const void* xy96_dev, uint64_t npoints) {
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!xy96_dev && npoints)) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   return srs_load_device(&ctx->c, (const G1Affine*)xy96_dev, npoints);
   });
@@ -557,7 +593,7 @@ int plonk_srs_load(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   int rc = srs_table_begin(&c, npoints);
   if (rc || npoints == 0) return rc;
@@ -623,7 +659,7 @@ int plonk_srs_validate(plonk_ctx* ctx, const uint8_t* xy96, uint64_t npoints) {
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!xy96 && npoints)) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   G1Affine* tmp = nullptr;
   int* flag = nullptr;
@@ -649,7 +685,7 @@ int plonk_srs_generate_dev(plonk_ctx* ctx, const uint64_t tau[4], const uint64_t
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !tau || !g_scalar || !out_dev) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   Fr t, g;
   memcpy(&t, tau, 32);
@@ -663,7 +699,7 @@ int plonk_lagrange_key(plonk_ctx* ctx, uint32_t log_n, uint8_t* out_xy96) {
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !out_xy96 || log_n >= 27) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   const uint64_t n = 1ull << log_n;
   G1Affine* pts = nullptr;
@@ -680,7 +716,7 @@ int plonk_msm_dev(plonk_ctx* ctx, const void* scalars, uint64_t m, void* out97_d
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!scalars && m) || !out97_dev) return PLONK_ERR_ARG;
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   int rc = msm_reserve(&ctx->c, m ? m : 1);
   if (rc) return rc;
@@ -695,7 +731,7 @@ int plonk_msm(plonk_ctx* ctx, const uint64_t* scalars, uint64_t m, uint8_t out_x
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || (!scalars && m) || !out_xy_inf) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   if (m && !c.srs_table) return PLONK_ERR_NO_SRS;
   if (m > c.srs_n) return PLONK_ERR_DEGREE;
@@ -726,7 +762,7 @@ int plonk_msm_batch(plonk_ctx* ctx, const uint64_t* const* scalars, const uint64
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !scalars || !m || !out || count < 0) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   uint64_t mmax = 0;
   for (int i = 0; i < count; ++i) {

@@ -335,11 +335,15 @@ int plonk_comm_init(plonk_ctx* ctx, const uint8_t id128[128], int rank, int worl
   c.nccl_comm = comm;
   c.comm_rank = rank;
   c.comm_world = world;
-  {   // the communicator can come up without the variable and fail later, inside an IPC exchange nobody annotates
+  // the communicator can come up without the variable and fail later, inside an IPC exchange nobody
+  // annotates.  A call that SUCCEEDS must not leave text in the thread's last-error string (a later failure that sets none
+  // would report it): the note is kept per context and read with plonk_comm_warning.
+  {
     const char* ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
-    if (world > 1 && !(ipc && ipc[0] == '0'))
-      set_last_error("plonk_comm_init: warning", "HSA_ENABLE_IPC_MODE_LEGACY=0 is not in the environment; on a dmabuf-only driver device-memory "
-                     "exchange between processes fails later with hipIpcGetMemHandle: invalid argument — export it before the first HIP call", __FILE__, __LINE__);
+    c.comm_warning = (world > 1 && !(ipc && ipc[0] == '0'))
+        ? "HSA_ENABLE_IPC_MODE_LEGACY=0 is not in the environment; on a dmabuf-only driver device-memory exchange between "
+          "processes fails later with hipIpcGetMemHandle: invalid argument — export it before the first HIP call"
+        : "";
   }
   return PLONK_OK;
   });
@@ -353,6 +357,16 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   std::lock_guard<std::mutex> lk(c.mu);
   if (!c.nccl_comm && !c.comm_send && !c.comm_recv && !c.comm_send_host) return PLONK_OK;
   (void)hipSetDevice(c.device);
+  if (ctx_abandon(&c)) {
+    // the dead collective still holds the stream: waiting for it, hipFree (device-wide wait) or ncclCommDestroy would hang.
+    // The staging buffers are leaked on purpose — the copies queued behind the collective may still target them.
+    c.nccl_comm = nullptr;
+    c.comm_send = c.comm_recv = c.comm_send_host = c.comm_recv_host = nullptr;
+    c.comm_world = 1;
+    c.comm_rank = 0;
+    set_last_error("plonk_comm_destroy", "context unusable (collective time-out, stream never drained): staging buffers abandoned, not freed", __FILE__, __LINE__);
+    return PLONK_ERR_STATE;
+  }
   (void)hipStreamSynchronize(c.main_stream);
   if (c.nccl_comm) {   // (already gone after a time-out abort in comm_sync: only the staging buffers are left to free)
     RcclApi* api = rccl_api();
@@ -366,6 +380,17 @@ int plonk_comm_destroy(plonk_ctx* ctx) {
   c.comm_send = c.comm_recv = c.comm_send_host = c.comm_recv_host = nullptr;
   c.comm_world = 1;
   c.comm_rank = 0;
+  return PLONK_OK;
+  });
+}
+
+// The note plonk_comm_init left on this context ("" = none); NUL-terminated, truncated to cap.
+int plonk_comm_warning(plonk_ctx* ctx, char* out, uint64_t cap) {
+  const char* const api_fn = __func__;
+  return plonk::api_guard(api_fn, [&]() -> int {
+  if (!ctx || !out || cap == 0) return PLONK_ERR_ARG;
+  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  snprintf(out, (size_t)cap, "%s", ctx->c.comm_warning);
   return PLONK_OK;
   });
 }
@@ -396,7 +421,7 @@ int plonk_comm_selftest(plonk_ctx* ctx) {
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx) return PLONK_ERR_ARG;
   Ctx& c = ctx->c;
-  std::lock_guard<std::mutex> lk(c.mu);
+  CTX_ENTER(c, api_fn);
   HIP_TRY(hipSetDevice(c.device));
   if (!c.nccl_comm) return (set_last_error("plonk_comm_selftest", "no communicator", __FILE__, __LINE__), PLONK_ERR_STATE);
   CommLink l;

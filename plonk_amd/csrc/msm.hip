@@ -1551,8 +1551,10 @@ int msm_reserve(Ctx* c, uint64_t m) {
     HIP_TRY(hipHostMalloc((void**)&w.result_host, sizeof(G1) * MSM_BIT_SUMS * KB, hipHostMallocDefault));
     w.fixed_ok = true;
   }
-  if (m > w.cap_m) {
-    const uint64_t cap = m;
+  //  the slice capacity depends on the forced slice length too: plonk_ctx_set_config may lower cfg.ksl after the
+  // buffers were sized — re-size whenever what this m needs exceeds what `partial` holds, not only when m grows
+  if (m > w.cap_m || msm_slice_cap(c, w.cap_m) > w.cap_slices) {
+    const uint64_t cap = m > w.cap_m ? m : w.cap_m;
     // release first (the stream may still be reading the old buffers), and forget the old capacity so
     // that a failed reallocation cannot leave a stale cap_m pointing at freed memory
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -25,6 +25,16 @@
 namespace plonk {
 
 void set_last_error(const char* what, const char* detail, const char* file, int line);
+struct Ctx;
+// A context whose collective timed out without its stream ever draining (comm_sync, Ctx::comm_poisoned) has a dead kernel at
+// the head of its main stream: anything queued behind it never runs and anything that waits for the stream never returns.
+// Every entry point that queues work on a context or waits for it therefore goes in through CTX_ENTER (the mutex + a
+// refusal with PLONK_ERR_STATE), and the destroy paths ask ctx_abandon() whether the device side has to be leaked.
+int ctx_refuse_poisoned(const char* api_fn);          // capi.hip: sets the last-error text, returns PLONK_ERR_STATE
+bool ctx_abandon(Ctx* c);                             // capi.hip: poisoned AND the streams did not drain within a bounded poll
+#define CTX_ENTER(C, FN)                      \
+  std::lock_guard<std::mutex> lk((C).mu);     \
+  if ((C).comm_poisoned) return plonk::ctx_refuse_poisoned(FN)
 
 struct NttTables {
   Fr* tw_lo = nullptr;         // w_N^e, e < 2^min(L,13)
@@ -158,7 +168,6 @@ struct Config {
   int rcwv = 0;                     // PLONK_MSM_RCWV
   int sort13 = -1;                  // PLONK_MSM_SORT13=0/1: 13-digit staging of the 2^19-bucket partition (round 5)
   int acc_wg = 0;                   // PLONK_MSM_ACC_WG=64: threads per workgroup of the ordered accumulation (A/B)
-  int rc_affine = -1;               // PLONK_MSM_RCAFFINE=0/1: affine buckets in the row / column sums (round 5)
   bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
@@ -209,6 +218,7 @@ struct Ctx {
   uint8_t* comm_send_host = nullptr;   // pinned twins of the two staging buffers: the host legs of a small all-gather never block
   uint8_t* comm_recv_host = nullptr;   // inside hipMemcpyAsync behind a collective (comm.hip comm_allgather_host)
   int comm_rank = 0, comm_world = 1;
+  const char* comm_warning = "";   // static text left by plonk_comm_init (plonk_comm_warning); never the last-error string
   bool comm_poisoned = false;      // comm_sync timed out and the stream never drained: sharded proofs and new communicators are refused
   bool comm_loopback = false;      // measurement only: collectives return the rank's own contribution (plonk_comm_measure_loopback)
   // instrumentation: hipEvent pairs around the dominant kernels

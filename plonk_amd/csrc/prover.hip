@@ -211,7 +211,7 @@ static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int
   return rc;
 }
 static int msm_to(Prover* p, const Fr* scalars, uint64_t m, int slot) { return msm_group(p, &scalars, &m, 1, slot); }
-static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48]);
+static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48], uint32_t local_mask = 0);
 
 // A Lagrange-basis key handed in by the caller (plonk_prover_desc.lagrange_xy96, kept from an earlier plonk_lagrange_key)
 // must be THE Lagrange form of the context's commit key — a key cached from another SRS would give wire commitments that
@@ -231,18 +231,35 @@ __global__ void lag_check_fill_kernel(Fr* r, uint64_t count, uint64_t seed) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) r[i] = Fr::from_u64(lag_check_mix(i, seed));
 }
+// Sharded provers (round 6): the same identity over the ranks.  Every rank fills the same r (rank 0's seed,
+// all-gathered); a rank holding its SLICE of the key sums r over it and the partial sums are added like any sharded
+// commitment; a rank holding the WHOLE key (wire group by column) sums all of it and compares its own sum (local_mask).  The
+// coefficient-form commitment is sharded by point range as always.  So the union of the slices — or every rank's copy of
+// the whole key — is checked against the union of the commit-key slices, which round 5 could not do ("only the points
+// themselves can be checked here").
 static int check_lagrange_key(Prover* p, uint32_t L) {
   Ctx* c = p->c;
   const uint64_t n = 1ull << L;
   Fr* r = p->agg;        // n + 2 values
   Fr* coef = p->wit;     // n + 2 coefficients
   std::random_device rd;
-  const uint64_t seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)rd() << 17);
+  uint64_t seed = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ ((uint64_t)rd() << 17);
+  if (p->world > 1) {
+    PTRY(comm_allgather_host(c, p->link, &seed, p->gather_host, sizeof seed));
+    memcpy(&seed, p->gather_host, sizeof seed);   // rank 0's
+  }
   hipLaunchKernelGGL(lag_check_fill_kernel, dim3((uint32_t)((n + 2 + 255) / 256)), dim3(256), 0, c->stream, r, n + 2, seed);
   HIP_TRY(hipGetLastError());
-  uint64_t m = n + 2;
-  const Fr* sc = r;
-  PTRY(msm_group(p, &sc, &m, 1, 0, p->lag_table, p->lag_n));
+  const bool slice = p->world > 1 && !p->lag_whole;
+  uint64_t m = slice ? p->lag_n : n + 2;
+  const Fr* sc = slice ? r + p->shard_lo : r;
+  if (m && p->lag_table) {
+    PTRY(msm_group(p, &sc, &m, 1, 0, p->lag_table, p->lag_n));
+  } else {   // an empty slice: the identity (all-zero bit sums)
+    HIP_TRY(hipMemsetAsync(p->res, 0, (size_t)RES_STRIDE, c->stream));
+    p->res_bitpos[0] = false;
+    p->res_rowbits[0] = 8;
+  }
   PTRY(ntt_device(c, r, coef, p->wit2, L, true, false, n));
   BlindArgs ba;
   ba.count = 2;
@@ -252,15 +269,23 @@ static int check_lagrange_key(Prover* p, uint32_t L) {
   PTRY(poly_blind(c, coef, n, ba));     // coef -= (b0 + b1 X), coef[n], coef[n + 1] = b0, b1: + (b0 + b1 X)(X^n - 1)
   PTRY(msm_to(p, coef, n + 2, 1));
   uint8_t out[2][48];
-  PTRY(fetch_commitments(p, 0, 2, out));
-  if (memcmp(out[0], out[1], 48) != 0)
+  PTRY(fetch_commitments(p, 0, 2, out, p->lag_whole ? 1u : 0u));
+  bool bad = memcmp(out[0], out[1], 48) != 0;
+  if (p->world > 1 && p->lag_whole) {   // whole keys are compared per rank: share the verdict, so that no rank walks on into a collective its failed peer never enters
+    uint8_t mine = bad ? 1 : 0;
+    PTRY(comm_allgather_host(c, p->link, &mine, p->gather_host, 1));
+    for (uint32_t r = 0; r < p->world; ++r) bad = bad || p->gather_host[r] != 0;
+  }
+  if (bad)
     return (plonk::set_last_error("lagrange_xy96", "not the Lagrange-basis form of this context's commit key", __FILE__, __LINE__), PLONK_ERR_DATA);
   return PLONK_OK;
 }
 // Bring `count` results to the host, all-gather the per-rank partial sums (EC addition is not
 // an RCCL reduction, so the "bucket-sum all-reduce" is an all-gather + local add), normalise
 // to affine on the host (one Fp inversion each) and compress.
-static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48]) {
+// local_mask: bit i set = slot first + i is NOT summed over the ranks — it holds a sum this rank computed whole (the
+// Lagrange-key check of a rank that holds the whole key); the all-gather still runs (every rank calls in the same order).
+static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48], uint32_t local_mask) {
   Ctx* c = p->c;
   HIP_TRY(hipMemcpyAsync(p->res_host + RES_STRIDE * first, p->res + RES_STRIDE * first, RES_STRIDE * (size_t)count,
                          hipMemcpyDeviceToHost, c->stream));
@@ -274,6 +299,7 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
     const size_t bytes = sizeof(G1) * (size_t)count;
     PTRY(comm_allgather_host(c, p->link, sums.data(), p->gather_host, bytes));
     for (int i = 0; i < count; ++i) {
+      if (local_mask >> i & 1) continue;
       G1 acc = G1::identity();
       for (int r = 0; r < p->world; ++r) {
         G1 part;
@@ -652,6 +678,20 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
       p->lag_n = want;
       p->lag_on = true;
       HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
+    }
+    if (p->world > 1) {
+      // every rank derives its mode from ITS OWN descriptor — no key (coefficient-form wire commitments), its slice,
+      // or the whole key (wire group by column).  Ranks that disagree would add whole-column commitments to point-range partial
+      // sums (or Lagrange-form to coefficient-form ones): silently wrong a / b / c / d commitments that the prover's own identity
+      // check cannot see.  One byte per rank settles it before the first proof.
+      uint8_t mine = p->lag_whole ? 2 : (p->lag_on ? 1 : 0);
+      PTRY(comm_allgather_host(c, p->link, &mine, p->gather_host, 1));
+      for (uint32_t r = 0; r < p->world; ++r)
+        if (p->gather_host[r] != mine)
+          return (plonk::set_last_error("plonk_prover_desc.lagrange_xy96 / lagrange_count",
+                                        "the ranks disagree on the wire-commitment mode (no Lagrange-basis key / the rank's slice / the whole key): "
+                                        "every rank of a sharded prover must pass the same kind", __FILE__, __LINE__), PLONK_ERR_ARG);
+      if (mine && !c->comm_loopback) PTRY(check_lagrange_key(p, L));   // (loop-back measurement: the gathered sums are wrong by construction)
     }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1590,7 +1630,7 @@ int plonk_prover_create(plonk_ctx* ctx, const plonk_prover_desc* desc, plonk_pro
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !desc || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   if (!ctx->c.srs_table && desc->shard_world <= 1) return PLONK_ERR_NO_SRS;
   plonk::Prover* p = nullptr;
@@ -1607,7 +1647,7 @@ int plonk_compile(plonk_ctx* ctx, const plonk_circuit_desc* circuit, plonk_prove
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!ctx || !circuit || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
-  std::lock_guard<std::mutex> lk(ctx->c.mu);
+  CTX_ENTER(ctx->c, api_fn);
   HIP_TRY(hipSetDevice(ctx->c.device));
   if (!ctx->c.srs_table && circuit->shard_world <= 1) return PLONK_ERR_NO_SRS;
   plonk_prover_desc d{};
@@ -1640,8 +1680,12 @@ void plonk_prover_destroy(plonk_prover* pr) {
   {
     std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
     (void)hipSetDevice(pr->ctx->c.device);
-    (void)hipStreamSynchronize(pr->ctx->c.stream);
-    prover_free(pr->p);
+    if (ctx_abandon(&pr->ctx->c)) {   // poisoned context, streams still busy: hipFree / hipStreamSynchronize would hang — leak the device buffers
+      delete pr->p;
+    } else {
+      (void)hipStreamSynchronize(pr->ctx->c.stream);
+      prover_free(pr->p);
+    }
   }
   delete pr;
 }
@@ -1694,7 +1738,7 @@ int plonk_prover_peek(plonk_prover* pr, int which, uint64_t offset, uint64_t cou
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!pr || !out) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
   plonk::Prover* p = pr->p;
-  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  CTX_ENTER(pr->ctx->c, api_fn);
   const Fr* base[] = {p->wpoly, p->zpoly, p->pipoly, p->cos, p->tbuf, p->tparts, p->agg, p->wit,
                       p->evals8, p->sigma_n, p->scratch, p->evout, p->polys};
   const uint64_t cap[] = {4 * p->np, p->np, p->np, 6 * p->qn, p->sharded ? p->np : p->n8, 3 * p->np, p->np, p->np,
@@ -1712,7 +1756,7 @@ int plonk_prover_prove_dev(plonk_prover* pr, const void* wires_dev, const uint64
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!pr || !wires_dev || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
-  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  CTX_ENTER(pr->ctx->c, api_fn);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   return prover_prove(pr->p, (const Fr*)wires_dev, pi_idx, (const Fr*)pi_val, pi_count, (const Fr*)blinders, proof);
   });
@@ -1750,7 +1794,7 @@ int plonk_prover_to_bytes(plonk_prover* pr, uint8_t* out, uint64_t cap, uint64_t
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!pr || !len) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
-  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  CTX_ENTER(pr->ctx->c, api_fn);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   Ctx* c = p->c;
@@ -1876,7 +1920,7 @@ int plonk_prover_prove_witnesses(plonk_prover* pr, const uint64_t* witnesses, ui
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!pr || !blinders || !proof || (count && !witnesses) || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
-  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  CTX_ENTER(pr->ctx->c, api_fn);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   Ctx* c = p->c;
@@ -1894,7 +1938,7 @@ int plonk_prover_prove(plonk_prover* pr, const uint64_t* const wires[4], const u
   const char* const api_fn = __func__;
   return plonk::api_guard(api_fn, [&]() -> int {
   if (!pr || !wires || !blinders || !proof || (pi_count && (!pi_idx || !pi_val))) return (plonk::set_last_error("invalid argument", api_fn, __FILE__, __LINE__), PLONK_ERR_ARG);
-  std::lock_guard<std::mutex> lk(pr->ctx->c.mu);
+  CTX_ENTER(pr->ctx->c, api_fn);
   HIP_TRY(hipSetDevice(pr->ctx->c.device));
   plonk::Prover* p = pr->p;
   Ctx* c = p->c;

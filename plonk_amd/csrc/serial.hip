@@ -361,7 +361,7 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
     // 48-byte chunks -> raw affine points on the device (a square root each), subgroup test, window tables: the decoded
     // key never visits the host
     Ctx& c = ctx->c;
-    std::lock_guard<std::mutex> lk(c.mu);
+    CTX_ENTER(c, api_fn);
     HIP_TRY(hipSetDevice(c.device));
     uint8_t* in = nullptr;
     G1Affine* pts = nullptr;

@@ -292,6 +292,9 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 ncclResult_t ncclCommAbort(ncclComm_t comm) {
   if (!comm) return ncclInvalidArgument;
   Comm* c = (Comm*)comm;
+  // fault injection (tests only): an abort that does NOT release the spinning kernels — what a transport without a working
+  // ncclCommAbort looks like to comm_sync, which must then mark the context unusable instead of waiting for the stream
+  if (const char* e = getenv("FAKE_RCCL_ABORT_FAILS"); e && e[0] == '1') return ncclSystemError;
   __atomic_store_n(c->abort_flag, 1u, __ATOMIC_RELEASE);   // every spinning kernel of this rank gives up
   release(c, false);                                       // (drains the stream first)
   return ncclSuccess;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Peer failure inside a sharded proof, on ONE GPU, through the stand-in transport (test infrastructure).
 
-  python tests/fake_rccl/peer_death.py WORLD LOG_GATES DIE_RANK DIE_AT        e.g.  2 12 1 alltoall:2
+  python tests/fake_rccl/peer_death.py WORLD LOG_GATES DIE_RANK DIE_AT [noabort]       e.g.  2 12 1 alltoall:2
 
 Starts WORLD ranks that share device 0.  Every rank brings up a communicator on libfakerccl.so, runs the library's
 self-test (all-gather #1, all-to-all #1 of the transport), builds its shard of the bench prover and proves.  The
@@ -62,6 +62,24 @@ def rank_main(rank: int, world: int, log_n: int, uid_path: str) -> int:
     except plonk_amd.PlonkError as e:
         out["rc_second"] = e.code
     out["seconds_second"] = round(time.perf_counter() - t0, 2)
+    if os.environ.get("FAKE_RCCL_ABORT_FAILS") == "1":
+        # the abort did not release the collective's kernel: the context is POISONED (comm.hip comm_sync).  Every entry point
+        # that would queue behind the dead kernel must refuse at once, and the destroy calls must come back after their
+        # bounded poll (2 s each) instead of sitting in hipStreamSynchronize / hipFree — ADVICE r5
+        for name, call in (("msm", lambda: ctx.msm([1, 2, 3])), ("ntt", lambda: ctx.ntt([1, 2, 3, 4], 2)),
+                           ("sync", ctx.sync), ("h2d", lambda: ctx.alloc(64).upload(bytes(64)))):
+            t0 = time.perf_counter()
+            try:
+                call()
+                out["rc_" + name] = 0
+            except plonk_amd.PlonkError as e:
+                out["rc_" + name] = e.code
+            out["seconds_" + name] = round(time.perf_counter() - t0, 2)
+        t0 = time.perf_counter()
+        prover.close()
+        wbuf = None
+        ctx.close()
+        out["seconds_teardown"] = round(time.perf_counter() - t0, 2)
     print("RANKJSON " + json.dumps(out), flush=True)
     os._exit(0)   # no teardown through a communicator whose peer is gone
 
@@ -70,13 +88,14 @@ def main() -> int:
     if "PEER_DEATH_RANK" in os.environ:
         return rank_main(int(os.environ["PEER_DEATH_RANK"]), int(sys.argv[1]), int(sys.argv[2]), os.environ["PEER_DEATH_UID"])
     world, log_n, die_rank, die_at = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    no_abort = len(sys.argv) > 5 and sys.argv[5] == "noabort"   # the transport's abort fails: the survivor's context ends up poisoned
     with tempfile.TemporaryDirectory() as td:
         uid_path = os.path.join(td, "uid")
         procs = []
         for r in range(world):
             env = dict(os.environ, PEER_DEATH_RANK=str(r), PEER_DEATH_UID=uid_path, HSA_ENABLE_IPC_MODE_LEGACY="0",
                        FAKE_RCCL_DIE_RANK=str(die_rank), FAKE_RCCL_DIE_AT=die_at, PLONK_COMM_TIMEOUT_MS=str(TIMEOUT_MS),
-                       FAKE_RCCL_KERNEL_TIMEOUT_S="60")
+                       FAKE_RCCL_KERNEL_TIMEOUT_S="25" if no_abort else "60", FAKE_RCCL_ABORT_FAILS="1" if no_abort else "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:3]], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
         ranks = []

@@ -73,6 +73,36 @@ def test_sharded_prove_matches_single_gpu_at_2p20(ranks):
     assert m["proof_blake2b"] == s["proof_blake2b"]
 
 
+def _run_failing(cmd, env):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0, out.stdout[-2000:]
+    return out.stdout + out.stderr
+
+
+def test_ranks_that_disagree_on_the_wire_commitment_mode_are_refused():
+    """rank 0 hands the prover the WHOLE Lagrange-basis key (wire group by column), rank 1 its slice (by point
+    range).  Until round 6 each rank inferred its mode from its own lagrange_count and nothing compared them: the all-gather
+    would have added whole-column commitments to point-range partial sums — wrong a / b / c / d that no identity check sees.
+    Now plonk_prover_create all-gathers one mode byte per rank and every rank fails with PLONK_ERR_ARG."""
+    log = _run_failing([sys.executable, "bench.py", "--gpus", "2", "--log-gates", "12", "--steps", "1", "--warmup", "0", "--no-extras"],
+                       {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1", "PLONK_BENCH_WIRE_SPLIT": "commitment,range"})
+    assert "disagree on the wire-commitment mode" in log, log[-3000:]
+
+
+@pytest.mark.parametrize("split", ["range", "commitment"])
+def test_a_rank_with_a_wrong_lagrange_key_is_caught_at_prover_creation(split):
+    """Round 6: the Lagrange-key identity (an MSM of random values over the supplied key = the commitment of their
+    interpolation over the commit key) now runs on sharded provers too — summed over the slices, or per rank for whole keys.
+    Rank 1's key has two points swapped (both still valid subgroup points): every rank must fail with PLONK_ERR_DATA instead
+    of producing proofs whose wire commitments do not verify."""
+    log = _run_failing([sys.executable, "bench.py", "--gpus", "2", "--log-gates", "12", "--steps", "1", "--warmup", "0", "--no-extras"],
+                       {"PLONK_BENCH_BACKEND": "gloo", "PLONK_BENCH_SHARE_GPU": "1", "PLONK_BENCH_WIRE_SPLIT": split,
+                        "PLONK_BENCH_CORRUPT_LAGRANGE": "1"})
+    assert "not the Lagrange-basis form of this context's commit key" in log, log[-3000:]
+
+
 def test_self_launcher_starts_the_ranks_on_the_gpu_path():
     """`python bench.py --gpus 2` with no launcher in front of it (how the driver starts the bench): two ranks, the
     single-GPU proof"""

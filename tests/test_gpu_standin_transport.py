@@ -125,6 +125,25 @@ def test_a_rank_that_dies_inside_a_proof_fails_the_others_within_the_timeout(die
     assert alive["rc_second"] == -7 and alive["seconds_second"] < 2.0, rep
 
 
+def test_a_poisoned_context_refuses_every_entry_point_and_tears_down_without_hanging():
+    """the transport's abort FAILS (fault injection in the stand-in), so after the time-out the dead collective's
+    kernel still holds the survivor's stream and comm_sync marks the context unusable.  Until round 6 only the provers and
+    plonk_comm_init checked that flag — plonk_msm / plonk_ntt / copies queued behind the dead kernel and blocked, and the destroy
+    calls sat in hipStreamSynchronize.  Now: every such entry point returns PLONK_ERR_STATE at once, and prover + context
+    teardown returns after the bounded polls (2 s each) with the device side abandoned."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl", "peer_death.py"), "2", "12", "1", "alltoall:2", "noabort"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    rep = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    alive = [x for x in rep["ranks"] if x["rank"] == 0][0]
+    assert alive["exit"] == 0 and alive["rc"] == -7, rep
+    assert "unusable" in alive["error"], rep
+    assert alive["rc_second"] == -7 and alive["seconds_second"] < 2.0, rep
+    for name in ("msm", "ntt", "sync", "h2d"):
+        assert alive["rc_" + name] == -7 and alive["seconds_" + name] < 1.0, (name, rep)
+    assert alive["seconds_teardown"] < 8.0, rep
+
+
 @pytest.mark.parametrize("ranks,log_gates,env", [(3, 13, {}), (2, 12, {"PLONK_SHARD_QUOTIENT": "0"})])
 def test_msm_only_sharding_through_device_collectives(ranks, log_gates, env):
     """world sizes other than 2 / 4 / 8 (and PLONK_SHARD_QUOTIENT=0): only the MSMs are sharded — every exchange is one of
