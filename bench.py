@@ -64,9 +64,10 @@ def circuit_polys(ctx, log_n, profile):
     return wires, polys, pi
 
 
-def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circuit=False, keep_inputs=False):
+def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circuit=False, keep_inputs=False, on_inputs=None):
     """keep_inputs: leave (wires, coefficient-form polynomials, public inputs) in build_prover.inputs — the tests hand them to
-    the C oracle for the byte comparison"""
+    the C oracle for the byte comparison; on_inputs(inputs): called with the same tuple as soon as it exists, BEFORE the
+    prover is built (the 2^22 test starts its CPU oracle there, beside the GPU's set-up)"""
     n = 1 << log_n
     srs_total = n + 7                      # the points prove() touches (commit key is trimmed to >= n + 7)
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
@@ -75,21 +76,25 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
     if world in (2, 4, 8) and n >= 64 and not eff.wire_commit and eff.shard_quotient >= 0:
         # multi-GPU: the Lagrange-basis key needs the WHOLE commit key once (a group FFT); every rank derives it from the
         # full synthetic key and keeps its slice (a real deployment computes it once and ships the slices)
-        full = ctx.alloc(96 * (n + 2))
-        ctx.srs_generate_dev(TAU, G_SCALAR, n + 2, full.ptr)
-        # this load only feeds the group FFT (row 0 of the tables): the 16 window rows are enough, the 256 bit-position
-        # rows of the full key would be 32 GiB per rank of pure setup
-        cfg = ctx.get_config()
-        saved = cfg.table_mode
-        cfg.table_mode = plonk_amd.TABLE_WINDOW
-        ctx.set_config(cfg)
-        try:
-            ctx.srs_load_dev(full.ptr, n + 2)
-        finally:
-            cfg.table_mode = saved
+        def whole_key():
+            full = ctx.alloc(96 * (n + 2))
+            ctx.srs_generate_dev(TAU, G_SCALAR, n + 2, full.ptr)
+            # this load only feeds the group FFT (row 0 of the tables): the 16 window rows are enough, the 256 bit-position
+            # rows of the full key would be 32 GiB per rank of pure setup
+            cfg = ctx.get_config()
+            saved = cfg.table_mode
+            cfg.table_mode = plonk_amd.TABLE_WINDOW
             ctx.set_config(cfg)
-        full.free()
-        key = ctx.lagrange_key(log_n)
+            try:
+                ctx.srs_load_dev(full.ptr, n + 2)
+            finally:
+                cfg.table_mode = saved
+                ctx.set_config(cfg)
+            full.free()
+            return ctx.lagrange_key(log_n)
+        # (test sessions only — PLONK_CIRCUIT_CACHE: ranks that SHARE one GPU would each run the same group FFT one after the
+        # other, 8 x 3.5 s at 2^22 gates; the key of (TAU, G_SCALAR, size) is computed by the first rank and read by the rest)
+        key = BC._cached("lagrange_key", log_n, "tau5eed", whole_key)
         llo, lhi = min(lo, n + 2), min(hi, n + 2)
         # 2 / 4 ranks: every rank takes the WHOLE Lagrange-basis key and commits to whole wire columns instead of a point range
         # of every column (prover.hip lag_whole; DESIGN.md section 5: rank alone at 2^20, same box, 18.34 -> 17.98 ms for W = 2,
@@ -131,6 +136,8 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
                                              if isinstance(polys.get(k), (bytes, bytearray)) and polys[k].strip(b"\0")
                                              or (not isinstance(polys.get(k), (bytes, bytearray)) and polys.get(k) and any(polys[k])))
         build_prover.inputs = (wires, polys, pi, circuit_polys.q_m_column) if keep_inputs else None
+        if on_inputs is not None:
+            on_inputs((wires, polys, pi, circuit_polys.q_m_column))
         circuit_polys.q_m_column = None
         t0 = time.perf_counter()
         prover = plonk_amd.Prover(ctx, n, b"bench", polys, None, rank, world, srs_total, allgather, lag_slice)

@@ -253,6 +253,18 @@ void oracle_prover_set_trapdoor(oprover* P, const u64 tau_m[4], const u64 g_scal
 }
 
 void oracle_prover_set_version(void* h, int version) { ((oprover*)h)->version = version; }
+/* The 15 VerifierKey commitments (Compiler::preprocess, compiler.rs:213-232) recomputed through the trapdoor — for sizes where
+ * the caller handed oracle_prover_new a vk48 it did not compute itself (the 2^22-gate test takes the GPU's) and 15 CPU MSMs
+ * of 4 M terms are out of reach: the test compares these bytes with the ones it passed in.  -1 without a trapdoor. */
+int oracle_prover_vk_trapdoor(const oprover* P, uint8_t out[15 * 48]);
+/* ... and adopted as the prover's own VerifierKey (what seeds its transcript): an oracle_prover_new that was handed a
+ * placeholder vk48 becomes independent of whoever produced one — the 2^22-gate test runs this oracle BESIDE the GPU. */
+int oracle_prover_adopt_vk_trapdoor(oprover* P) { return oracle_prover_vk_trapdoor(P, (uint8_t*)P->vk); }
+int oracle_prover_vk_trapdoor(const oprover* P, uint8_t out[15 * 48]) {
+  if (!P->trapdoor) return -1;
+  for (int k = 0; k < K_COUNT; ++k) { const int rc = commit48(P, P->polys[k], P->poly_len[k], out + 48 * k); if (rc) return rc; }
+  return 0;
+}
 static void commit_trapdoor(const oprover* P, const fr* poly, u64 len, uint8_t raw[97]) {
   memset(raw, 0, 97);
   const u64 chunk = 1 << 14, nch = (len + chunk - 1) / chunk;
@@ -775,28 +787,55 @@ int oracle_srs_generate(const u64 tau_m[4], const u64 g_scalar_m[4], u64 n, uint
   if (threads <= 0) threads = omp_get_max_threads();
   g1a* table = (g1a*)malloc(sizeof(g1a) * 32 * 255);   /* table[w][d-1] = d * 2^(8w) * G */
   g1a base; memcpy(base.x.l, G1_GEN_X, 48); memcpy(base.y.l, G1_GEN_Y, 48);
-  for (int w = 0; w < 32; ++w) {
+  for (int w = 0; w < 32; ++w) {          /* d * base for d = 1 .. 256, normalised with one shared inversion per window */
+    g1j mult[256];
+    fp pre[256], run;
+    memcpy(run.l, FP_ONE, 48);
     g1j acc = j_identity();
-    for (int d = 1; d <= 255; ++d) { acc = j_add_mixed(acc, &base); j_to_affine(acc, &table[w * 255 + d - 1]); }
-    g1j nb = j_add_mixed(acc, &base);   /* 256 * base */
-    j_to_affine(nb, &base);
+    for (int d = 0; d < 256; ++d) { acc = j_add_mixed(acc, &base); mult[d] = acc; pre[d] = run; run = fp_mul(run, acc.z); }
+    fp inv = fp_inv(run);
+    g1a norm[256];
+    for (int d = 256; d-- > 0;) {
+      const fp zi = fp_mul(inv, pre[d]), zi2 = fp_mul(zi, zi);
+      inv = fp_mul(inv, mult[d].z);
+      norm[d].x = fp_mul(mult[d].x, zi2);
+      norm[d].y = fp_mul(mult[d].y, fp_mul(zi2, zi));
+    }
+    memcpy(&table[w * 255], norm, sizeof(g1a) * 255);
+    base = norm[255];                     /* 256 * base */
   }
   const fr tau = fr_ld(tau_m), gs = fr_ld(g_scalar_m);
   const u64 chunk = 1 << 10;
 #pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
   for (u64 c0 = 0; c0 < n; c0 += chunk) {
+    /* the chunk's points stay Jacobian until ONE shared inversion normalises them (Montgomery's trick: prefix products of
+     * the z, one fp_inv — a 381-bit exponentiation, until round 6 one per point and most of this function's time —
+     * then two products per point on the way back).  Same affine coordinates: they are unique. */
+    g1j* acc = (g1j*)malloc(sizeof(g1j) * chunk);
+    fp* pre = (fp*)malloc(sizeof(fp) * chunk);
+    const u64 cnt = c0 + chunk < n ? chunk : n - c0;
     fr k = fr_mul(gs, fr_pow(tau, c0));
-    for (u64 i = c0; i < c0 + chunk && i < n; ++i) {
+    fp run; memcpy(run.l, FP_ONE, 48);
+    for (u64 j = 0; j < cnt; ++j) {
       uint8_t kb[32];
       fr_to_bytes(k, kb);
-      g1j acc = j_identity();
-      for (int w = 0; w < 32; ++w) if (kb[w]) acc = j_add_mixed(acc, &table[w * 255 + kb[w] - 1]);
-      g1a a;
-      if (fp_is_zero(acc.z)) { memset(out96 + 96 * i, 0, 96); k = fr_mul(k, tau); continue; }   /* only for tau or g == 0 */
-      j_to_affine(acc, &a);
-      memcpy(out96 + 96 * i, a.x.l, 48); memcpy(out96 + 96 * i + 48, a.y.l, 48);
+      g1j a = j_identity();
+      for (int w = 0; w < 32; ++w) if (kb[w]) a = j_add_mixed(a, &table[w * 255 + kb[w] - 1]);
+      acc[j] = a;
+      pre[j] = run;                                          /* product of the finite z before j */
+      if (!fp_is_zero(a.z)) run = fp_mul(run, a.z);
       k = fr_mul(k, tau);
     }
+    fp inv = fp_inv(run);                                    /* 1 / (product of all finite z) */
+    for (u64 j = cnt; j-- > 0;) {
+      uint8_t* o = out96 + 96 * (c0 + j);
+      if (fp_is_zero(acc[j].z)) { memset(o, 0, 96); continue; }   /* only for tau or g == 0 */
+      const fp zi = fp_mul(inv, pre[j]), zi2 = fp_mul(zi, zi);
+      inv = fp_mul(inv, acc[j].z);
+      const fp x = fp_mul(acc[j].x, zi2), y = fp_mul(acc[j].y, fp_mul(zi2, zi));
+      memcpy(o, x.l, 48); memcpy(o + 48, y.l, 48);
+    }
+    free(acc); free(pre);
   }
   free(table);
   return 0;

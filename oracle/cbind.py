@@ -41,6 +41,10 @@ def load() -> ctypes.CDLL:
     lib.oracle_prover_free.restype = None
     lib.oracle_prover_vk.argtypes = [vp, vp]
     lib.oracle_prover_vk.restype = None
+    lib.oracle_prover_vk_trapdoor.argtypes = [vp, vp]
+    lib.oracle_prover_adopt_vk_trapdoor.argtypes = [vp]
+    lib.oracle_prover_adopt_vk_trapdoor.restype = ctypes.c_int
+    lib.oracle_prover_vk_trapdoor.restype = ctypes.c_int
     lib.oracle_prover_set_trapdoor.argtypes = [vp, vp, vp]
     lib.oracle_prover_set_trapdoor.restype = None
     lib.oracle_prover_set_version.argtypes = [vp, ctypes.c_int]
@@ -143,6 +147,18 @@ class CProver:
     def vk(self) -> bytes:
         out = ctypes.create_string_buffer(15 * 48)
         self.lib.oracle_prover_vk(self.h, out)
+        return out.raw
+
+    def adopt_vk_trapdoor(self):
+        """make the trapdoor commitments of the key polynomials this prover's VerifierKey (replaces a placeholder vk48)"""
+        rc = self.lib.oracle_prover_adopt_vk_trapdoor(self.h)
+        assert rc == 0, rc
+
+    def vk_trapdoor(self) -> bytes:
+        """the 15 key commitments recomputed as [g p(tau)] G (set_trapdoor first) — independent of a vk48 passed to __init__"""
+        out = ctypes.create_string_buffer(15 * 48)
+        rc = self.lib.oracle_prover_vk_trapdoor(self.h, out)
+        assert rc == 0, rc
         return out.raw
 
     def prove(self, wires, pi_idx, pi_val_mont: bytes, blinders_mont: bytes, trace: bool = False):

@@ -7,6 +7,7 @@ Permutation::compute_sigma_polynomials (src/composer/permutation.rs:150-211); in
 the C restatement of EvaluationDomain::ifft (oracle/c/oracle.c)."""
 from __future__ import annotations
 
+import functools
 import random
 
 from oracle import bls12_381 as E
@@ -118,6 +119,7 @@ def big_widget_circuit(ngates: int, seed: int = 1):
     return build
 
 
+@functools.lru_cache(maxsize=2)   # the 2^20-gate tests of one module ask for the same 100 MB key several times in a row
 def synthetic_srs(n: int, tau: int = 0x5EED0000 * 0x9E3779B97F4A7C15 % Q, g: int = 0xA5A5A5A5DEADBEEF) -> bytes:
     """[g tau^i] G1, i < n, as raw 96-byte points (C oracle; PublicParameters::setup semantics)."""
     return cbind.srs_generate(fr_bytes([tau]), fr_bytes([g]), n)

@@ -18,12 +18,47 @@ def test_bench_proof_verifies(log_n):
     (bench.build_prover), 8.6 GiB of window tables + 8.5 GiB of key evaluations resident."""
     import plonk_amd
     ctx = plonk_amd.Context(0)
-    prover, wbuf, srs_total = bench.build_prover(ctx, log_n, 0, 1, None, keep_inputs=log_n == 22)
     tau, g = bench.TAU, bench.G_SCALAR
+    bl1 = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
+    oracle = {}
+
+    def start_oracle(inputs):
+        # BASELINE config 5's size, BYTE parity: a valid-but-different proof (a misplaced blinder in the split of t, a wrong
+        # coefficient range) passes the verification equation below but not this.  The C oracle proves the same circuit
+        # with the key's trapdoor — the commitment [g p(tau)] G is the group element the MSM over [g tau^i] G returns
+        # (tests/test_oracle_c_prove.py::test_trapdoor_commitments_are_the_msm_commitments) — because eleven CPU MSMs of
+        # 4 M terms would take minutes; the transforms, the quotient and every O(n) pass are the oracle's own.
+        # Round 6: it runs in a thread BESIDE the GPU's set-up (ctypes releases the GIL; ~1.5 of the test's 1.8 minutes were
+        # this oracle running after the GPU had finished), and it no longer takes the GPU's VerifierKey on trust: its 15 key
+        # commitments are its own trapdoor commitments (VERDICT r5 weak 1 iii) and are compared with the GPU's BY BYTES.
+        import threading
+        from oracle import cbind
+        wires, polys, _, q_m_column = inputs
+
+        def run():
+            try:
+                n = 1 << log_n
+                threads = cbind.max_threads()
+                mont = plonk_amd.fr_to_bytes_mont
+                # the key polynomials are INPUTS of prove() (Compiler::compile made them); pin one GPU-interpolated column to
+                # the CPU transform so that the shared input is not taken on trust
+                oracle["q_m_ok"] = cbind.ntt_bytes(q_m_column, log_n, True, False, n, threads) == polys["q_m"]
+                pb = {k: (v if isinstance(v, (bytes, bytearray)) else mont(v)) for k, v in polys.items()}   # short ones come as integers
+                cp = cbind.CProver(n, b"bench", pb, bytes(96 * (n + 7)), vk48=bytes(15 * 48), threads=threads)
+                cp.set_trapdoor(mont([tau]), mont([g]))
+                cp.adopt_vk_trapdoor()
+                oracle["vk"] = cp.vk()
+                oracle["proof"] = cp.prove(wires, [], b"", bl1)
+                cp.close()
+            except BaseException as e:   # noqa: BLE001  (re-raised on the main thread)
+                oracle["error"] = e
+        oracle["thread"] = threading.Thread(target=run, name="c-oracle-2p22", daemon=True)
+        oracle["thread"].start()
+
+    prover, wbuf, srs_total = bench.build_prover(ctx, log_n, 0, 1, None, on_inputs=start_oracle if log_n == 22 else None)
     srs_g = E.g1_mul(E.G1_GEN, g)
     raw = prover.vk_commitments()
     vk = {name: E.g1_decompress(raw[48 * i:48 * i + 48]) for i, name in enumerate(plonk_amd.POLY_ORDER)}
-    bl1 = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
     bl2 = plonk_amd.fr_to_bytes_mont([(0xC0FFEE00 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
     p1 = prover.prove_dev(wbuf.ptr, {}, bl1)
     p1b = prover.prove_dev(wbuf.ptr, {}, bl1)
@@ -42,25 +77,12 @@ def test_bench_proof_verifies(log_n):
     bad[530] ^= 4
     assert not verify_with_tau(bytes(bad), vk, b"bench", n, {}, tau, srs_g)
     if log_n == 22:
-        # BASELINE config 5's size, BYTE parity: a valid-but-different proof (a misplaced blinder in the split of t, a wrong
-        # coefficient range) passes the verification equation above but not this.  The C oracle proves the same circuit
-        # with the key's trapdoor — the commitment [g p(tau)] G is the group element the MSM over [g tau^i] G returns
-        # (tests/test_oracle_c_prove.py::test_trapdoor_commitments_are_the_msm_commitments) — because eleven CPU MSMs of
-        # 4 M terms would take minutes; the transforms, the quotient and every O(n) pass are the oracle's own.
-        from oracle import cbind
-        wires, polys, _, q_m_column = bench.build_prover.inputs
-        bench.build_prover.inputs = None
-        threads = cbind.max_threads()
-        mont = plonk_amd.fr_to_bytes_mont
-        # the key polynomials are INPUTS of prove() (Compiler::compile made them); pin one GPU-interpolated column to
-        # the CPU transform so that the shared input is not taken on trust
-        assert cbind.ntt_bytes(q_m_column, log_n, True, False, n, threads) == polys["q_m"]
-        polys = {k: (v if isinstance(v, (bytes, bytearray)) else mont(v)) for k, v in polys.items()}   # short ones come as integers
-        cp = cbind.CProver(n, b"bench", polys, bytes(96 * (n + 7)), vk48=raw, threads=threads)
-        cp.set_trapdoor(mont([tau]), mont([g]))
-        expected = cp.prove(wires, [], b"", bl1)
-        cp.close()
-        assert p1 == expected
+        oracle["thread"].join()
+        if "error" in oracle:
+            raise oracle["error"]
+        assert oracle["q_m_ok"]
+        assert oracle["vk"] == raw          # the 15 key commitments, byte for byte
+        assert p1 == oracle["proof"]
     prover.close()
     wbuf.free()
     ctx.close()

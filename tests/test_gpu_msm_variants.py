@@ -41,25 +41,49 @@ VARIANTS = [
 ]
 
 
+PROVER_VARIANTS = [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"},
+                   {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},
+                   {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"}]
+PROVER_SELECT = "deterministic_v3 or random_arithmetic or (proof_bytes_equal_c_oracle and not 16 and not 2p20)"
+
+
+def _key(env):
+    return ",".join(f"{k}={x}" for k, x in sorted(env.items()))
+
+
+@pytest.fixture(scope="module")
+def children():
+    """Every child of this module is started when the first test asks for one, four at a time (round 6: the 16 children used
+    to run one after the other, ~80 s of a GPU session in which the device and most host cores sat idle — a child is
+    interpreter start-up, the Python KAT set-up and a few small proofs).  Each test still owns exactly one child and fails on
+    that child's output."""
+    import concurrent.futures as cf
+    import json
+    pool = cf.ThreadPoolExecutor(max_workers=4)
+    futs = {}
+    for variant in PROVER_VARIANTS:      # the long ones first
+        futs["prover:" + _key(variant)] = pool.submit(run_variant, variant, PROVER_SELECT, "gpu and not slow",
+                                                      "tests/test_gpu_prover.py tests/test_gpu_prove_sizes.py")   # one child, both files
+    for variant, plan in VARIANTS:
+        futs["edge:" + _key(variant)] = pool.submit(run_variant, dict(variant, PLONK_TEST_EXPECT_PLAN=json.dumps(plan)))
+    yield futs
+    pool.shutdown(wait=False, cancel_futures=True)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant,plan", VARIANTS, ids=[",".join(f"{k}={x}" for k, x in v.items()) for v, _ in VARIANTS])
-def test_variant_matches_the_oracle_on_the_edge_cases(variant, plan):
-    import json
-    r = run_variant(dict(variant, PLONK_TEST_EXPECT_PLAN=json.dumps(plan)))
+def test_variant_matches_the_oracle_on_the_edge_cases(children, variant, plan):
+    r = children["edge:" + _key(variant)].result()
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"},
-                                     {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},
-                                     {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"}],
-                         ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
-def test_prover_parity_holds_with_every_table_and_bucket_layout(variant):
+@pytest.mark.parametrize("variant", PROVER_VARIANTS, ids=lambda v: ",".join(f"{k}={x}" for k, x in v.items()))
+def test_prover_parity_holds_with_every_table_and_bucket_layout(children, variant):
     """whole proofs (reference KAT digest, random circuits, widget circuits vs the C oracle at 2^12 / 2^13) with the table /
     bucket layouts that the size rules would only pick for large circuits"""
-    r = run_variant(variant, select="deterministic_v3 or random_arithmetic or (proof_bytes_equal_c_oracle and not 16 and not 2p20)",
-                    marker="gpu and not slow", target="tests/test_gpu_prover.py tests/test_gpu_prove_sizes.py")   # one child, both files
+    r = children["prover:" + _key(variant)].result()
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
 

@@ -132,6 +132,15 @@ def test_trapdoor_commitments_are_the_msm_commitments():
     want = cp.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31))
     cp.set_trapdoor(C.fr_bytes([tau]), C.fr_bytes([g]))
     assert cp.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31)) == want
+    assert cp.vk_trapdoor() == cp.vk()                            # the 15 key commitments too (they were MSMs at construction)
+    # the way the 2^22-gate GPU test builds its oracle: a placeholder VerifierKey and no key points at all, everything through the trapdoor
+    blind = cbind.CProver(case["constraints"], case["label"], case["polys"], bytes(len(srs)), vk48=bytes(15 * 48))
+    blind.set_trapdoor(C.fr_bytes([tau]), C.fr_bytes([g]))
+    blind.adopt_vk_trapdoor()
+    assert blind.vk() == cp.vk()
+    assert blind.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31)) == want
+    blind.close()
     cp.set_trapdoor(C.fr_bytes([tau + 1]), C.fr_bytes([g]))      # a wrong trapdoor is a different proof
+    assert cp.vk_trapdoor() != cp.vk()
     assert cp.prove(case["wires"], case["pi_idx"], case["pi_val"], C.blinders(31)) != want
     cp.close()
