@@ -149,20 +149,69 @@ def build_prover(ctx, log_n, rank, world, allgather, profile="dense", from_circu
     return prover, wbuf, srs_total
 
 
-def time_profile(ctx, log_n, profile, steps, blinders, digest=None):
-    """ms per prove() of another workload on this (single) GPU; digest: a dict that receives the proof's blake2b"""
-    prover, wbuf, _ = build_prover(ctx, log_n, 0, 1, None, profile)
-    proof = prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
-    if digest is not None:
-        digest["proof_blake2b"] = hashlib.blake2b(proof).hexdigest()[:32]
-    ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
-    ctx.sync()
-    ms = (time.perf_counter() - t0) * 1e3 / steps
-    prover.close()
-    wbuf.free()
+def host_wire_legs(ctx, prover, wbuf, n, blinders, proof, steps):
+    """prove() with the four wire columns handed over as pinned HOST buffers (what a shim around Prover::prove holds,
+    prover.rs:446-460): PCIe-inclusive, never `value`.  Returns ms per proof; the bytes must be the resident proof's."""
+    hw = [plonk_amd.PinnedBuffer(32 * n) for _ in range(4)]
+    try:
+        for k in range(4):
+            ctx.d2h_into(hw[k].ptr, wbuf.ptr + 32 * n * k, 32 * n)
+        ptrs = [b.ptr for b in hw]
+        assert prover.prove_host_ptrs(ptrs, prover.public_inputs, blinders) == proof
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            prover.prove_host_ptrs(ptrs, prover.public_inputs, blinders)
+        ctx.sync()
+        return round((time.perf_counter() - t1) * 1e3 / steps, 3)
+    finally:
+        for b in hw:
+            b.free()
+
+
+def time_profile(ctx, log_n, profile, steps, blinders, digest=None, host_legs=None, from_circuit=False):
+    """ms per prove() of another workload on this (single) GPU; digest: a dict that receives the proof's blake2b;
+    host_legs: a dict that receives the PCIe-inclusive legs of the same prover (pinned host wire columns)"""
+    prover, wbuf, _ = build_prover(ctx, log_n, 0, 1, None, profile, from_circuit=from_circuit)
+    try:   # (a failure must not leave a 2^22 prover's tens of GB behind: the caller may fall back to another constructor)
+        proof = prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+        if digest is not None:
+            digest["proof_blake2b"] = hashlib.blake2b(proof).hexdigest()[:32]
+            digest["prover_built_by"] = "plonk_compile (gate columns)" if from_circuit else "plonk_prover_create (coefficient forms)"
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
+        ctx.sync()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        if host_legs is not None:
+            try:
+                host_legs["prove_ms_host_wires_pinned"] = host_wire_legs(ctx, prover, wbuf, 1 << log_n, blinders, proof, steps)
+                host_legs["wire_bytes_mib"] = 4 * 32 << (log_n - 20)
+                host_legs["prove_ms_resident"] = round(ms, 3)
+                if from_circuit and build_prover.witness_values is not None:
+                    # a proof that starts from the witness TABLE in pinned host memory (plonk_prover_prove_witnesses: one Fr per
+                    # witness up, the four padded columns gathered on the device, prover.rs:446-460)
+                    vals = build_prover.witness_values
+                    host = plonk_amd.PinnedBuffer(len(vals))
+                    try:
+                        host.write(vals)
+                        cnt = len(vals) // 32
+                        assert prover.prove_witnesses_ptr(host.ptr, cnt, prover.public_inputs, blinders) == proof
+                        ctx.sync()
+                        t1 = time.perf_counter()
+                        for _ in range(steps):
+                            prover.prove_witnesses_ptr(host.ptr, cnt, prover.public_inputs, blinders)
+                        ctx.sync()
+                        host_legs["prove_ms_from_witness_table_pinned"] = round((time.perf_counter() - t1) * 1e3 / steps, 3)
+                        host_legs["witness_table_mib"] = round(len(vals) / 2**20, 1)
+                    finally:
+                        host.free()
+            except Exception as e:   # noqa: BLE001
+                host_legs["error"] = repr(e)
+    finally:
+        prover.close()
+        wbuf.free()
     return round(ms, 3)
 
 
@@ -264,6 +313,55 @@ def valu_issue(wave_instructions, ms):
     """the bound that holds for every kernel on this path: integer-VALU issue"""
     ach = wave_instructions / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     return {"achieved": round(ach, 1), "peak": VALU_PEAK_GWIPS, "unit": "G wave-instructions/s", "frac": round(ach / VALU_PEAK_GWIPS, 4)}
+
+
+def accumulate_roofline(plan, model_wi, counter_wi, acc_ms_per_prove, pmc, run):
+    """`roofline` of the dominant kernel.  counter_wi: VALU wave-instructions per proof from the committed SQ_INSTS_VALU pass
+    (None when no round-6 profile is present or the workload is not the profiled one: the model count is used and says so);
+    model_wi: non-zero digits / 64 lanes x 4850 instructions.  No field of this object can exceed 1: `frac` divides by the issue
+    rate at the 2.4 GHz peak clock — above what the power-limited kernel ever gets — and `frac_at_measured_clock` is quoted from
+    ONE counter pass (instructions, duration and clock of the same dispatches), not rescaled across runs as in round 5."""
+    wi = counter_wi if counter_wi else model_wi
+    issue = valu_issue(wi, acc_ms_per_prove)
+    model = valu_issue(model_wi, acc_ms_per_prove)
+    hbm_frac = round(run["achieved"] / HBM_PEAK_GBS, 5)
+    out = {"bound": "valu-int-issue",
+           # the variant that ran: 2^19 buckets (namespace nbl, lanes in order of length) above 2^18 terms over bit-position /
+           # half-density rows, else 2^15 buckets (ordered lanes where slices are 32 entries long)
+           "kernel": plan["accumulate_kernel"], "bucket_bits": plan["bucket_bits"], "digit_width": plan["digit_width"],
+           "slice_entries": plan["slice_entries"],
+           "achieved": issue["achieved"], "peak": issue["peak"], "unit": issue["unit"], "frac": issue["frac"],
+           "frac_source": ("SQ_INSTS_VALU of the four prove() launches (%s) / this run's hipEvent time of the same launches" % pmc["src"]) if counter_wi
+                          else "MODEL (no counter pass with valu_wave_instructions_per_proof for this workload): non-zero digits x 4850 instructions",
+           "valu_wave_instructions_per_proof": None if not counter_wi else round(counter_wi),
+           "valu_wave_instructions_per_launch": None if not pmc.get("instr_launch") else [round(v) for v in pmc["instr_launch"]],
+           "model": {"wave_instructions_per_proof": round(model_wi), "instructions_per_addition_model": 4850,
+                     "additions_per_scalar": run["digits_per_scalar"], "frac": model["frac"],
+                     "ratio_to_counters": None if not counter_wi else round(model_wi / counter_wi, 4)},
+           "traffic": pmc["traffic"], "valu_int_fraction": None if pmc["valu_busy"] is None else round(pmc["valu_busy"], 3),
+           "hbm": {"achieved": round(run["achieved"], 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac},
+           "hbm_frac": hbm_frac, "valu_issue_fraction": issue["frac"],
+           "additions_per_scalar": run["digits_per_scalar"], "table_rows": run["table_rows"],
+           "traffic_source": pmc["src"], "avg_launch_ms": round(run["avg_acc"], 4), "launches": int(run["acc_n"]),
+           "algorithmic_bytes_per_launch": run["alg_bytes_per_launch"], "launch_groups_per_prove": list(run["groups"]),
+           # the shader clock the counters show under this kernel (power-limited) and the issue fraction at THAT clock — both from the
+           # committed counter pass, self-consistent
+           "shader_clock_ghz_under_kernel": None if pmc["clock"] is None else round(pmc["clock"], 2),
+           "frac_at_measured_clock": None if pmc.get("frac_clock") is None else round(pmc["frac_clock"], 4),
+           "frac_vs_guide_valu_rate": round(issue["frac"] / 2, 4),
+           "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound.  `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles: the "
+                   "MEASURED issue class of v_mad_u64_u32 and the carry adds around it (4.4-4.9 cycles per wave-instruction, "
+                   "profiles/r01/valu_issue_rates_gfx950.txt) — not the guide's generic VALU rate of one wave-instruction per 2 cycles, "
+                   "against which the same kernel is at `frac_vs_guide_valu_rate`.  `frac_at_measured_clock`: the same counter pass's instructions "
+                   "over ITS duration at ITS shader clock (power-limited, well below 2.4 GHz).  `traffic` (PMC, HBM bytes per launch) is one "
+                   "128-B table gather per non-zero digit by design; see DESIGN.md 4.2 / 6"}
+    # no fraction above 1 ships (VERDICT r5: round 5 printed frac_at_measured_clock = 1.02): a value outside [0, 1] means the counter
+    # pass and this run do not describe the same kernel — it is withheld and named, never printed as if it were a measurement
+    for k in ("frac", "hbm_frac", "valu_issue_fraction", "frac_at_measured_clock", "frac_vs_guide_valu_rate", "valu_int_fraction"):
+        if out[k] is not None and not 0.0 <= out[k] <= 1.0:
+            out.setdefault("withheld_not_a_fraction", {})[k] = out[k]
+            out[k] = None
+    return out
 
 
 def quotient_roofline(prover, n, qmul, has_pi, profile, ms_per_launch):
@@ -680,8 +778,8 @@ def main():
         achieved = alg_bytes_per_prove / (acc_ms_per_prove * 1e-3) / 1e9 if acc_ms_per_prove > 0 else 0.0
         # HBM traffic / VALU utilisation of the same kernel come from PMC passes (rocprofv3 --pmc, separate runs):
         # NOT measured by this run — the latest committed profile is quoted with its source
-        valu_busy = traffic = pmc_src = pmc_clock = None
-        if world == 1 and log_n == 20:
+        valu_busy = traffic = pmc_src = pmc_clock = pmc_instr = pmc_instr_launch = pmc_frac_clock = None
+        if world == 1 and log_n == 20 and args.profile == "dense":
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc.json"))):
                 try:
@@ -689,6 +787,11 @@ def main():
                     traffic = round(pj["traffic_bytes_per_launch"])
                     valu_busy = pj.get("valu_busy_frac")
                     pmc_clock = pj.get("shader_clock_ghz_under_kernel")
+                    # round 6: SQ_INSTS_VALU of the four prove() launches of the dominant kernel (tools/summarize_profile.py) — what
+                    # `achieved` / `frac` are built on; absent in the profiles of rounds 1-5
+                    pmc_instr = pj.get("valu_wave_instructions_per_proof")
+                    pmc_instr_launch = pj.get("valu_wave_instructions_per_launch")
+                    pmc_frac_clock = pj.get("valu_issue_frac_at_measured_clock")
                     pmc_src = os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of an earlier run, not this run)"
                 except Exception:   # noqa: BLE001
                     pass
@@ -705,8 +808,8 @@ def main():
         if table_rows == 16:
             digits_per_scalar = 16.0 - 0.5
         else:
-            per = 254.86 / (w_bits + (1 if table_rows == 256 else 2 / 3)) + 0.5
-            digits_per_scalar = round(per - (nb / max(m_local, 1) if plan["bucket_bits"] > 15 else 0.5), 2)
+            digits = 254.86 / (w_bits + (1 if table_rows == 256 else 2 / 3)) + 0.5   # (round 5 called this `per` too and garbled config.srs)
+            digits_per_scalar = round(digits - (nb / max(m_local, 1) if plan["bucket_bits"] > 15 else 0.5), 2)
         npoly = 6 if pi else 5
         out = {
             "metric": "prove() wall-clock (ms) at 2^%d gates" % log_n,
@@ -714,6 +817,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": False,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32 limbs (Fr 256-bit / Fp 384-bit Montgomery)",
             "data": "synthetic",
+            # the contract's `value`: inputs resident in HBM when the timed region starts.  What a drop-in caller of Prover::prove
+            # pays on top is printed beside it: prove_ms_host_wires_pinned (2^20) / host_legs_2p22
+            "value_excludes": "H2D of the 4 x 32 n wire bytes (%d MiB at this size)" % (4 * 32 * n >> 20),
             "config": {"workload": "Prover::prove V3, synthetic 2^%d-gate circuit, profile `%s` (%s), random SRS of n+7 points, "
                                    "wires/ProverKey/SRS tables resident in HBM" % (
                                        log_n, args.profile,
@@ -737,38 +843,17 @@ def main():
             # whole-job MSM rate: all 11 x (n + 6) terms of a proof over the time rank 0 spends in its (sharded) MSM kernels
             "msm_mscalar_per_s": round(11 * (n + 6) / max((acc_ms + oth_ms) / args.steps, 1e-9) / 1e3, 2),
             "proof_blake2b": hashlib.blake2b(proof).hexdigest()[:32],
-            # the dominant kernel is bound by integer-VALU issue, not by HBM: `frac` is the issue-rate fraction —
-            # wave-instructions (additions / 64 lanes x 4850 instructions per mixed addition, profiles/r02c/accumulate_isa.md;
-            # additions = non-zero digits of the 11 commitments' scalars) over one VALU wave-instruction per 4 cycles per SIMD.  The
-            # HBM figure the contract asks for (algorithmic (32 b + 96) m bytes per group launch over the launch time) is `hbm`.
-            "roofline": dict(
-                {"bound": "valu-int-issue",
-                 # the variant that ran: 2^19 buckets (namespace nbl, lanes in order of length) above 2^18 terms over bit-position /
-                 # half-density rows, else 2^15 buckets (ordered lanes where slices are 32 entries long)
-                 "kernel": plan["accumulate_kernel"], "bucket_bits": plan["bucket_bits"], "digit_width": plan["digit_width"],
-                 "slice_entries": plan["slice_entries"]},
-                **valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove),
-                **{"traffic": traffic, "valu_int_fraction": None if valu_busy is None else round(valu_busy, 3),
-                   "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
-                   "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
-                   "valu_issue_fraction": valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"],
-                   "additions_per_scalar": digits_per_scalar, "instructions_per_addition": 4850, "table_rows": table_rows,
-                   "traffic_source": pmc_src, "avg_launch_ms": round(avg_acc, 4), "launches": int(acc_n),
-                   "algorithmic_bytes_per_launch": alg_bytes_per_prove // len(groups),
-                   "launch_groups_per_prove": list(groups),
-                   # the shader clock the counters show under this kernel (power-limited, from the same committed PMC passes) and the issue
-                   # fraction at THAT clock instead of the 2.4 GHz `peak` is quoted at
-                   "shader_clock_ghz_under_kernel": None if pmc_clock is None else round(pmc_clock, 2),
-                   "frac_at_measured_clock": None if not pmc_clock else round(
-                       valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"] * 2.4 / pmc_clock, 4),
-                   "frac_vs_guide_valu_rate": round(valu_issue(digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, acc_ms_per_prove)["frac"] / 2, 4),
-                   "note": "integer-VALU bound (384-bit Montgomery products), not HBM bound.  `peak` = 1024 SIMDs x 2.4 GHz / 4 cycles: the "
-                           "MEASURED issue class of v_mad_u64_u32 and the carry adds around it (4.4-4.9 cycles per wave-instruction, "
-                           "profiles/r01/valu_issue_rates_gfx950.txt) — not the guide's generic VALU rate of one wave-instruction per 2 cycles, "
-                           "against which the same kernel is at `frac_vs_guide_valu_rate`.  `frac_at_measured_clock` rescales `frac` from the 2.4 GHz of "
-                           "`peak` to the shader clock the committed PMC passes show under this kernel (power-limited); a value slightly above 1 "
-                           "means the instruction mix issues a little faster than one per 4 cycles (its carry additions are 2-cycle class).  `traffic` (PMC, HBM bytes per launch) is one "
-                           "128-B table gather per non-zero digit by design; see DESIGN.md 4.2 / 6"}),
+            # the dominant kernel is bound by integer-VALU issue, not by HBM: `frac` is the issue-rate fraction.
+            # Round 6: `achieved` = the VALU wave-instructions the COUNTERS show for the four prove() launches
+            # (SQ_INSTS_VALU, profiles/<tag>/pmc.json `valu_wave_instructions_per_proof`, same build) over this run's hipEvent time of
+            # those launches; `peak` = one VALU wave-instruction per 4 cycles per SIMD.  The static count of rounds 2-5 (non-zero digits x
+            # 4850 instructions per mixed addition, profiles/r02c/accumulate_isa.md) stays as `model` with its ratio to the counters.
+            # The HBM figure the contract asks for (algorithmic (32 b + 96) m bytes per group launch over the launch time) is `hbm`.
+            "roofline": accumulate_roofline(plan, digits_per_scalar * 11 * (n + 6) / max(world, 1) / 64 * 4850, pmc_instr, acc_ms_per_prove,
+                                            dict(traffic=traffic, valu_busy=valu_busy, clock=pmc_clock, frac_clock=pmc_frac_clock, src=pmc_src,
+                                                 instr_launch=pmc_instr_launch),
+                                            dict(achieved=achieved, digits_per_scalar=digits_per_scalar, table_rows=table_rows, avg_acc=avg_acc,
+                                                 acc_n=acc_n, alg_bytes_per_launch=alg_bytes_per_prove // len(groups), groups=groups)),
             # the pass of a proof that comes closest to HBM: quotient_kernel over the quotient-domain points
             "roofline_quotient": quotient_roofline(prover, n, 8 if qd8 else 4, bool(pi), args.profile, q_ms / max(q_n, 1)),
             "kernel_ms_per_prove": {"msm_accumulate": round(acc_ms / args.steps, 3),
@@ -780,19 +865,7 @@ def main():
         vk48 = prover.vk_commitments()
         if world == 1 and not args.no_extras:
             try:   # the boundary handing over HOST wire columns (pinned): PCIe-inclusive prove(), never `value`
-                hw = [plonk_amd.PinnedBuffer(32 * n) for _ in range(4)]
-                for k in range(4):
-                    ctx.d2h_into(hw[k].ptr, wbuf.ptr + 32 * n * k, 32 * n)
-                ptrs = [b.ptr for b in hw]
-                assert prover.prove_host_ptrs(ptrs, pi, blinders) == proof
-                ctx.sync()
-                t1 = time.perf_counter()
-                for _ in range(max(2, min(args.steps, 5))):
-                    prover.prove_host_ptrs(ptrs, pi, blinders)
-                ctx.sync()
-                out["prove_ms_host_wires_pinned"] = round((time.perf_counter() - t1) * 1e3 / max(2, min(args.steps, 5)), 3)
-                for b in hw:
-                    b.free()
+                out["prove_ms_host_wires_pinned"] = host_wire_legs(ctx, prover, wbuf, n, blinders, proof, max(2, min(args.steps, 5)))
             except Exception as e:   # noqa: BLE001
                 out["host_wires_error"] = repr(e)
         if world == 1 and not args.no_extras and args.profile == "dense":
@@ -834,8 +907,15 @@ def main():
             try:   # BASELINE config 5's size on one GPU (commit key streamed from pinned host memory): after everything else, own guard
                 t22 = time.perf_counter()
                 dg = {}
-                out["prove_ms_2p22"] = time_profile(ctx, 22, "dense", 3, blinders, dg)
+                legs = {}
+                try:     # through plonk_compile: the one prover that can start a proof from resident columns, host columns AND the witness table
+                    out["prove_ms_2p22"] = time_profile(ctx, 22, "dense", 3, blinders, dg, host_legs=legs, from_circuit=True)
+                except Exception as e:   # noqa: BLE001   (the coefficient-form constructor of rounds 3-5)
+                    legs = {"compile_path_error": repr(e)}
+                    out["prove_ms_2p22"] = time_profile(ctx, 22, "dense", 3, blinders, dg, host_legs=legs)
+                out["prove_2p22_prover_built_by"] = dg.get("prover_built_by")
                 out["proof_blake2b_2p22"] = dg.get("proof_blake2b")
+                out["host_legs_2p22"] = legs   # the drop-in costs at BASELINE config 5's size
                 out["msm_micro"] = out.get("msm_micro", []) + msm_micro_rows(ctx, 22, 2)   # the 2^22 + 7-point key is still loaded
                 out["prove_2p22_setup_and_run_s"] = round(time.perf_counter() - t22, 1)
             except Exception as e:   # noqa: BLE001

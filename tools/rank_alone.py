@@ -54,7 +54,10 @@ def run(log_n, world, rank, steps):
     out = {"log_gates": log_n, "world": world, "rank": rank, "points": hi - lo, "prove_ms_rank_alone": round(ms, 3), "kernel_ms": slots,
            "table_rows": ctx.table_rows() if hasattr(ctx, "table_rows") else None, "callback_calls": calls[0],
            "wire_split": getattr(bench.build_prover, "wire_split", "range") if world > 1 else None,   # PLONK_BENCH_WIRE_SPLIT=commitment
-           "lagrange_points": prover.describe()["lagrange_points"]}
+           "lagrange_points": prover.describe()["lagrange_points"],
+           # what the commit-key groups of this rank ran as (the last group of a proof is the two opening witnesses over the commit key)
+           "commit_key_plan": {k: v for k, v in ctx.last_msm().items() if k in ("table_rows", "bucket_bits", "digit_width", "slice_entries", "accumulate_kernel")},
+           "forced": {k: v for k, v in os.environ.items() if k.startswith("PLONK_MSM_") or k == "PLONK_BENCH_WIRE_SPLIT"}}
     prover.close()
     wbuf.free()
     ctx.close()

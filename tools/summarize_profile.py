@@ -71,6 +71,7 @@ if acc in pm["FETCH_SIZE"]:
                "share one bucket set; the kernel is integer-VALU bound, not HBM bound.")
     import json
     valu = valu_res = waves = None
+    valu_per_proof = valu_per_launch = prove_ns = frac_at_clock = None
     try:
         # Units (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"): SQ_WAVE_CYCLES and SQ_ACTIVE_INST_VALU count QUAD-cycles
         # summed over waves; SQ_BUSY_CYCLES counts cycles summed over the chip's 32 shader engines (check: srs_generate_kernel,
@@ -96,6 +97,44 @@ if acc in pm["FETCH_SIZE"]:
             return agg[k]["SQ_BUSY_CYCLES"] / (32 * dur[k]) if dur.get(k) else float("nan")
         a = agg[acc]
         waves, valu = occ(acc)
+        # ---- round 6: the roofline leg of bench.py follows from THESE counters, not from a static ISA listing.
+        # SQ_INSTS_VALU per dispatch of the dominant kernel; the counter pass runs the set-up (15 key commitments = 4 group
+        # launches) and then whole proofs (4 launches each: groups of 4 / 1 / 4 / 2 commitments) — the last 4 x proofs dispatches.
+        per_disp = collections.OrderedDict()
+        disp_ns = {}
+        for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+            if r["Kernel_Name"].split("(")[0][:70] != acc:
+                continue
+            if r["Counter_Name"] == "SQ_INSTS_VALU":
+                per_disp[r["Dispatch_Id"]] = per_disp.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+            disp_ns[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        ids = list(per_disp)
+        nproofs_sq = max((len(ids) - 4) // 4, 0)
+        prove_ids = ids[-4 * nproofs_sq:] if nproofs_sq else []
+        valu_per_launch = [per_disp[i] for i in prove_ids[-4:]]
+        valu_per_proof = sum(per_disp[i] for i in prove_ids) / nproofs_sq if nproofs_sq else None
+        prove_ns = sum(disp_ns[i] for i in prove_ids) / nproofs_sq if nproofs_sq else None
+        # issue fraction of the SAME pass, self-consistent (instructions, duration and clock all from these dispatches):
+        # wave-instructions / (1024 SIMDs x cycles / 4) with cycles = clock x duration = BUSY / 32 of the kernel's dispatches
+        busy_prove = None
+        if nproofs_sq:
+            bsum = 0.0
+            for r in rows:
+                if r["Counter_Name"] == "SQ_BUSY_CYCLES" and r["Dispatch_Id"] in set(prove_ids) and r["Kernel_Name"].split("(")[0][:70] == acc:
+                    bsum += float(r["Counter_Value"])
+            busy_prove = bsum / nproofs_sq
+        frac_at_clock = valu_per_proof / (1024 * (busy_prove / 32) / 4) if busy_prove else None
+        if valu_per_proof:
+            out.append(f"\n## Integer-VALU issue of the dominant kernel, from the counters (what `roofline.frac` of bench.py is built on)\n")
+            out.append(f"* SQ_INSTS_VALU of the {len(prove_ids)} prove() launches ({nproofs_sq} proof(s), groups of 4 / 1 / 4 / 2 commitments): "
+                       f"{' + '.join('%.3f' % (v / 1e9) for v in valu_per_launch)} = **{valu_per_proof / 1e9:.3f} G wave-instructions per proof**.")
+            out.append(f"* the same launches took {prove_ns / 1e6:.3f} ms under the counter pass, at {busy_prove / 32 / prove_ns:.3f} GHz (SQ_BUSY_CYCLES / 32 / duration): "
+                       f"{valu_per_proof / prove_ns:.1f} G wave-instructions/s = {valu_per_proof / prove_ns / (1024 * 2.4 / 4):.3f} of the 614.4 G/s peak "
+                       f"(1024 SIMDs x 2.4 GHz / 4 cycles); at the clock the kernel actually ran at, one instruction per "
+                       f"{1024 * (busy_prove / 32) / valu_per_proof:.2f} cycles per SIMD = **{frac_at_clock:.3f}** of one per 4 cycles.")
+            out.append("* bench.py: `roofline.achieved` = `valu_wave_instructions_per_proof` / (its own hipEvent time of the four launches); "
+                       "`frac_at_measured_clock` is quoted from here (one pass, one clock) and can by construction not exceed what the pipe issues.")
+            assert frac_at_clock <= 1.0, f"issue fraction at the measured clock {frac_at_clock:.3f} > 1: the 4-cycle issue class does not describe this kernel"
         valu_res = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / max(waves, 1e-9))   # = valu by construction; kept explicit below
         valu_two = a["SQ_ACTIVE_INST_VALU"] / (a["SQ_WAVE_CYCLES"] / 2)
         out.append(f"\n## VALU utilisation (occupancy derived from the counters)\n\n| kernel | resident waves per SIMD = WAVE_CYCLES / (8 BUSY) | VALU busy = ACTIVE_INST_VALU / (8 BUSY) | shader clock while it runs = BUSY / (32 x duration), GHz |\n|---|---|---|---|")
@@ -114,7 +153,11 @@ if acc in pm["FETCH_SIZE"]:
     except Exception as e:  # noqa
         out.append(f"\n(VALU utilisation unavailable: {e})")
     json.dump({"kernel": acc, "workload": "bench.py 2^20 gates, 1 GPU", "fetch_size_kib_per_launch": fa,
-               "valu_busy_frac": valu, "resident_waves_per_simd": waves, "shader_clock_ghz_under_kernel": clock(acc) if valu is not None else None,
+               "valu_busy_frac": valu, "resident_waves_per_simd": waves,
+               "valu_wave_instructions_per_proof": valu_per_proof, "valu_wave_instructions_per_launch": valu_per_launch,
+               "valu_wave_instructions_source": "SQ_INSTS_VALU summed over the four prove() launches of the kernel (commitment groups of 4 / 1 / 4 / 2), rocprofv3 --pmc pass",
+               "accumulate_ms_per_proof_under_counters": None if not prove_ns else prove_ns / 1e6,
+               "valu_issue_frac_at_measured_clock": frac_at_clock, "shader_clock_ghz_under_kernel": clock(acc) if valu is not None else None,
                "valu_busy_formula": "SQ_ACTIVE_INST_VALU / (8 x SQ_BUSY_CYCLES): quad-cycles over 1024 SIMDs x (BUSY / 32 shader engines) / 4; "
                                     "resident waves per SIMD = SQ_WAVE_CYCLES / (8 x SQ_BUSY_CYCLES)",
                "write_size_kib_per_launch": wa, "traffic_bytes_per_launch": (2 * fa + wa) * 1024,
