@@ -80,7 +80,15 @@ static fr fr_inv(fr a) {   /* a^(q-2) */
 static fr fr_from_u64(u64 v) { fr x = {{v, 0, 0, 0}}, r2; memcpy(r2.l, FR_R2, 32); return fr_mul(x, r2); }
 
 /* ------------------------------------------------------------------ NTT */
-static inline uint32_t bitrev(uint32_t n, uint32_t l) { uint32_t r = 0; for (uint32_t i = 0; i < l; ++i) { r = (r << 1) | (n & 1); n >>= 1; } return r; }
+static inline uint32_t bitrev(uint32_t n, uint32_t l) {   /* the low l bits of n reversed (l <= 32) */
+  if (l == 0) return 0;
+  n = ((n >> 1) & 0x55555555u) | ((n & 0x55555555u) << 1);
+  n = ((n >> 2) & 0x33333333u) | ((n & 0x33333333u) << 2);
+  n = ((n >> 4) & 0x0f0f0f0fu) | ((n & 0x0f0f0f0fu) << 4);
+  n = ((n >> 8) & 0x00ff00ffu) | ((n & 0x00ff00ffu) << 8);
+  n = (n >> 16) | (n << 16);
+  return n >> (32 - l);
+}
 
 /* best_fft (domain.rs:383-422) with OpenMP in place of rayon: bit-reverse, then log n DIT
  * stages.  Each stage's n/2 butterflies are cut into contiguous ranges (one per task); a
@@ -89,8 +97,12 @@ static inline uint32_t bitrev(uint32_t n, uint32_t l) { uint32_t r = 0; for (uin
  * butterfly_chunk (:466-469).  Below 2^12 elements it is the serial_fft (:388,443-463). */
 static void best_fft(fr* a, fr omega, uint32_t log_n, int threads) {
   const u64 n = 1ull << log_n;
-  for (u64 k = 0; k < n; ++k) { u64 rk = bitrev((uint32_t)k, log_n); if (k < rk) { fr t = a[k]; a[k] = a[rk]; a[rk] = t; } }
   if (n < (1u << 12)) threads = 1;
+  /* bitreverse_permute (:429-437; serial in the reference).  Every pair (k, rk) is swapped by the one iteration with k < rk, so
+   * the iterations are independent: run them on all threads (round 6: at 2^25 elements the serial loop — 33 M cache-missing
+   * swaps — was a third of a transform and the 2^22-gate parity test is 22 such transforms).  Same permutation. */
+#pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
+  for (u64 k = 0; k < n; ++k) { u64 rk = bitrev((uint32_t)k, log_n); if (k < rk) { fr t = a[k]; a[k] = a[rk]; a[rk] = t; } }
   const u64 half = n / 2;
   u64 ntasks = (u64)threads * 4;
   if (ntasks > half) ntasks = half ? half : 1;
@@ -126,18 +138,46 @@ int oracle_ntt(u64* data, uint32_t log_n, int inverse, int coset, u64 in_len, in
   fr g; memcpy(g.l, FR_GEN, 32);
   fr omega; memcpy(omega.l, FR_ROOT, 32);
   for (uint32_t i = log_n; i < 32; ++i) omega = fr_mul(omega, omega);
-  if (coset && !inverse) {                          /* distribute_powers :198-204 (serial in the reference) */
-    fr p; memcpy(p.l, FR_ONE, 32);
-    for (u64 i = 0; i < in_len; ++i) { a[i] = fr_mul(a[i], p); p = fr_mul(p, g); }
+  /* multiply a[i] by base^i for i < cnt: distribute_powers (:198-204, a serial running product in the reference) cut into
+   * ranges that seed their running power with base^start — the same products, on all threads */
+#define SCALE_BY_POWERS(base, cnt)                                                                   \
+  do {                                                                                               \
+    const u64 cnt_ = (cnt), blk_ = 1u << 14, nblk_ = (cnt_ + blk_ - 1) / blk_;                       \
+    const fr base_ = (base);                                                                         \
+    _Pragma("omp parallel for num_threads(threads) schedule(static) if (cnt_ >= (1u << 15))")        \
+    for (u64 b_ = 0; b_ < nblk_; ++b_) {                                                             \
+      const u64 lo_ = b_ * blk_, hi_ = lo_ + blk_ < cnt_ ? lo_ + blk_ : cnt_;                        \
+      fr p_ = fr_pow(base_, lo_);                                                                    \
+      for (u64 i_ = lo_; i_ < hi_; ++i_) { a[i_] = fr_mul(a[i_], p_); p_ = fr_mul(p_, base_); }      \
+    }                                                                                                \
+  } while (0)
+  if (!inverse && in_len <= 2) {
+    /* A polynomial of at most two coefficients (the key's constant / linear / identically-zero polynomials, the `linear`
+     * evaluations X, compiler.rs:312-377): its evaluations are a0 + a1 * s * omega^i (s = 7 on the coset) — the transform
+     * of a two-term input written out, not 2^25-point butterflies over zeros.  The reference runs the full transform; the
+     * result is the same unique linear map (closed forms of domain.rs:620-651, tests/test_oracle_c.py). */
+    const fr a0 = in_len ? a[0] : fr_from_u64(0);
+    fr a1 = in_len == 2 ? a[1] : fr_from_u64(0);
+    if (coset) a1 = fr_mul(a1, g);
+    const u64 blk = 1u << 14, nblk = (n + blk - 1) / blk;
+#pragma omp parallel for num_threads(threads) schedule(static) if (n >= (1u << 15))
+    for (u64 b = 0; b < nblk; ++b) {
+      const u64 lo = b * blk, hi = lo + blk < n ? lo + blk : n;
+      fr t = fr_mul(a1, fr_pow(omega, lo));
+      for (u64 i = lo; i < hi; ++i) { a[i] = fr_add(a0, t); t = fr_mul(t, omega); }
+    }
+    return 0;
   }
+  if (coset && !inverse) SCALE_BY_POWERS(g, in_len);
   if (inverse) omega = fr_inv(omega);
   best_fft(a, omega, log_n, threads);
   if (inverse) {
     const fr ninv = fr_inv(fr_from_u64(n));
 #pragma omp parallel for num_threads(threads) schedule(static) if (n >= (1u << 12))
     for (u64 i = 0; i < n; ++i) a[i] = fr_mul(a[i], ninv);
-    if (coset) { fr gi = fr_inv(g), p; memcpy(p.l, FR_ONE, 32); for (u64 i = 0; i < n; ++i) { a[i] = fr_mul(a[i], p); p = fr_mul(p, gi); } }
+    if (coset) SCALE_BY_POWERS(fr_inv(g), n);
   }
+#undef SCALE_BY_POWERS
   return 0;
 }
 

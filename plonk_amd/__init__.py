@@ -795,6 +795,13 @@ class Prover:
                                                         fr_to_bytes_mont(blinders), proof))
         return proof.raw
 
+    def prove_host_bytes(self, wires, public_inputs, blinders_mont: bytes) -> bytes:
+        """plonk_prover_prove on four byte strings of size x 32 B (pageable host memory), blinders as Montgomery bytes"""
+        n = self.size
+        assert all(len(w) == 32 * n for w in wires)
+        bufs = [ctypes.create_string_buffer(bytes(w), 32 * n) for w in wires]
+        return self.prove_host_ptrs([ctypes.addressof(b) for b in bufs], public_inputs, blinders_mont)
+
     def prove_host_ptrs(self, wire_ptrs, public_inputs, blinders_mont: bytes) -> bytes:
         """plonk_prover_prove on four raw host addresses (e.g. PinnedBuffer.ptr): the columns are uploaded on the copy
         stream while round 1 already transforms the ones that have arrived."""

@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
                                                              const uint32_t* __restrict__ offsets_all,
                                                              const uint32_t* __restrict__ slice_off_all,
                                                              G1RSlot* __restrict__ partial_all) {
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
                                                                      const uint32_t* __restrict__ full_off_all,
                                                                      const uint32_t* __restrict__ part_list_all,
                                                                      G1RSlot* __restrict__ partial_all, G1RSlot* __restrict__ buckets_all) {
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3, 3))
 msm_accumulate_lds_kernel(const G1AffineR* __restrict__ table, MsmBatch bt, const uint32_t* __restrict__ entries_all,
                           const uint32_t* __restrict__ offsets_all, const uint32_t* __restrict__ slice_off_all,
                           G1RSlot* __restrict__ partial_all) {
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint32_t* __restrict__ entries = entries_all + (uint64_t)kb * MSM_W * bt.cap_m;
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(128) msm_bucket_sum_kernel(MsmBatch bt, const 
                                                              const uint32_t* __restrict__ nheavy_all, const HeavyItem* __restrict__ heavy_list_all,
                                                              G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap, uint32_t fused, uint32_t direct,
                                                              const uint32_t* __restrict__ multi_list_all, uint32_t dense_quad) {
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
   G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(64) msm_heavy_seg_kernel(MsmBatch bt, const G1
                                                            G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap) {
   // one WAVE per segment: 4 slices per lane, then a 6-step tree over 14 KiB of LDS — ~11 segments in flight per CU
   // (a 256-lane workgroup with its 57 KiB tree buffer allowed 2, and the segment pass was occupancy-bound)
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const G1RSlot* __restrict__ partial = partial_all + (uint64_t)kb * bt.cap_slices;
   const uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)kb * (MSM_NB + 1);
   const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
@@ -645,8 +645,8 @@ __global__ void __launch_bounds__(64) msm_heavy_seg_kernel(MsmBatch bt, const G1
 __global__ void __launch_bounds__(256) msm_heavy_bucket_kernel(const uint32_t* __restrict__ nheavy_all,
                                                                const HeavyItem* __restrict__ heavy_list_all,
                                                                const G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap,
-                                                               G1RSlot* __restrict__ buckets_all) {
-  const int kb = blockIdx.y;
+                                                               G1RSlot* __restrict__ buckets_all, int kb0) {
+  const int kb = (int)blockIdx.y + kb0;
   const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
   const G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
   G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
@@ -910,8 +910,8 @@ __global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G
 __global__ void __launch_bounds__(256) msm_heavy_bucket_quad_kernel(const uint32_t* __restrict__ nheavy_all,
                                                                     const HeavyItem* __restrict__ heavy_list_all,
                                                                     const G1RSlot* __restrict__ seg_sum_all, uint64_t seg_cap,
-                                                                    G1RSlot* __restrict__ buckets_all, uint32_t fused) {
-  const int kb = blockIdx.y;
+                                                                    G1RSlot* __restrict__ buckets_all, uint32_t fused, int kb0) {
+  const int kb = (int)blockIdx.y + kb0;
   const HeavyItem* __restrict__ list = heavy_list_all + (uint64_t)kb * MSM_NB;
   const G1RSlot* __restrict__ seg_sum = seg_sum_all + (uint64_t)kb * seg_cap;
   G1RSlot* __restrict__ buckets = buckets_all + (uint64_t)kb * MSM_NB;
@@ -1338,7 +1338,12 @@ int msm_buckets_bits() { return MSM_NB_BITS; }
 #endif
 // One commitment group through the pipeline: bucket grouping, accumulation, bucket sums, reduction tail.
 // bt arrives filled (scalars, sizes, outputs, table); ksl / wide / heavy_thresh are decided here.
-int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
+// phase: 1 = everything up to the bucket sums of the commitments [bt.kb0, bt.kb0 + bt.count) of the group (bucket sort,
+// accumulation, bucket sums, heavy buckets), 2 = the group's reduction tail (row / column sums ... bit sums) over all
+// bt.group_count commitments, 3 = both (the ordinary grouped launch).  Round 6: a group whose scalars arrive column by
+// column over PCIe (plonk_prover_prove) runs phase 1 per column as it lands and phase 2 once — the throughput-bound
+// part overlaps the copies, the latency-bound tail is still paid once per group.
+int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int phase) {
   MsmWork& w = c->msm;
   hipStream_t st = c->stream;
   const int count = bt.count;
@@ -1356,9 +1361,11 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   // phases: 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums (+ fold), 5 bit sums) —
   // hipEvents between the launches, i.e. kernel times WITHOUT a profiler attached (tools/msm_phases.py)
   const bool fine = c->cfg.prof_fine;
-  const int fbase = count >= 3 ? 16 : 24;
+  const int fbase = bt.group_count >= 3 ? 16 : 24;
 #define FINE_BEGIN(ph) do { if (fine) prof_begin(c, fbase + (ph)); } while (0)
 #define FINE_END(ph) do { if (fine) prof_end(c, fbase + (ph)); } while (0)
+  const bool tail_quad = !c->cfg.tail_serial;
+  if (phase & 1) {
   prof_begin(c, 2);
   FINE_BEGIN(0);
   rc = msm_group_sort(c, bt, mmax);
@@ -1418,17 +1425,24 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
   }
   FINE_END(2);
   FINE_BEGIN(3);
-  const bool tail_quad = !c->cfg.tail_serial;
   if (tail_quad || MSM_NB_BITS > 15) {
     hipLaunchKernelGGL(msm_heavy_bucket_quad_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
-                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets, HEAVY_FUSED_WGS);
+                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets, HEAVY_FUSED_WGS, bt.kb0);
   } else {
     hipLaunchKernelGGL(msm_heavy_seg_kernel, dim3(4 * HEAVY_WGS, count), dim3(64), 0, st, bt, (const G1RSlot*)w.partial, w.slice_off,
                        w.nheavy, (const HeavyItem*)w.heavy_list, (G1RSlot*)w.seg_sum, w.cap_segs);
     hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(256, count), dim3(256), 0, st, w.nheavy, (const HeavyItem*)w.heavy_list,
-                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets);
+                       (const G1RSlot*)w.seg_sum, w.cap_segs, (G1RSlot*)w.buckets, bt.kb0);
   }
   FINE_END(3);
+  if (!(phase & 2)) { prof_end(c, 2); HIP_TRY(hipGetLastError()); return PLONK_OK; }
+  } else {
+    prof_begin(c, 2);
+  }
+  // ---- the group's reduction tail: over every commitment of the group
+  bt.kb0 = 0;
+  bt.count = bt.group_count;
+  const int count_g = bt.group_count;
   c->msm.last_rowbits = 8 + (MSM_NB_BITS - 15);
 #if PLONK_MSM_NB_BITS > 15
   {   // many buckets: throughput row / column sums, the fold to the 2^15 shapes, then the same bit sums (outputs shifted by E)
@@ -1436,27 +1450,27 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     G1RSlot* rc2 = rc1 + (size_t)TP_RC1 * MSM_MAX_BATCH;
     // PLONK_MSM_RCTREE=lane: the partial sums of a row / column combined by a lane tree instead of quads (A/B)
     const bool rc_lane_tree = c->cfg.rc_lane_tree;
-#define TPK(LPS) do { if (rc_lane_tree) hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, false>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); \
-                      else hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, true>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); } while (0)
+#define TPK(LPS) do { if (rc_lane_tree) hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, false>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count_g), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); \
+                      else hipLaunchKernelGGL((msm_rowcol_tp_kernel<LPS, true>), dim3(TP_ROWS * LPS / 128 + TP_PARTS * LPS, count_g), dim3(128), 0, st, (const G1RSlot*)w.buckets, rc1); } while (0)
     // lanes per sum of 128 buckets: the chip holds 2^17 lanes at two waves per SIMD and a commitment has 2^13 sums; fewer
     // lanes per sum waste less of the tree steps (useful additions per lane-step: LPS 4: 96 %, 8: 88 %, 16: 72 %, 32: 50 %)
     // but lengthen the serial chain.  Measured (profiles/r03e section 7): 8 / 8 / 16 for groups of >= 3 / 2 / 1 commitments
     // (until then 8 / 16 / 32: the small groups over-subscribed the chip two-fold for the sake of depth); 4 for the large
     // groups gains nothing at 2^20 and loses 0.5 ms at 2^22, where the kernel shares the chip with longer transforms.
     const int lps_env = c->cfg.lps;   // PLONK_MSM_LPS: A/B runs
-    int lps = count >= 2 ? 8 : 16;
+    int lps = count_g >= 2 ? 8 : 16;
     // 2^17 buckets (r04): a quarter of the sums — 8 lanes per sum left half of the chip idle behind 18 dependent additions
     // (0.64 ms per group of four, profiles/r04d); lanes per sum so that a launch has about the chip's 2^17 lane slots
-    if (MSM_NB_BITS == 17) lps = count >= 3 ? 16 : 32;
+    if (MSM_NB_BITS == 17) lps = count_g >= 3 ? 16 : 32;
     if (lps_env == 4 || lps_env == 8 || lps_env == 16 || lps_env == 32) lps = lps_env;
-    else if (lps_env == 1) lps = count >= 3 ? 8 : (count == 2 ? 16 : 32);   // the old rule
+    else if (lps_env == 1) lps = count_g >= 3 ? 8 : (count_g == 2 ? 16 : 32);   // the old rule
     FINE_BEGIN(4);
     if (lps == 4) TPK(4); else if (lps == 8) TPK(8); else if (lps == 16) TPK(16); else TPK(32);
 #undef TPK
-    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + TP_NP + 128, count), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
+    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + TP_NP + 128, count_g), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
     FINE_END(4);
     FINE_BEGIN(5);
-    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
+    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count_g), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
     FINE_END(5);
     prof_end(c, 2);
     HIP_TRY(hipGetLastError());
@@ -1467,27 +1481,27 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums) {
     // waves per sum so that the 512 sums per commitment fit the chip's wave slots in one round (1024 SIMDs x 2 waves)
     FINE_BEGIN(4);
     const int rcwv_env = c->cfg.rcwv;   // PLONK_MSM_RCWV, A/B runs: waves per sum for groups of 1 / 2 / >= 3 commitments as a 3-digit number, e.g. 421
-    int wv = count >= 3 ? 1 : (count == 2 ? 2 : 4);
-    if (rcwv_env >= 111) wv = count >= 3 ? rcwv_env % 10 : (count == 2 ? (rcwv_env / 10) % 10 : rcwv_env / 100);
-    if (wv == 1) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
-    else if (wv == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
-    else hipLaunchKernelGGL(msm_rowcol_quad_kernel<4>, dim3(RCQ_SUMS, count), dim3(256), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    int wv = count_g >= 3 ? 1 : (count_g == 2 ? 2 : 4);
+    if (rcwv_env >= 111) wv = count_g >= 3 ? rcwv_env % 10 : (count_g == 2 ? (rcwv_env / 10) % 10 : rcwv_env / 100);
+    if (wv == 1) hipLaunchKernelGGL(msm_rowcol_quad_kernel<1>, dim3(RCQ_SUMS, count_g), dim3(64), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    else if (wv == 2) hipLaunchKernelGGL(msm_rowcol_quad_kernel<2>, dim3(RCQ_SUMS, count_g), dim3(128), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
+    else hipLaunchKernelGGL(msm_rowcol_quad_kernel<4>, dim3(RCQ_SUMS, count_g), dim3(256), 0, st, (const G1RSlot*)w.buckets, (G1RSlot*)w.chunk);
     FINE_END(4);
     FINE_BEGIN(5);
-    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17, count), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk, (uint32_t)RCQ_SUMS, 0u);
+    hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17, count_g), dim3(256), 0, st, bt, (const G1RSlot*)w.chunk, (uint32_t)RCQ_SUMS, 0u);
     FINE_END(5);
     prof_end(c, 2);
     HIP_TRY(hipGetLastError());
     return PLONK_OK;
   }
-  hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count), dim3(256), 0, st, (const G1RSlot*)w.buckets,
+  hipLaunchKernelGGL(msm_rowcol_kernel, dim3(RC_WG, count_g), dim3(256), 0, st, (const G1RSlot*)w.buckets,
                      (G1RSlot*)w.chunk);
   if (bit_sums) {
-    hipLaunchKernelGGL(msm_bits_kernel, dim3(17, count), dim3(128), 0, st, bt, (const G1RSlot*)w.chunk);
+    hipLaunchKernelGGL(msm_bits_kernel, dim3(17, count_g), dim3(128), 0, st, bt, (const G1RSlot*)w.chunk);
   } else {
     constexpr size_t smem = sizeof(G1R) * (RC_ROWS + RC_COLS);
     smem_opt_in(c, (const void*)msm_final_kernel, smem);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(count), dim3(384), smem, st, bt, (const G1RSlot*)w.chunk);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(count_g), dim3(384), smem, st, bt, (const G1RSlot*)w.chunk);
   }
   prof_end(c, 2);
   HIP_TRY(hipGetLastError());
@@ -1623,9 +1637,13 @@ void msm_plan(const Ctx* c, uint32_t table_rows, uint64_t table_n, uint64_t mmax
 // instead of 14.7 additions per scalar, a bucket is one lane of ~24 entries — else 2^15 (nb15).  PLONK_MSM_BUCKETS=15 / 19
 // forces either wherever it is possible (19 needs bit-position tables and the bit-sum tail).
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_dev, bool bit_sums,
-                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split, uint32_t table_rows) {
+                     const void* table, uint64_t table_n, const Fr* const* tail_dev, const uint64_t* split, uint32_t table_rows,
+                     int phase, int kb0, int kcount) {
   if (count <= 0) return PLONK_OK;
   if (count > MSM_MAX_BATCH) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (kcount < 0) kcount = count - kb0;
+  if (phase < 1 || phase > 3 || kb0 < 0 || kcount < 1 || kb0 + kcount > count || (phase == 3 && (kb0 != 0 || kcount != count)))
+    return (plonk::set_last_error("invalid argument", "msm_batch_device: phase / column range", __FILE__, __LINE__), PLONK_ERR_ARG);
   if (!table) { table = c->srs_table; table_n = c->srs_n; table_rows = c->srs_rows; }
   if (table && table_rows != MSM_ROWS_WINDOW && table_rows != MSM_ROWS_BITPOS && table_rows != MSM_ROWS_HALFPOS) return (plonk::set_last_error("invalid argument", "msm: table rows", __FILE__, __LINE__), PLONK_ERR_ARG);
   uint64_t mmax = 0;
@@ -1635,6 +1653,7 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   }
   hipStream_t st = c->stream;
   if (mmax == 0) {
+    if (!(phase & 2)) return PLONK_OK;   // (a group in parts: the identities are written with the tail)
     c->msm.last_rowbits = 8;
     for (int k = 0; k < count; ++k)
       for (int j = 0; j < (bit_sums ? MSM_BIT_SUMS : 1); ++j) hipLaunchKernelGGL(msm_identity_kernel, dim3(1), dim3(64), 0, st, out_dev[k] + j);
@@ -1647,7 +1666,9 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   if (rc) return rc;
   MsmWork& w = c->msm;
   MsmBatch bt{};
-  bt.count = count;
+  bt.count = (phase & 1) ? kcount : count;
+  bt.kb0 = (phase & 1) ? kb0 : 0;
+  bt.group_count = count;
   bt.cap_m = w.cap_m;
   bt.cap_slices = w.cap_slices;
   bt.table = table;
@@ -1662,13 +1683,13 @@ int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, in
   msm_plan(c, table_rows, table_n, mmax, count, bit_sums, &plan);
   c->last_plan = plan;
   const int nb_bits = (int)plan.bucket_bits;
-  if (nb_bits == 19) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums);
+  if (nb_bits == 19) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums, phase);
 #ifdef PLONK_MSM_WITH_MEDIUM
-  if (nb_bits == 17) return nbm::msm_batch_device_v(c, bt, mmax, bit_sums);
+  if (nb_bits == 17) return nbm::msm_batch_device_v(c, bt, mmax, bit_sums, phase);
 #else
-  if (nb_bits == 17) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums);
+  if (nb_bits == 17) return nbl::msm_batch_device_v(c, bt, mmax, bit_sums, phase);
 #endif
-  return nb15::msm_batch_device_v(c, bt, mmax, bit_sums);
+  return nb15::msm_batch_device_v(c, bt, mmax, bit_sums, phase);
 }
 
 int msm_device(Ctx* c, const Fr* scalars_dev, uint64_t m, G1* out_dev) {

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(SORT_T) msm_hist_kernel(MsmBatch bt, uint32_t*
   constexpr bool BITPOS = MODE != 0;                   // the scalar is parked in LDS for the run-time bit positions of modes 1 and 2
   __shared__ uint32_t hist[COARSE];
   __shared__ uint32_t park[BITPOS ? 9 * SORT_T : 1];   // bit-position recoding: the canonical scalar, limb-major, + a zero limb (StridedLimbs)
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint64_t m = bt.m[kb];
   const uint64_t base = (uint64_t)blockIdx.x * HIST_TILE;
   if (base >= m) return;
@@ -201,12 +201,12 @@ __device__ __forceinline__ uint32_t big_chunks(uint32_t cnt) { return cnt > BIG_
 __global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t* __restrict__ coarse_cnt_all,
                                                                  uint32_t* __restrict__ coarse_off_all,
                                                                  uint32_t* __restrict__ coarse_cur_all,
-                                                                 uint32_t* __restrict__ big_off_all) {
+                                                                 uint32_t* __restrict__ big_off_all, int kb0) {
   __shared__ uint32_t sh[SORT_T];
-  const uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)blockIdx.x * COARSE;
-  uint32_t* __restrict__ off = coarse_off_all + (uint64_t)blockIdx.x * (COARSE + 1);
-  uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)blockIdx.x * COARSE;
-  uint32_t* __restrict__ big = big_off_all + (uint64_t)blockIdx.x * (COARSE + 1);
+  const uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * COARSE;
+  uint32_t* __restrict__ off = coarse_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (COARSE + 1);
+  uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * COARSE;
+  uint32_t* __restrict__ big = big_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (COARSE + 1);
   const uint32_t t = threadIdx.x;
   const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
   uint32_t total;
@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(SORT_T) msm_partition_kernel(MsmBatch bt, uint
   uint32_t* loff = hist + COARSE;                 // COARSE: start of the bin's run inside `stage`
   uint32_t* gbase = loff + COARSE;                // COARSE: start of the run in the global array
   __shared__ uint32_t sh[SORT_T];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint64_t m = bt.m[kb];
   const uint64_t base = (uint64_t)blockIdx.x * TILE;
   if (base >= m) return;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(P2_T, 4) msm_partition2_kernel(MsmBatch bt, ui
   uint32_t* loff = hist + COARSE;
   uint32_t* gbase = loff + COARSE;
   __shared__ uint32_t sh[P2_T];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint64_t m = bt.m[kb];
   const uint64_t base = (uint64_t)blockIdx.x * P2_TILE;
   if (base >= m) return;
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(FINE_T) msm_fine_kernel(MsmBatch bt, const uin
                                                           uint32_t* __restrict__ entries_all,
                                                           uint32_t* __restrict__ offsets_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS], start[1u << FINE_BITS], cur[1u << FINE_BITS], scan_tmp[1u << FINE_BITS];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_hist_kernel(MsmBatch bt, const 
                                                              const uint32_t* __restrict__ big_off_all,
                                                              void* __restrict__ tmp_all, uint32_t* __restrict__ big_cnt_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
   const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
                                                                 const uint32_t* __restrict__ big_cnt_all, uint32_t* __restrict__ big_cur_all,
                                                                 uint32_t* __restrict__ entries_all, uint32_t* __restrict__ offsets_all) {
   __shared__ uint32_t cnt[1u << FINE_BITS], base[1u << FINE_BITS], cur[1u << FINE_BITS], bin_cnt[1u << FINE_BITS], scan_tmp[1u << FINE_BITS];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + bt.kb0;
   const uint32_t* __restrict__ coff = coarse_off_all + (uint64_t)kb * (COARSE + 1);
   const uint32_t* __restrict__ big = big_off_all + (uint64_t)kb * (COARSE + 1);
   const TmpPlanes<WordT> tmp(tmp_all, kb, (uint64_t)MSM_W * bt.cap_m);
@@ -589,12 +589,12 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
 static constexpr uint32_t HEAVY_SEG_SLICES = 128;   // = HEAVY_SEG of msm.hip
 __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __restrict__ offsets_all,
                                                             uint32_t* __restrict__ slice_off_all, uint32_t ksl, uint32_t heavy_thresh,
-                                                            uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all) {
+                                                            uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all, int kb0) {
   __shared__ uint32_t sh[SORT_T];
-  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
-  uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
-  uint32_t* __restrict__ nheavy = nheavy_all + 2 * blockIdx.x;
-  HeavyItem* __restrict__ heavy_list = heavy_list_all + (uint64_t)blockIdx.x * MSM_NB;
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
+  uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
+  uint32_t* __restrict__ nheavy = nheavy_all + 2 * (blockIdx.x + (uint32_t)kb0);
+  HeavyItem* __restrict__ heavy_list = heavy_list_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * MSM_NB;
   constexpr uint32_t PER = MSM_NB / SORT_T;
   const uint32_t t = threadIdx.x;
   // the thread's PER + 1 bucket offsets in ONE batch of independent loads (r04: the two loops of dependent reads this
@@ -633,12 +633,12 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
 // part_list; part_list[NB] = their number).  The partial sums keep their slots slice_off[b] + q, so nothing after the
 // accumulation changes.  tests/msm_wide_model.py::slice_order is the executable statement of this map.
 __global__ void __launch_bounds__(SORT_T) msm_order_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ full_off_all,
-                                                           uint32_t* __restrict__ part_list_all, uint32_t ksl) {
+                                                           uint32_t* __restrict__ part_list_all, uint32_t ksl, int kb0) {
   __shared__ uint32_t sh[SORT_T];
   __shared__ uint32_t hist[129];   // ksl <= 128
-  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
-  uint32_t* __restrict__ full_off = full_off_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
-  uint32_t* __restrict__ part_list = part_list_all + (uint64_t)blockIdx.x * (MSM_NB + 1);
+  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
+  uint32_t* __restrict__ full_off = full_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
+  uint32_t* __restrict__ part_list = part_list_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
   constexpr uint32_t PER = MSM_NB / SORT_T;
   const uint32_t t = threadIdx.x;
   if (t < 129) hist[t] = 0;
@@ -681,10 +681,10 @@ __global__ void __launch_bounds__(SORT_T) msm_order_kernel(const uint32_t* __res
 static constexpr uint32_t LAY_NBLK = MSM_NB / SORT_T, LAY_H = 132;
 static constexpr uint32_t LAY_WORDS = 2 * LAY_NBLK + (LAY_NBLK + 1) * LAY_H;
 __global__ void __launch_bounds__(SORT_T) msm_layout_count_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ slice_off_all,
-                                                                  uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ lay_all, uint32_t ksl) {
+                                                                  uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ lay_all, uint32_t ksl, int kb0) {
   __shared__ uint32_t sh[SORT_T];
   __shared__ uint32_t hist[LAY_H];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + kb0;
   const uint32_t blk = blockIdx.x, t = threadIdx.x, b = blk * SORT_T + t;
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   uint32_t* __restrict__ lay = lay_all + (uint64_t)kb * LAY_WORDS;
@@ -702,10 +702,10 @@ __global__ void __launch_bounds__(SORT_T) msm_layout_count_kernel(const uint32_t
   if (t < LAY_H) lay[2 * LAY_NBLK + blk * LAY_H + t] = hist[t];   // (the scans' barriers completed the histogram)
 }
 __global__ void __launch_bounds__(SORT_T) msm_layout_scan_kernel(uint32_t* __restrict__ slice_off_all, uint32_t* __restrict__ full_off_all,
-                                                                 uint32_t* __restrict__ part_list_all, uint32_t* __restrict__ lay_all, uint32_t ksl) {
+                                                                 uint32_t* __restrict__ part_list_all, uint32_t* __restrict__ lay_all, uint32_t ksl, int kb0) {
   __shared__ uint32_t sh[SORT_T];
   __shared__ uint32_t ctot[LAY_H];
-  const int kb = blockIdx.x;
+  const int kb = (blockIdx.x + (uint32_t)kb0);
   const uint32_t t = threadIdx.x;
   uint32_t* __restrict__ lay = lay_all + (uint64_t)kb * LAY_WORDS;
   static_assert(LAY_NBLK <= SORT_T, "one thread per block total");
@@ -741,9 +741,9 @@ __global__ void __launch_bounds__(SORT_T) msm_layout_apply_kernel(const uint32_t
                                                                   uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ part_list_all,
                                                                   const uint32_t* __restrict__ lay_all, uint32_t ksl, uint32_t heavy_thresh,
                                                                   uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all,
-                                                                  uint4* __restrict__ buckets_raw, uint32_t* __restrict__ multi_list_all) {
+                                                                  uint4* __restrict__ buckets_raw, uint32_t* __restrict__ multi_list_all, int kb0) {
   __shared__ uint32_t rank[LAY_H];
-  const int kb = blockIdx.y;
+  const int kb = (int)blockIdx.y + kb0;
   const uint32_t blk = blockIdx.x, t = threadIdx.x, b = blk * SORT_T + t;
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)kb * (MSM_NB + 1);
   const uint32_t* __restrict__ lay = lay_all + (uint64_t)kb * LAY_WORDS;
@@ -791,7 +791,7 @@ int msm_order_slices(Ctx* c, const MsmBatch& bt) {
 #else
   MsmWork& w = c->msm;
   if (bt.ksl > 128) return (set_last_error("msm_order_slices", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
-  hipLaunchKernelGGL(msm_order_kernel, dim3(bt.count), dim3(SORT_T), 0, c->stream, w.offsets, w.full_off, w.part_list, bt.ksl);
+  hipLaunchKernelGGL(msm_order_kernel, dim3(bt.count), dim3(SORT_T), 0, c->stream, w.offsets, w.full_off, w.part_list, bt.ksl, bt.kb0);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 #endif
@@ -805,9 +805,12 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   const uint32_t tiles = (uint32_t)((mmax + TILE - 1) / TILE);
   const uint32_t htiles = (uint32_t)((mmax + HIST_TILE - 1) / HIST_TILE);
   void* tmp = (void*)w.tmp_words;
-  HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * bt.count, st));
+  // bt.kb0 > 0 (a group launched column by column, msm_batch_device's phases): this launch covers commitments
+  // [kb0, kb0 + count) of the group's buffers — every kernel adds kb0 to its blockIdx-derived commitment index
+  const int kb0 = bt.kb0;
+  HIP_TRY(hipMemsetAsync(w.coarse_cnt + (size_t)COARSE * kb0, 0, sizeof(uint32_t) * COARSE * bt.count, st));
   hipLaunchKernelGGL(msm_hist_kernel<MODE>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
-  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off);
+  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off, kb0);
 #if PLONK_MSM_NB_BITS >= 19
   if constexpr (MODE != 0) {
     if (c->cfg.sort13 == 1) {   // round 5 A/B: two half-size partition workgroups per CU (13 digit slots of 1024 scalars)
@@ -831,21 +834,31 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
     const uint64_t words = (uint64_t)MSM_W * mmax;
     const uint32_t most = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
     const uint32_t big_wgs = most < 512u ? most : 512u;   // the kernels stride over the chunk list
-    HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
+    if (kb0 == 0 && bt.count == bt.group_count) {
+      HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
+    } else {   // a column launch clears only its own counters (the other columns' may be in use on another stream one day)
+      HIP_TRY(hipMemsetAsync(w.big_cnt + (size_t)MSM_NB * kb0, 0, sizeof(uint32_t) * MSM_NB * bt.count, st));
+      HIP_TRY(hipMemsetAsync(w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH + (size_t)MSM_NB * kb0, 0, sizeof(uint32_t) * MSM_NB * bt.count, st));
+    }
     hipLaunchKernelGGL(msm_big_hist_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp, w.big_cnt);
     hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp,
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
-  HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 4 * MSM_MAX_BATCH, st));
+  if (kb0 == 0 && bt.count == bt.group_count) {
+    HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 4 * MSM_MAX_BATCH, st));
+  } else {   // nheavy[2 kb], nheavy[2 kb + 1] (heavy buckets / segments) and nheavy[2 KB + kb] (multi-slice buckets) of these columns
+    HIP_TRY(hipMemsetAsync(w.nheavy + 2 * kb0, 0, sizeof(uint32_t) * 2 * bt.count, st));
+    HIP_TRY(hipMemsetAsync(w.nheavy + 2 * MSM_MAX_BATCH + kb0, 0, sizeof(uint32_t) * bt.count, st));
+  }
 #if PLONK_MSM_NB_BITS > 15
   if (bt.ksl > 128) return (set_last_error("msm_group_sort", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
-  hipLaunchKernelGGL(msm_layout_count_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.layout, bt.ksl);
-  hipLaunchKernelGGL(msm_layout_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.slice_off, w.full_off, w.part_list, w.layout, bt.ksl);
+  hipLaunchKernelGGL(msm_layout_count_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.layout, bt.ksl, kb0);
+  hipLaunchKernelGGL(msm_layout_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.slice_off, w.full_off, w.part_list, w.layout, bt.ksl, kb0);
   hipLaunchKernelGGL(msm_layout_apply_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.part_list,
-                     (const uint32_t*)w.layout, bt.ksl, bt.heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list, (uint4*)w.buckets, w.multi_list);
+                     (const uint32_t*)w.layout, bt.ksl, bt.heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list, (uint4*)w.buckets, w.multi_list, kb0);
 #else
   hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
-                     w.nheavy, (HeavyItem*)w.heavy_list);
+                     w.nheavy, (HeavyItem*)w.heavy_list, kb0);
 #endif
   HIP_TRY(hipGetLastError());
   return PLONK_OK;

@@ -105,6 +105,10 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   // blinders elsewhere); split[k] >= m[k] when the scalars are one array
   const Fr* tail[MSM_MAX_BATCH];
   uint64_t split[MSM_MAX_BATCH];
+  // a group launched in parts (round 6: wire columns that arrive one after the other over PCIe): this launch covers the
+  // `count` commitments [kb0, kb0 + count) of a group of `group_count`; scalars[] / m[] / out[] stay indexed by the GROUP's kb
+  int kb0;
+  int group_count;
 };
 
 struct HeavyItem { uint32_t bucket, seg_base, nseg, pad; };   // a bucket with far more slices than expected, cut into 256-slice segments
@@ -171,6 +175,7 @@ struct Config {
   bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
+  int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN=0 -> -1: host wire columns commit as ONE grouped launch after the last copy (round 5), A/B
   int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
 };
 
@@ -277,7 +282,7 @@ static constexpr int MSM_BIT_SUMS = 12 + 9;          // slots per commitment (th
   int msm_order_slices(Ctx* c, const MsmBatch& bt);                                                                      \
   int msm_group_sort(Ctx* c, const MsmBatch& bt, uint64_t mmax);                                                         \
   bool msm_needs_wide_words(uint32_t rows, uint64_t table_n);                                                            \
-  int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums);                                            \
+  int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int phase);                                 \
   uint32_t msm_ksl(const Ctx* c, uint64_t m);                                                                            \
   bool msm_acc_ordered(const Ctx* c, uint32_t ksl);
 namespace nb15 { PLONK_MSM_VARIANT_DECLS }
@@ -289,7 +294,11 @@ namespace nbl { PLONK_MSM_VARIANT_DECLS int msm_buckets_bits(); }
 // c->msm.last_rowbits tells the caller how the bit sums of THIS call are laid out (finish_bit_sums).
 int msm_batch_device(Ctx* c, const Fr* const* scalars_dev, const uint64_t* m, int count, G1* const* out_xyzz_dev,
                      bool bit_sums = false, const void* table = nullptr, uint64_t table_n = 0,
-                     const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr, uint32_t table_rows = 0);
+                     const Fr* const* tail_dev = nullptr, const uint64_t* split = nullptr, uint32_t table_rows = 0,
+                     int phase = 3, int kb0 = 0, int kcount = -1);
+// phase / kb0 / kcount (round 6): a group launched in parts.  phase 1 = bucket sort + accumulation + bucket sums of the
+// commitments [kb0, kb0 + kcount) only; phase 2 = the group's reduction tail over all `count`; 3 = the ordinary grouped launch.
+// The caller passes the SAME arrays (all `count` entries) to every part and runs the parts on one stream, phase 2 last.
 // rows of the tables of an n-point key — 256 (one per bit position), 128 (every second) or the 16 window rows — from the
 // context's table budget and what it already holds (msm.hip); Config::table_mode forces one
 // last_key: the key is built after everything else the context needs (a prover's Lagrange-basis key) and may take what is

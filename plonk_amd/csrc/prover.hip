@@ -185,14 +185,17 @@ static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 17 bit su
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
 // [shard_lo, shard_lo + srs_n) against the matching scalars; partial sums are combined in
 // fetch_commitments.  With world == 1 this is the whole MSM.
+// phase / kb0 / kcount: a group over a prover-owned key launched in parts (msm_batch_device) — the wire columns of
+// plonk_prover_prove as they arrive over PCIe
 static int msm_group(Prover* p, const Fr* const* scalars, const uint64_t* m, int count, int first_slot,
-                     const void* table = nullptr, uint64_t table_n = 0, const Fr* const* tail = nullptr, const uint64_t* split = nullptr) {
+                     const void* table = nullptr, uint64_t table_n = 0, const Fr* const* tail = nullptr, const uint64_t* split = nullptr,
+                     int phase = 3, int kb0 = 0, int kcount = -1) {
   const Fr* sc[MSM_MAX_BATCH];
   uint64_t cnt[MSM_MAX_BATCH];
   G1* out[MSM_MAX_BATCH];
   if (table) {   // a prover-owned key (Lagrange basis, single GPU): no point-range sharding
     for (int k = 0; k < count; ++k) { out[k] = (G1*)(p->res + RES_STRIDE * (first_slot + k)); p->res_bitpos[first_slot + k] = p->lag_rows == MSM_ROWS_BITPOS; }
-    const int rc = msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split, p->lag_rows);
+    const int rc = msm_batch_device(p->c, scalars, m, count, out, true, table, table_n, tail, split, p->lag_rows, phase, kb0, kcount);
     for (int k = 0; k < count; ++k) p->res_rowbits[first_slot + k] = p->c->msm.last_rowbits;
     return rc;
   }
@@ -810,9 +813,9 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // ---- round 1 (prover.rs:444-479)
   const bool lag = p->lag_on;
   // iNTT + blinding of the four columns and their lowest coefficients (quotient_low), on the CURRENT stream
-  auto wire_polynomials = [&](Fr* ntt_tmp) -> int {
+  auto wire_polynomials = [&](Fr* ntt_tmp, int k0 = 0, int k1 = 4) -> int {
     prof_begin(c, 4);   // slot 4: the polynomial work of rounds 1-2 (replicated on every rank of a multi-GPU run)
-    for (int k = 0; k < 4; ++k) {
+    for (int k = k0; k < k1; ++k) {
       Fr* wp = p->wpoly + k * np;
       if (p->wires_pending) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_wire[k], 0));   // column k has arrived
       PTRY(ntt_device(c, wires_dev + k * n, wp, ntt_tmp, L, true, false, n));
@@ -824,7 +827,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       PTRY(poly_blind(c, wp, n, ba));
     }
     prof_end(c, 4);
-    for (int k = 0; k < 4; ++k)
+    for (int k = k0; k < k1; ++k)
       HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     return PLONK_OK;
   };
@@ -832,8 +835,18 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // on) ride on the side stream under it; above, the accumulation owns the VALU and the side stream would only fall
   // behind (A/B at 2^20, r02: +0.7 ms), so they keep their place in front of the commitment.
   const bool polys_on_side = lag && L <= 18;
-  if (!polys_on_side) PTRY(wire_polynomials(p->tmp8));
-  if (lag) {
+  // Host wire columns (plonk_prover_prove, round 6): column k lands over PCIe 32 n bytes after column k - 1 (0.65 ms apart at
+  // 2^20 gates), and until round 5 the commitment group waited for all four before its grouped bucket sort — 2.1 ms of every
+  // such proof with nothing but the four inverse transforms to hide in.  Now each column's transform is followed at once by
+  // ITS bucket sort, accumulation and bucket sums (msm_batch_device phase 1 on column k: the throughput-bound 90 % of a
+  // commitment), under the next columns' copies; the latency-bound reduction tail still runs once for the group (phase 2).
+  // Same additions, same bucket sums, same bytes.  Resident columns (plonk_prover_prove_dev, what `value` times) keep the
+  // grouped launch: four launches have four ramp-downs.
+  const bool by_column = lag && p->wires_pending && !polys_on_side && c->cfg.wire_by_column >= 0;
+  if (!polys_on_side && !by_column) PTRY(wire_polynomials(p->tmp8));
+  if (lag && by_column) {
+    HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+  } else if (lag) {
     // Lagrange-basis key: a(X) = sum_i w_i L_i(X) + b0 (X^n - 1) + b1 (X^(n+1) - X)  (blind_poly, prover.rs:139-152), so the
     // commitment is an MSM of the wire VALUES and the two blinders over [L_i(tau)] G, [tau^n] G - G, [tau^(n+1)] G - [tau] G
     // (the values are read in place; only the eight blinders travel: bl[0..8) = a0 a1 b0 b1 c0 c1 d0 d1)
@@ -867,11 +880,26 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     if (pi_len) PTRY(ntt_device(c, p->pipoly, p->cos + 5 * n8, p->tmp8b, L + p->lq, false, true, pi_len));   // no public inputs: PI(X) = 0, nothing to transform or read
     return PLONK_OK;
   };
-  if (!side_defer) {
+  if (!side_defer && !by_column) {
     SideScope side(c, p->ev_ready);
     PTRY(side_round1());
   }
-  {
+  if (by_column) {
+    const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
+    const Fr* sc[4] = {wires_dev, wires_dev + n, wires_dev + 2 * n, wires_dev + 3 * n};
+    const Fr* tl[4] = {p->wscal, p->wscal + 2, p->wscal + 4, p->wscal + 6};
+    const uint64_t sp[4] = {n, n, n, n};
+    for (int k = 0; k < 4; ++k) {
+      PTRY(wire_polynomials(p->tmp8, k, k + 1));   // waits for column k's copy, then its inverse transform + blinding
+      if (k == 3 && !side_defer) {                 // all four polynomials exist: their coset transforms go to the side stream
+        SideScope side(c, p->ev_ready);
+        PTRY(side_round1());
+      }
+      AccMark mark(c, (side_defer && k == 3) ? p->ev_acc : nullptr);
+      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 1, k, 1));
+    }
+    PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 2));
+  } else {
     AccMark mark(c, side_defer ? p->ev_acc : nullptr);
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
     if (lag) {

@@ -128,7 +128,17 @@ uint64_t kernel_timeout_ticks() {   // wall_clock64 counts at 100 MHz on gfx9
   return (uint64_t)(env_seconds("FAKE_RCCL_KERNEL_TIMEOUT_S", 120.0) * 1e8);
 }
 
+// Fault injection.  FAKE_RCCL_DIE_RANK / FAKE_RCCL_DIE_AT=<kind>:<k> make that rank _exit(17) on entering its k-th collective of
+// that kind — counted from communicator creation, or, after fake_rccl_arm() (called by the test harness once the prover is
+// built), from the moment of arming: "the z commitment's all-gather of the first proof" then stays the same index however
+// many collectives prover creation needs (round 6 added three: mode agreement, the Lagrange-key check).
+static int g_arm_allgather = 0, g_arm_alltoall = 0, g_seen_allgather = 0, g_seen_alltoall = 0;
+extern "C" void fake_rccl_arm(void) { g_arm_allgather = g_seen_allgather; g_arm_alltoall = g_seen_alltoall; }
+
 void maybe_die(Comm* c, const char* kind, int nth) {
+  const bool ag = kind[3] == 'g';   // "allgather" / "alltoall"
+  (ag ? g_seen_allgather : g_seen_alltoall) = nth;
+  nth -= ag ? g_arm_allgather : g_arm_alltoall;
   const char* r = getenv("FAKE_RCCL_DIE_RANK");
   const char* at = getenv("FAKE_RCCL_DIE_AT");
   if (!r || !at || atoi(r) != c->rank) return;

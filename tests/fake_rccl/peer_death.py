@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Peer failure inside a sharded proof, on ONE GPU, through the stand-in transport (test infrastructure).
 
-  python tests/fake_rccl/peer_death.py WORLD LOG_GATES DIE_RANK DIE_AT [noabort]       e.g.  2 12 1 alltoall:2
+  python tests/fake_rccl/peer_death.py WORLD LOG_GATES DIE_RANK DIE_AT [noabort]       e.g.  2 12 1 alltoall:1
 
 Starts WORLD ranks that share device 0.  Every rank brings up a communicator on libfakerccl.so, runs the library's
 self-test (all-gather #1, all-to-all #1 of the transport), builds its shard of the bench prover and proves.  The
-stand-in makes rank DIE_RANK _exit(17) when it enters the collective DIE_AT names (`alltoall:2` = the quotient
-all-to-all of the first proof), i.e. in the middle of a proof whose other ranks are already inside — or about to enter —
+stand-in makes rank DIE_RANK _exit(17) when it enters the collective DIE_AT names, counted from the start of the first
+proof (`alltoall:1` = its quotient all-to-all, `allgather:2` = the all-gather of the z commitment), i.e. in the middle of a proof whose other ranks are already inside — or about to enter —
 the same collective.  The survivors must come back from plonk_prover_prove_dev with PLONK_ERR_STATE after about
 PLONK_COMM_TIMEOUT_MS (comm.hip comm_sync: poll, ncclCommAbort, bounded drain) instead of hanging.
 
@@ -45,7 +45,13 @@ def rank_main(rank: int, world: int, log_n: int, uid_path: str) -> int:
     ctx = plonk_amd.Context(0)
     ctx.comm_init(uid, rank, world)
     ctx.comm_selftest()
+    # the fault is armed only AFTER the prover exists: FAKE_RCCL_DIE_AT then counts the collectives of the proof (all-gather 1 =
+    # the wire commitments, 2 = z; all-to-all 1 = the quotient), however many the set-up took
+    die_at = os.environ.pop("PEER_DEATH_AT")
     prover, wbuf, _ = bench.build_prover(ctx, log_n, rank, world, None, "dense")
+    import ctypes
+    ctypes.CDLL(FAKE).fake_rccl_arm()
+    os.environ["FAKE_RCCL_DIE_AT"] = die_at
     blinders = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % plonk_amd.Q for i in range(14)])
     t0 = time.perf_counter()
     out = {"rank": rank, "rc": 0, "error": ""}
@@ -94,7 +100,7 @@ def main() -> int:
         procs = []
         for r in range(world):
             env = dict(os.environ, PEER_DEATH_RANK=str(r), PEER_DEATH_UID=uid_path, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                       FAKE_RCCL_DIE_RANK=str(die_rank), FAKE_RCCL_DIE_AT=die_at, PLONK_COMM_TIMEOUT_MS=str(TIMEOUT_MS),
+                       FAKE_RCCL_DIE_RANK=str(die_rank), PEER_DEATH_AT=die_at, PLONK_COMM_TIMEOUT_MS=str(TIMEOUT_MS),
                        FAKE_RCCL_KERNEL_TIMEOUT_S="25" if no_abort else "60", FAKE_RCCL_ABORT_FAILS="1" if no_abort else "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:3]], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))

@@ -44,8 +44,10 @@ def case_for(log_n):
     return _cases[log_n]
 
 
-def gpu_proof(ctx, case, srs, blinders_mont, vk=None, expect=None):
-    """expect: fields of plonk_prover_describe the prover must report (the switch under test was honoured)"""
+def gpu_proof(ctx, case, srs, blinders_mont, vk=None, expect=None, host_too=False):
+    """expect: fields of plonk_prover_describe the prover must report (the switch under test was honoured);
+    host_too: also prove from HOST wire columns (plonk_prover_prove) and require the same bytes — above 2^18 gates that path
+    commits column by column as the copies land (round 6: msm_batch_device phases, prover.hip by_column)"""
     import plonk_amd
     ctx.srs_load_bytes(srs, len(srs) // 96)
     gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"], vk)
@@ -60,6 +62,8 @@ def gpu_proof(ctx, case, srs, blinders_mont, vk=None, expect=None):
             wbuf.upload(case["wires"][k], 32 * case["size"] * k)
         proof = gp.prove_dev(wbuf.ptr, case["pi"], blinders_mont)
         wbuf.free()
+        if host_too:
+            assert gp.prove_host_bytes(case["wires"], case["pi"], blinders_mont) == proof
         return proof, got_vk
     finally:
         gp.close()
@@ -138,7 +142,7 @@ def test_side_workloads_equal_c_oracle_2p20(ctx, monkeypatch, profile):
     case = dict(constraints=n, size=n, label=b"bench", polys=polys, wires=wires, pi=pi, pi_idx=idx,
                 pi_val=C.fr_bytes([pi[i] for i in idx]))
     bl = C.blinders(2021)
-    got, vk = gpu_proof(ctx, case, srs, bl)
+    got, vk = gpu_proof(ctx, case, srs, bl, host_too=True)   # bench-like: heavy buckets in every column's own launch
     cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk, threads=threads)
     # the oracle takes its eleven commitments from the key's trapdoor — [g p(tau)] G is the group element the MSM over
     # [g tau^i] G returns (tests/test_oracle_c_prove.py::test_trapdoor_commitments_are_the_msm_commitments), as the 2^22 test
@@ -173,7 +177,7 @@ def test_proof_bytes_equal_c_oracle_2p20(ctx, monkeypatch, domain):
     wires, polys, srs = _cases[key]
     case = dict(constraints=n, size=n, label=b"bench", polys=polys, wires=wires, pi={}, pi_idx=[], pi_val=b"")
     bl = C.blinders(2020)
-    got, vk = gpu_proof(ctx, case, srs, bl)
+    got, vk = gpu_proof(ctx, case, srs, bl, host_too=True)
     cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk)   # VK commitments are compared at 2^12..2^16; here they seed both transcripts
     expected = cp.prove(wires, [], b"", bl)
     cp.close()
@@ -198,7 +202,7 @@ def test_proof_bytes_equal_c_oracle_at_the_layout_crossover(ctx, monkeypatch, lo
     srs = C.synthetic_srs(n + 7)
     case = dict(constraints=n, size=n, label=b"bench", polys=polys, wires=wires, pi={}, pi_idx=[], pi_val=b"")
     bl = C.blinders(1800 + log_n)
-    got, vk = gpu_proof(ctx, case, srs, bl)
+    got, vk = gpu_proof(ctx, case, srs, bl, host_too=True)
     cp = cbind.CProver(n, b"bench", polys, srs, vk48=vk)
     expected = cp.prove(wires, [], b"", bl)
     cp.close()
