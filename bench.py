@@ -625,6 +625,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-2p22", action="store_true", help="skip the 2^22-gate extra of the default line (about half a minute of setup)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads / leaf costs of the N=1 line")
+    ap.add_argument("--host-wires-only", action="store_true", help="of the extras, only the proof from pinned host wire columns (A/B scripts)")
     ap.add_argument("--from-circuit", action="store_true",
                     help="build the prover with plonk_compile from gate columns (Compiler::preprocess on the device) instead of "
                          "from coefficient forms, and check plonk_prover_prove_witnesses against the column entry point")
@@ -868,7 +869,7 @@ def main():
                 out["prove_ms_host_wires_pinned"] = host_wire_legs(ctx, prover, wbuf, n, blinders, proof, max(2, min(args.steps, 5)))
             except Exception as e:   # noqa: BLE001
                 out["host_wires_error"] = repr(e)
-        if world == 1 and not args.no_extras and args.profile == "dense":
+        if world == 1 and not args.no_extras and not args.host_wires_only and args.profile == "dense":
             try:   # seam-level cost, measured while the prover is still alive: once a process has FREED tens of GB of device
                    # buffers the runtime stops overlapping the two copy directions of plonk_ntt_batch (33 -> 53 ms; bisected in
                    # profiles/r03b/ntt_batch_overlap_bisect.txt — variant C = prover.close() before the call)
@@ -881,7 +882,7 @@ def main():
                 out["leaf_error"] = repr(e)
         prover.close()
         wbuf.free()
-        if world == 1 and not args.no_extras and args.profile == "dense":
+        if world == 1 and not args.no_extras and not args.host_wires_only and args.profile == "dense":
             try:   # the other workloads of SURVEY §8(d); never a reason to lose the line
                 k = max(2, min(args.steps, 5))
                 out["prove_ms_bench_like"] = time_profile(ctx, log_n, "bench-like", k, blinders)
@@ -903,7 +904,7 @@ def main():
                     out["compile"]["proof_matches_timed_run"] = bool(out["compile"]["proof_blake2b"] == out["proof_blake2b"])
             except Exception as e:   # noqa: BLE001
                 out["extras_error"] = repr(e)
-        if world == 1 and not args.no_extras and args.profile == "dense" and log_n == 20 and not args.no_2p22:
+        if world == 1 and not args.no_extras and not args.host_wires_only and args.profile == "dense" and log_n == 20 and not args.no_2p22:
             try:   # BASELINE config 5's size on one GPU (commit key streamed from pinned host memory): after everything else, own guard
                 t22 = time.perf_counter()
                 dg = {}

@@ -205,6 +205,7 @@ struct Ctx {
   Fr* ntt_buf2 = nullptr;          // second and third transform buffer of plonk_ntt_batch's upload / compute / download pipeline
   Fr* ntt_buf3 = nullptr;
   hipStream_t copy_stream = nullptr;
+  hipStream_t col_stream[2] = {nullptr, nullptr};   // host wire columns: column k's bucket sort + accumulation on stream k & 1 (prover.hip by_column)
   hipStream_t down_stream = nullptr;   // device -> host leg of that pipeline
   Fr* ntt_tmp = nullptr;
   uint64_t ntt_cap = 0;
