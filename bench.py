@@ -163,7 +163,17 @@ def host_wire_legs(ctx, prover, wbuf, n, blinders, proof, steps):
         for _ in range(steps):
             prover.prove_host_ptrs(ptrs, prover.public_inputs, blinders)
         ctx.sync()
-        return round((time.perf_counter() - t1) * 1e3 / steps, 3)
+        ms = round((time.perf_counter() - t1) * 1e3 / steps, 3)
+        # the floor of this path: no kernel of prove() can start before the FIRST column has crossed PCIe (every later column
+        # travels under the commitment work of the ones before it, prover.hip by_column) — measured here, same buffers
+        ctx.h2d_from(wbuf.ptr, hw[0].ptr, 32 * n)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ctx.h2d_from(wbuf.ptr, hw[0].ptr, 32 * n)   # (column a onto itself: the same bytes)
+            ctx.sync()
+        host_wire_legs.first_column_h2d_ms = round((time.perf_counter() - t1) * 1e3 / 5, 3)
+        return ms
     finally:
         for b in hw:
             b.free()
@@ -187,6 +197,8 @@ def time_profile(ctx, log_n, profile, steps, blinders, digest=None, host_legs=No
         if host_legs is not None:
             try:
                 host_legs["prove_ms_host_wires_pinned"] = host_wire_legs(ctx, prover, wbuf, 1 << log_n, blinders, proof, steps)
+                host_legs["first_column_h2d_ms"] = host_wire_legs.first_column_h2d_ms
+                host_legs["pcie_floor_ms"] = round(ms + host_wire_legs.first_column_h2d_ms, 3)   # resident proof + the one copy nothing can hide
                 host_legs["wire_bytes_mib"] = 4 * 32 << (log_n - 20)
                 host_legs["prove_ms_resident"] = round(ms, 3)
                 if from_circuit and build_prover.witness_values is not None:
@@ -867,6 +879,12 @@ def main():
         if world == 1 and not args.no_extras:
             try:   # the boundary handing over HOST wire columns (pinned): PCIe-inclusive prove(), never `value`
                 out["prove_ms_host_wires_pinned"] = host_wire_legs(ctx, prover, wbuf, n, blinders, proof, max(2, min(args.steps, 5)))
+                # what separates it from `value`: the first column's copy (measured, nothing can run under it) + three extra
+                # launch sets (columns a, b, then c + d: DESIGN.md 4.4)
+                out["host_wires"] = {"first_column_h2d_ms": host_wire_legs.first_column_h2d_ms,
+                                     "pcie_floor_ms": round(ms_per_step + host_wire_legs.first_column_h2d_ms, 3),
+                                     "gap_to_value_ms": round(out["prove_ms_host_wires_pinned"] - ms_per_step, 3),
+                                     "wire_bytes_mib": 4 * 32 * n >> 20}
             except Exception as e:   # noqa: BLE001
                 out["host_wires_error"] = repr(e)
         if world == 1 and not args.no_extras and not args.host_wires_only and args.profile == "dense":

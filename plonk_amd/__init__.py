@@ -474,6 +474,10 @@ class Context:
     def d2h_into(self, host_ptr: int, dev_ptr: int, nbytes: int) -> None:
         self._check(self.lib.plonk_dev_d2h(self.handle, ctypes.c_void_p(host_ptr), dev_ptr, nbytes))
 
+    def h2d_from(self, dev_ptr: int, host_ptr: int, nbytes: int) -> None:
+        """plonk_dev_h2d from a raw host address (e.g. PinnedBuffer.ptr); queued on the context's stream"""
+        self._check(self.lib.plonk_dev_h2d(self.handle, dev_ptr, ctypes.c_void_p(host_ptr), nbytes))
+
     def msm_bytes(self, scalars_mont: bytes, m: int) -> bytes:
         out = ctypes.create_string_buffer(97)
         self._check(self.lib.plonk_msm(self.handle, scalars_mont, m, out))

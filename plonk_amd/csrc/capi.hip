@@ -201,6 +201,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   g.bi_cfg = env_int("PLONK_BI_CFG", -1);
   if (const char v = env_chr("PLONK_SIDE_DEFER")) g.side_defer = v == '1' ? 1 : (v == '2' ? 2 : 0);
   if (const char v = env_chr("PLONK_SIDE_AFTER_ELOG"); v == '2' || v == '3') g.side_after_elog = v - '0';
+  if (env_chr("PLONK_MSM_TIDY") == '0') g.sort_tidy = -1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '0') g.wire_by_column = -1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '2') g.wire_by_column = 2;
   // ---- resolution
@@ -413,7 +414,6 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   (void)hipFree(c.ntt_buf); (void)hipFree(c.ntt_buf2); (void)hipFree(c.ntt_buf3); (void)hipFree(c.ntt_tmp);
   if (c.down_stream) (void)hipStreamDestroy(c.down_stream);
   if (c.copy_stream) (void)hipStreamDestroy(c.copy_stream); (void)hipFree(c.srs_table); (void)hipFree(c.table_scratch);
-  for (hipStream_t cs : c.col_stream) if (cs) (void)hipStreamDestroy(cs);
   MsmWork& w = c.msm;
   (void)hipFree(w.tmp_words); (void)hipFree(w.entries); (void)hipFree(w.coarse_cnt); (void)hipFree(w.coarse_off); (void)hipFree(w.coarse_cur); (void)hipFree(w.big_off); (void)hipFree(w.big_cnt); (void)hipFree(w.nheavy); (void)hipFree(w.heavy_list); (void)hipFree(w.seg_sum);
   (void)hipFree(w.offsets); (void)hipFree(w.slice_off); (void)hipFree(w.full_off); (void)hipFree(w.part_list); (void)hipFree(w.partial); (void)hipFree(w.buckets);

@@ -61,8 +61,6 @@ struct Prover {
   hipEvent_t ev_ready = nullptr, ev_side = nullptr;
   hipEvent_t ev_acc = nullptr;   // end of a commitment group's msm_accumulate (deferred side work starts there)
   hipEvent_t ev_wire[4] = {nullptr, nullptr, nullptr, nullptr};   // host-wire uploads in flight on the copy stream (plonk_prover_prove)
-  hipEvent_t ev_col[4] = {nullptr, nullptr, nullptr, nullptr};    // ... and the end of column k's own bucket sort / accumulation / bucket sums (by_column)
-  hipEvent_t ev_ws = nullptr;                                      // the eight wire blinders are on the device
   bool wires_pending = false;
   Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
   Fr* agg = nullptr;               // [np] linear combination
@@ -335,8 +333,6 @@ static void prover_free(Prover* p) {
   if (p->ev_acc) (void)hipEventDestroy(p->ev_acc);
   if (p->ev_pi) (void)hipEventDestroy(p->ev_pi);
   for (int k = 0; k < 4; ++k) if (p->ev_wire[k]) (void)hipEventDestroy(p->ev_wire[k]);
-  for (int k = 0; k < 4; ++k) if (p->ev_col[k]) (void)hipEventDestroy(p->ev_col[k]);
-  if (p->ev_ws) (void)hipEventDestroy(p->ev_ws);
   if (p->low_host) (void)hipHostFree(p->low_host);
   if (p->res_host) (void)hipHostFree(p->res_host);
   if (p->gather_host) free(p->gather_host);
@@ -518,8 +514,6 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
   HIP_TRY(hipEventCreateWithFlags(&p->ev_acc, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_pi, hipEventDisableTiming));
   for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&p->ev_wire[k], hipEventDisableTiming));
-  for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&p->ev_col[k], hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&p->ev_ws, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&p->low_host, 42 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * RES_STRIDE, hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->ev_host, 16 * sizeof(Fr), hipHostMallocDefault));
@@ -895,43 +889,25 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     const Fr* sc[4] = {wires_dev, wires_dev + n, wires_dev + 2 * n, wires_dev + 3 * n};
     const Fr* tl[4] = {p->wscal, p->wscal + 2, p->wscal + 4, p->wscal + 6};
     const uint64_t sp[4] = {n, n, n, n};
-    // column k's commitment work runs on stream k & 1, gated only by ITS copy (the MSM reads the wire values, not the
-    // polynomial): the bandwidth-bound sort of column k + 1 then overlaps the VALU-bound accumulation of column k and no
-    // launch waits for the previous one's last waves.  The inverse transforms stay on the main stream in column order.
-    // PLONK_WIRE_BY_COLUMN=2: everything on the main stream (A/B)
-    const bool two_streams = c->cfg.wire_by_column != 2;
-    if (two_streams) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      for (hipStream_t& cs : c->col_stream) if (!cs) HIP_TRY(hipStreamCreateWithPriority(&cs, hipStreamNonBlocking, hi));
-      HIP_TRY(hipEventRecord(p->ev_ws, c->stream));
-    }
-    for (int k = 0; k < 4; ++k) {
-      if (two_streams) {
-        hipStream_t cs = c->col_stream[k & 1];
-        HIP_TRY(hipStreamWaitEvent(cs, p->ev_wire[k], 0));
-        if (k < 2) HIP_TRY(hipStreamWaitEvent(cs, p->ev_ws, 0));
-        struct Swap { Ctx* c; hipStream_t keep; ~Swap() { c->stream = keep; } } swap{c, c->stream};
-        c->stream = cs;
-        PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 1, k, 1));
-        HIP_TRY(hipEventRecord(p->ev_col[k], cs));
-      }
-      PTRY(wire_polynomials(p->tmp8, k, k + 1));   // waits for column k's copy, then its inverse transform + blinding
-      if (k == 3 && !side_defer) {                 // all four polynomials exist: their coset transforms go to the side stream
+    // Columns a and b each get a launch of their own as they land; c and d — both have arrived by the time b's accumulation
+    // ends (0.65 ms per column over PCIe against ~1.5 ms of commitment work per column at 2^20 gates) — share one: a sort
+    // launch set and an accumulation ramp-down less.  Measured and NOT adopted (profiles/r06/host_wires_ab.jsonl): column k's
+    // work on a stream of its own (k & 1), gated only by its copy — no gain at 2^20 (gap 1.09-1.27 against 1.12 ms) and a
+    // loss at 2^19 (0.38-0.54 against 0.24): the accumulations are VALU-bound, so overlapping them only interleaves them.
+    // PLONK_WIRE_BY_COLUMN=2: one launch per column (A/B)
+    const int parts[3][2] = {{0, 1}, {1, 1}, {2, 2}};
+    const int nparts = c->cfg.wire_by_column == 2 ? 4 : 3;
+    for (int q = 0; q < nparts; ++q) {
+      const int k0 = nparts == 4 ? q : parts[q][0], kc = nparts == 4 ? 1 : parts[q][1];
+      PTRY(wire_polynomials(p->tmp8, k0, k0 + kc));   // waits for the columns' copies, then their inverse transforms + blinding
+      if (k0 + kc == 4 && !side_defer) {              // all four polynomials exist: their coset transforms go to the side stream
         SideScope side(c, p->ev_ready);
         PTRY(side_round1());
       }
-      if (!two_streams) {
-        AccMark mark(c, (side_defer && k == 3) ? p->ev_acc : nullptr);
-        PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 1, k, 1));
-      }
+      AccMark mark(c, (side_defer && k0 + kc == 4) ? p->ev_acc : nullptr);
+      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 1, k0, kc));
     }
-    if (two_streams) for (int k = 0; k < 4; ++k) HIP_TRY(hipStreamWaitEvent(c->stream, p->ev_col[k], 0));
-    {
-      AccMark mark(c, nullptr);
-      PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 2));
-    }
-    if (side_defer) HIP_TRY(hipEventRecord(p->ev_acc, c->stream));   // (by_column excludes the deferred schedule; never leave the event unrecorded)
+    PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 2));
   } else {
     AccMark mark(c, side_defer ? p->ev_acc : nullptr);
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
