@@ -28,8 +28,22 @@ def load() -> ctypes.CDLL:
         return _lib
     srcs = [os.path.join(_DIR, "oracle_prove.c"), os.path.join(_DIR, "oracle.c")]   # oracle_prove.c includes oracle.c
     so = os.path.join(_DIR, f"liboracle_{_cpu_tag()}.so")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", srcs[0], "-o", so])
+    def stale():
+        return not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)
+    if stale():
+        # several test processes may get here together (the variant children of tests/test_gpu_msm_variants.py run four at a
+        # time on a fresh GPU box, where this CPU's copy does not exist yet): one builds, under a file lock, into a temporary
+        # name that is renamed into place — nobody ever maps a half-written library
+        import fcntl
+        with open(so + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if stale():
+                    tmp = f"{so}.tmp{os.getpid()}"
+                    subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", srcs[0], "-o", tmp])
+                    os.replace(tmp, so)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     lib = ctypes.CDLL(so)
     lib.oracle_ntt.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_int]
     lib.oracle_msm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]

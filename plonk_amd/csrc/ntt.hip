@@ -516,6 +516,13 @@ int ntt_tables(Ctx* c, uint32_t L, bool inverse, NttTables** out) {
     }
   }
   tb->n_inv = n_inv;
+  // The tables were filled by kernels queued on the CURRENT stream — which is the low-priority side stream when a size is first
+  // needed inside a SideScope (the wire inverse transforms of a first proof at <= 2^18 gates) — and every later user finds them in
+  // the map, on whatever stream it runs: without a wait here the main stream's next transform of that size races the fill.
+  // Found in round 6 by running four provers on one GPU at once (tests/test_gpu_msm_variants.py children in parallel): with the
+  // side stream starved, the first proof of a fresh context read an unwritten twiddle table about once in eight runs and
+  // returned CircuitUnsatisfied.  One wait per (size, direction) per context, at creation.
+  HIP_TRY(hipStreamSynchronize(c->stream));
   c->ntt_tables[key] = tb;
   *out = tb;
   return PLONK_OK;
