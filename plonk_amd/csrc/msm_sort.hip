@@ -198,33 +198,17 @@ static constexpr uint32_t BIG_LIMIT = 1u << 16;
 static constexpr uint32_t BIG_CHUNK = 1u << 14;
 __device__ __forceinline__ uint32_t big_chunks(uint32_t cnt) { return cnt > BIG_LIMIT ? (cnt + BIG_CHUNK - 1) / BIG_CHUNK : 0u; }
 
-// Round 6: with `tidy` set (the 2^15-bucket variant, where a commitment's counters are small) the kernel also does what three
-// hipMemsetAsync launches used to do around it — ~5 us each in a chain of ~10 dependent launches per commitment group, which
-// is what a 2^12 … 2^17-gate proof and every rank of an 8-GPU job are made of: it clears the coarse counters it has just
-// consumed (they are zero again for the NEXT group's msm_hist; msm_sort_reserve_fixed zeroes them once), this commitment's
-// heavy / multi-slice counters (msm_slices / msm_layout_apply run later) and its oversized-bin counters | cursors.
-__global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(uint32_t* __restrict__ coarse_cnt_all,
+__global__ void __launch_bounds__(SORT_T) msm_coarse_scan_kernel(const uint32_t* __restrict__ coarse_cnt_all,
                                                                  uint32_t* __restrict__ coarse_off_all,
                                                                  uint32_t* __restrict__ coarse_cur_all,
-                                                                 uint32_t* __restrict__ big_off_all, int kb0,
-                                                                 uint32_t tidy, uint32_t* __restrict__ nheavy_all, uint32_t* __restrict__ big_cnt_all) {
+                                                                 uint32_t* __restrict__ big_off_all, int kb0) {
   __shared__ uint32_t sh[SORT_T];
-  uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * COARSE;
+  const uint32_t* __restrict__ cnt = coarse_cnt_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * COARSE;
   uint32_t* __restrict__ off = coarse_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (COARSE + 1);
   uint32_t* __restrict__ cur = coarse_cur_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * COARSE;
   uint32_t* __restrict__ big = big_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (COARSE + 1);
   const uint32_t t = threadIdx.x;
   const uint32_t c0 = cnt[2 * t], c1 = cnt[2 * t + 1];
-  if (tidy) {
-    const uint32_t kb = blockIdx.x + (uint32_t)kb0;
-    cnt[2 * t] = 0;
-    cnt[2 * t + 1] = 0;
-    if (t < 2) nheavy_all[2 * kb + t] = 0;
-    if (t == 2) nheavy_all[2 * MSM_MAX_BATCH + kb] = 0;
-    uint32_t* __restrict__ bc = big_cnt_all + (uint64_t)kb * MSM_NB;
-    uint32_t* __restrict__ bq = big_cnt_all + (uint64_t)MSM_NB * MSM_MAX_BATCH + (uint64_t)kb * MSM_NB;
-    for (uint32_t i = t; i < MSM_NB; i += SORT_T) { bc[i] = 0; bq[i] = 0; }
-  }
   uint32_t total;
   const uint32_t ex = block_exclusive_scan(c0 + c1, sh, &total);
   off[2 * t] = ex;
@@ -824,18 +808,12 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   // bt.kb0 > 0 (a group launched column by column, msm_batch_device's phases): this launch covers commitments
   // [kb0, kb0 + count) of the group's buffers — every kernel adds kb0 to its blockIdx-derived commitment index
   const int kb0 = bt.kb0;
-  // PLONK_MSM_TIDY=0 restores the three memsets (A/B); the many-bucket variant keeps them (its counters are megabytes)
-  const bool tidy = MSM_NB_BITS == 15 && c->cfg.sort_tidy >= 0;
-  if (!tidy) {
-    HIP_TRY(hipMemsetAsync(w.coarse_cnt + (size_t)COARSE * kb0, 0, sizeof(uint32_t) * COARSE * bt.count, st));
-    w.coarse_zeroed = false;   // this launch leaves its counts behind (the buffer is shared by both bucket-count variants)
-  } else if (!w.coarse_zeroed) {
-    HIP_TRY(hipMemsetAsync(w.coarse_cnt, 0, sizeof(uint32_t) * COARSE * MSM_MAX_BATCH, st));   // EVERY commitment's counters, once
-    w.coarse_zeroed = true;    // from here on every tidy scan leaves what it read at zero
-  }
+  // (Round 6, measured and NOT adopted: clearing the three counter arrays inside msm_coarse_scan_kernel instead of by three
+  // hipMemsetAsync launches — 2^12: 2.577 -> 2.556 ms, 2^16: 4.778 -> 4.759, a rank of 8 at 2^20: 6.77 -> 6.75, i.e. < 1 %
+  // for a zero-between-groups invariant shared by both bucket-count variants; profiles/r06/tidy_ab.jsonl.)
+  HIP_TRY(hipMemsetAsync(w.coarse_cnt + (size_t)COARSE * kb0, 0, sizeof(uint32_t) * COARSE * bt.count, st));
   hipLaunchKernelGGL(msm_hist_kernel<MODE>, dim3(htiles, bt.count), dim3(SORT_T), 0, st, bt, w.coarse_cnt);
-  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off, kb0,
-                     tidy ? 1u : 0u, w.nheavy, w.big_cnt);
+  hipLaunchKernelGGL(msm_coarse_scan_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.coarse_cnt, w.coarse_off, w.coarse_cur, w.big_off, kb0);
 #if PLONK_MSM_NB_BITS >= 19
   if constexpr (MODE != 0) {
     if (c->cfg.sort13 == 1) {   // round 5 A/B: two half-size partition workgroups per CU (13 digit slots of 1024 scalars)
@@ -859,9 +837,7 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
     const uint64_t words = (uint64_t)MSM_W * mmax;
     const uint32_t most = (uint32_t)(words / BIG_CHUNK + words / BIG_LIMIT + 1);
     const uint32_t big_wgs = most < 512u ? most : 512u;   // the kernels stride over the chunk list
-    if (tidy) {
-      // cleared by msm_coarse_scan_kernel
-    } else if (kb0 == 0 && bt.count == bt.group_count) {
+    if (kb0 == 0 && bt.count == bt.group_count) {
       HIP_TRY(hipMemsetAsync(w.big_cnt, 0, sizeof(uint32_t) * 2 * MSM_NB * MSM_MAX_BATCH, st));   // big_cnt | big_cur
     } else {   // a column launch clears only its own counters (the other columns' may be in use on another stream one day)
       HIP_TRY(hipMemsetAsync(w.big_cnt + (size_t)MSM_NB * kb0, 0, sizeof(uint32_t) * MSM_NB * bt.count, st));
@@ -871,9 +847,7 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
     hipLaunchKernelGGL(msm_big_scatter_kernel<WordT>, dim3(big_wgs, bt.count), dim3(BIG_T), 0, st, bt, w.coarse_off, w.big_off, tmp,
                        w.big_cnt, w.big_cnt + (size_t)MSM_NB * MSM_MAX_BATCH, w.entries, w.offsets);
   }
-  if (tidy) {
-    // cleared by msm_coarse_scan_kernel
-  } else if (kb0 == 0 && bt.count == bt.group_count) {
+  if (kb0 == 0 && bt.count == bt.group_count) {
     HIP_TRY(hipMemsetAsync(w.nheavy, 0, sizeof(uint32_t) * 4 * MSM_MAX_BATCH, st));
   } else {   // nheavy[2 kb], nheavy[2 kb + 1] (heavy buckets / segments) and nheavy[2 KB + kb] (multi-slice buckets) of these columns
     HIP_TRY(hipMemsetAsync(w.nheavy + 2 * kb0, 0, sizeof(uint32_t) * 2 * bt.count, st));

@@ -114,7 +114,6 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
 struct HeavyItem { uint32_t bucket, seg_base, nseg, pad; };   // a bucket with far more slices than expected, cut into 256-slice segments
 
 struct MsmWork {   // per-context scratch, grown on demand
-  bool coarse_zeroed = false;      // coarse_cnt is all zero between groups (msm_sort.hip: the tidy msm_coarse_scan clears what it consumed)
   bool fixed_ok = false;           // every size-independent buffer below is allocated (msm_reserve: all or nothing)
   uint64_t cap_m = 0;
   uint32_t* tmp_words = nullptr;   // W * m words grouped by coarse bin (msm_sort.hip); room for 64-bit words
@@ -176,7 +175,6 @@ struct Config {
   bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
-  int sort_tidy = 0;                // PLONK_MSM_TIDY=0 -> -1: the sort's counters cleared by hipMemsetAsync launches (rounds 2-5), A/B
   int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN=0 -> -1: host wire columns commit as ONE grouped launch after the last copy (round 5), A/B
   int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
 };

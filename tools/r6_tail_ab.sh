@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: PLONK_MSM_TIDY was an experimental switch of round 6, removed after this measurement (< 1 %: profiles/r06/tidy_ab.jsonl); the script is kept as the record of how the A/B was run.
 # VERDICT r5 item 2 (bounded attempt at the per-group constant of small proofs and ranks), same-box A/B:
 #   PLONK_MSM_TIDY=0  the bucket sort's counters cleared by three hipMemsetAsync launches per group (rounds 2-5)
 #   default           cleared inside msm_coarse_scan_kernel (three launches fewer in a chain of ~10 per commitment group)
