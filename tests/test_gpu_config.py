@@ -33,6 +33,22 @@ def test_defaults_and_round_trip():
     ctx.close()
 
 
+def test_a_refused_reconfiguration_changes_nothing():
+    """plonk_ctx_set_config used to overwrite the context's configuration BEFORE it rejected a change of
+    side_stream_cus (the streams are created once), so the rejected call still replaced every other field.  It now resolves
+    into a temporary and commits only what it accepts."""
+    import plonk_amd
+    ctx = plonk_amd.Context(0, plonk_amd.GpuConfig())
+    before = ctx.get_config().as_dict()
+    g = ctx.get_config()
+    g.side_stream_cus, g.quotient_domain, g.table_mode, g.comm_timeout_ms = 32, 8, plonk_amd.TABLE_WINDOW, 777
+    with pytest.raises(plonk_amd.PlonkError) as ei:
+        ctx.set_config(g)
+    assert ei.value.code == -7
+    assert ctx.get_config().as_dict() == before
+    ctx.close()
+
+
 def test_invalid_configurations_are_refused():
     import plonk_amd
     for kw in ({"table_mode": 17}, {"msm_bucket_bits": 16}, {"quotient_domain": 2}, {"ntt_elements_log2": 4}, {"shard_quotient": 2},
