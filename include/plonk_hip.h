@@ -263,7 +263,8 @@ typedef struct plonk_prover_info {
   uint32_t shard_world, shard_rank;
   uint32_t sharded_quotient;     /* 1: quotient by residue class, rounds 4-5 by coefficient range; 0: only the MSMs are sharded */
   uint32_t quotient_classes;     /* Q: 4, or 8 for eight ranks (0 when the quotient is not sharded) */
-  uint32_t reserved;
+  uint32_t wire_group_launches;  /* of the LAST proof's wire commitments: 1 = one grouped launch (resident columns); 3 = columns a, b, then c + d
+                                    as they arrive from the host (plonk_prover_prove from 2^19 gates on); 4 = one launch per column; 0 before the first proof */
   uint64_t lagrange_points;      /* points of the Lagrange-basis key (or of this rank's slice) */
 } plonk_prover_info;
 int plonk_prover_describe(plonk_prover* p, plonk_prover_info* out);

@@ -98,7 +98,7 @@ class _MsmPlan(ctypes.Structure):
 class _ProverInfo(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint64), ("quotient_domain", ctypes.c_uint32), ("wire_commit_values", ctypes.c_uint32),
                 ("lagrange_table_rows", ctypes.c_uint32), ("shard_world", ctypes.c_uint32), ("shard_rank", ctypes.c_uint32),
-                ("sharded_quotient", ctypes.c_uint32), ("quotient_classes", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("sharded_quotient", ctypes.c_uint32), ("quotient_classes", ctypes.c_uint32), ("wire_group_launches", ctypes.c_uint32),
                 ("lagrange_points", ctypes.c_uint64)]
 
 

@@ -202,6 +202,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   if (const char v = env_chr("PLONK_SIDE_DEFER")) g.side_defer = v == '1' ? 1 : (v == '2' ? 2 : 0);
   if (const char v = env_chr("PLONK_SIDE_AFTER_ELOG"); v == '2' || v == '3') g.side_after_elog = v - '0';
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '0') g.wire_by_column = -1;
+  if (env_chr("PLONK_WIRE_BY_COLUMN") == '1') g.wire_by_column = 1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '2') g.wire_by_column = 2;
   // ---- resolution
   if (g.table_mode != (int)MSM_ROWS_WINDOW && g.table_mode != (int)MSM_ROWS_HALFPOS && g.table_mode != (int)MSM_ROWS_BITPOS) g.table_mode = 0;

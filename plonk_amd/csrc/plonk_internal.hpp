@@ -175,7 +175,7 @@ struct Config {
   bool ntt_direct = true;           // PLONK_NTT_DIRECT=0 switches the whole inter-pass twiddle tables off
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
-  int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN=0 -> -1: host wire columns commit as ONE grouped launch after the last copy (round 5), A/B
+  int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN: 0 -> -1 (host wire columns commit as ONE grouped launch after the last copy, round 5), 1 / 2 -> by column at every size (a, b, c + d / one launch each); unset: by column from 2^19 gates on
   int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
 };
 

@@ -62,6 +62,7 @@ struct Prover {
   hipEvent_t ev_acc = nullptr;   // end of a commitment group's msm_accumulate (deferred side work starts there)
   hipEvent_t ev_wire[4] = {nullptr, nullptr, nullptr, nullptr};   // host-wire uploads in flight on the copy stream (plonk_prover_prove)
   bool wires_pending = false;
+  uint32_t last_wire_launches = 0;   // of the last proof's wire group: 1 grouped, 3 = a, b, c + d, 4 = one per column (plonk_prover_describe)
   Fr* tparts = nullptr;            // [3][np] t_low, t_mid, t_high
   Fr* agg = nullptr;               // [np] linear combination
   Fr* wit = nullptr;               // [np] opening witness polynomial W_z
@@ -834,7 +835,11 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // Up to 2^18 gates the GPU is not saturated by the commitment pipeline and the wire polynomials (needed from round 3
   // on) ride on the side stream under it; above, the accumulation owns the VALU and the side stream would only fall
   // behind (A/B at 2^20, r02: +0.7 ms), so they keep their place in front of the commitment.
-  const bool polys_on_side = lag && L <= 18;
+  // plonk_gpu_config has no field for it; PLONK_WIRE_BY_COLUMN: 0 = never, 1 / 2 = at EVERY size (a, b, c + d / one launch per
+  // column: what the variant tests use to run the phased launches on small circuits), unset = from 2^19 gates on
+  const int bc_cfg = c->cfg.wire_by_column;
+  const bool by_column = lag && p->wires_pending && p->world == 1 && bc_cfg >= 0 && (L > 18 || bc_cfg > 0);
+  const bool polys_on_side = lag && L <= 18 && !by_column;
   // Host wire columns (plonk_prover_prove, round 6): column k lands over PCIe 32 n bytes after column k - 1 (0.65 ms apart at
   // 2^20 gates), and until round 5 the commitment group waited for all four before its grouped bucket sort — 2.1 ms of every
   // such proof with nothing but the four inverse transforms to hide in.  Now each column's transform is followed at once by
@@ -842,7 +847,6 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // commitment), under the next columns' copies; the latency-bound reduction tail still runs once for the group (phase 2).
   // Same additions, same bucket sums, same bytes.  Resident columns (plonk_prover_prove_dev, what `value` times) keep the
   // grouped launch: four launches have four ramp-downs.
-  const bool by_column = lag && p->wires_pending && !polys_on_side && c->cfg.wire_by_column >= 0;
   if (!polys_on_side && !by_column) PTRY(wire_polynomials(p->tmp8));
   if (lag && by_column) {
     HIP_TRY(hipMemcpyAsync(p->wscal, bl, 8 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
@@ -897,6 +901,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     // PLONK_WIRE_BY_COLUMN=2: one launch per column (A/B)
     const int parts[3][2] = {{0, 1}, {1, 1}, {2, 2}};
     const int nparts = c->cfg.wire_by_column == 2 ? 4 : 3;
+    p->last_wire_launches = (uint32_t)nparts;
     for (int q = 0; q < nparts; ++q) {
       const int k0 = nparts == 4 ? q : parts[q][0], kc = nparts == 4 ? 1 : parts[q][1];
       PTRY(wire_polynomials(p->tmp8, k0, k0 + kc));   // waits for the columns' copies, then their inverse transforms + blinding
@@ -909,6 +914,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     }
     PTRY(msm_group(p, sc, ms, 4, 0, p->lag_table, p->lag_n, tl, sp, 2));
   } else {
+    p->last_wire_launches = 1;
     AccMark mark(c, side_defer ? p->ev_acc : nullptr);
     const uint64_t ms[4] = {n + 2, n + 2, n + 2, n + 2};
     if (lag) {
@@ -1765,6 +1771,7 @@ int plonk_prover_describe(plonk_prover* pr, plonk_prover_info* out) {
   out->shard_rank = (uint32_t)p->rank;
   out->sharded_quotient = p->sharded ? 1u : 0u;
   out->quotient_classes = p->sharded ? p->Q : 0u;
+  out->wire_group_launches = p->last_wire_launches;
   return PLONK_OK;
   });
 }

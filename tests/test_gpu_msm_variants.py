@@ -45,6 +45,12 @@ PROVER_VARIANTS = [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"P
                    {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},
                    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"}]
 PROVER_SELECT = "deterministic_v3 or random_arithmetic or (proof_bytes_equal_c_oracle and not 16 and not 2p20)"
+# round 6: the phased launches of msm_batch_device (host wire columns committed as they arrive) forced at small sizes, over both
+# bucket-count variants; the child's test_host_wire_schedule_is_the_one_asked_for compares plonk_prover_describe
+SCHEDULE_VARIANTS = [({"PLONK_WIRE_BY_COLUMN": "1"}, 3), ({"PLONK_WIRE_BY_COLUMN": "2"}, 4),
+                     ({"PLONK_WIRE_BY_COLUMN": "1", "PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, 3),
+                     ({"PLONK_WIRE_BY_COLUMN": "0"}, 1)]
+SCHEDULE_SELECT = "host_wire_schedule or deterministic_v3 or random_arithmetic"   # the latter prove from host columns too (gp.prove)
 
 
 def _key(env):
@@ -64,6 +70,9 @@ def children():
     for variant in PROVER_VARIANTS:      # the long ones first
         futs["prover:" + _key(variant)] = pool.submit(run_variant, variant, PROVER_SELECT, "gpu and not slow",
                                                       "tests/test_gpu_prover.py tests/test_gpu_prove_sizes.py")   # one child, both files
+    for variant, launches in SCHEDULE_VARIANTS:
+        futs["schedule:" + _key(variant)] = pool.submit(run_variant, dict(variant, PLONK_TEST_EXPECT_WIRE_LAUNCHES=str(launches)), SCHEDULE_SELECT,
+                                                        "gpu and not slow", "tests/test_gpu_prover.py")
     for variant, plan in VARIANTS:
         futs["edge:" + _key(variant)] = pool.submit(run_variant, dict(variant, PLONK_TEST_EXPECT_PLAN=json.dumps(plan)))
     yield futs
@@ -86,6 +95,17 @@ def test_prover_parity_holds_with_every_table_and_bucket_layout(children, varian
     r = children["prover:" + _key(variant)].result()
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,launches", SCHEDULE_VARIANTS, ids=[",".join(f"{k}={x}" for k, x in v.items()) for v, _ in SCHEDULE_VARIANTS])
+def test_host_wire_columns_commit_by_phase_with_the_same_bytes(children, variant, launches):
+    """msm_batch_device's phases (bucket sort + accumulation + bucket sums per column or column pair, one reduction tail per
+    group) against the grouped launch and the C oracle: 2^12-gate widget circuit (heavy buckets in every column), the KAT and
+    random arithmetic circuits, proved from HOST wire columns under each forced schedule"""
+    r = children["schedule:" + _key(variant)].result()
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout and "skipped" not in r.stdout.splitlines()[-1]
 
 
 def test_child_process_harness_selects_and_runs_tests():

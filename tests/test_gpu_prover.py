@@ -231,3 +231,38 @@ def test_prover_refuses_to_prove_after_its_srs_was_replaced(ctx):
     gp2 = gpu_prover(ctx, oprover)          # rebuilt on the original key: same proof again
     assert gp2.prove(cols, {}, list(range(1, 15))) == first
     gp2.close()
+
+
+def test_host_wire_schedule_is_the_one_asked_for(ctx, kat_setup):
+    """Run by the variant children of tests/test_gpu_msm_variants.py (PLONK_TEST_EXPECT_WIRE_LAUNCHES): with PLONK_WIRE_BY_COLUMN=1 / 2
+    a proof from HOST wire columns commits to them in 3 (a, b, c + d) / 4 launches of msm_batch_device's phase 1 at EVERY size
+    (the default takes that schedule from 2^19 gates on), and plonk_prover_describe reports what the last proof did — a switch
+    the library ignores fails here instead of re-testing the grouped launch.  Same bytes as the resident-column proof."""
+    import os
+    want = os.environ.get("PLONK_TEST_EXPECT_WIRE_LAUNCHES")
+    if want is None:
+        pytest.skip("only meaningful under a forced schedule")
+    import plonk_amd
+    from oracle import cbind
+    from tests import circuits as C
+    comp = C.big_widget_circuit(1 << 12, seed=77)()
+    case = C.compile_fast(comp, b"wire-schedule")
+    srs = C.synthetic_srs(case["size"] + 7)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"])
+    bl = C.blinders(random.Random(5).randrange(1 << 30))
+    assert gp.describe()["wire_group_launches"] == 0
+    n = case["size"]
+    wbuf = ctx.alloc(4 * 32 * n)
+    for k in range(4):
+        wbuf.upload(case["wires"][k], 32 * n * k)
+    resident = gp.prove_dev(wbuf.ptr, case["pi"], bl)
+    assert gp.describe()["wire_group_launches"] == 1
+    host = gp.prove_host_bytes(case["wires"], case["pi"], bl)
+    assert gp.describe()["wire_group_launches"] == int(want)
+    assert host == resident
+    cp = cbind.CProver(case["constraints"], case["label"], case["polys"], srs)
+    assert resident == cp.prove(case["wires"], case["pi_idx"], case["pi_val"], bl)
+    cp.close()
+    wbuf.free()
+    gp.close()
