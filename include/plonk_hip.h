@@ -239,8 +239,12 @@ typedef struct {
    *   NULL / 0 = commit to the wire polynomials in coefficient form.
    * A supplied key is validated: every point on the curve and in the prime-order subgroup (PLONK_ERR_POINT) and, on one
    * GPU, the whole key against the context's commit key by a random linear combination — one inverse transform and two
-   * MSMs (PLONK_ERR_DATA for the key of another setup, a permuted or otherwise wrong key).  A rank of a sharded prover
-   * holds only slices of both keys and checks the points alone. */
+   * MSMs (PLONK_ERR_DATA for the key of another setup, a permuted or otherwise wrong key).  Sharded provers (round 6): every
+   * rank must pass the SAME kind — NULL, its slice (a non-NULL pointer even when the slice is empty) or the whole key; one
+   * mode byte per rank is all-gathered at creation and a disagreement is PLONK_ERR_ARG on every rank (mixed modes would add
+   * whole-column commitments to point-range partial sums: silently wrong wire commitments).  The same random-combination
+   * identity then runs over the ranks — slices summed like any sharded commitment, whole keys compared per rank with the
+   * verdict shared — so a wrong key on any rank is PLONK_ERR_DATA on all of them. */
   const uint8_t* lagrange_xy96;
   uint64_t lagrange_count;
 } plonk_prover_desc;
