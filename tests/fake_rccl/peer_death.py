@@ -49,6 +49,12 @@ def rank_main(rank: int, world: int, log_n: int, uid_path: str) -> int:
     # the wire commitments, 2 = z; all-to-all 1 = the quotient), however many the set-up took
     die_at = os.environ.pop("PEER_DEATH_AT")
     prover, wbuf, _ = bench.build_prover(ctx, log_n, rank, world, None, "dense")
+    # the SHORT time-out only from here on: set-up collectives (prover creation has four since round 6) see the ranks seconds
+    # apart on a busy box — what is under test is a peer that dies INSIDE a proof.  The self-test is the barrier in front of it.
+    ctx.comm_selftest()
+    g = ctx.get_config()
+    g.comm_timeout_ms = TIMEOUT_MS
+    ctx.set_config(g)
     import ctypes
     ctypes.CDLL(FAKE).fake_rccl_arm()
     os.environ["FAKE_RCCL_DIE_AT"] = die_at
@@ -100,7 +106,7 @@ def main() -> int:
         procs = []
         for r in range(world):
             env = dict(os.environ, PEER_DEATH_RANK=str(r), PEER_DEATH_UID=uid_path, HSA_ENABLE_IPC_MODE_LEGACY="0",
-                       FAKE_RCCL_DIE_RANK=str(die_rank), PEER_DEATH_AT=die_at, PLONK_COMM_TIMEOUT_MS=str(TIMEOUT_MS),
+                       FAKE_RCCL_DIE_RANK=str(die_rank), PEER_DEATH_AT=die_at,
                        FAKE_RCCL_KERNEL_TIMEOUT_S="25" if no_abort else "60", FAKE_RCCL_ABORT_FAILS="1" if no_abort else "0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:3]], env=env,
                                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
