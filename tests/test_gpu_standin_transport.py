@@ -141,7 +141,7 @@ def test_a_poisoned_context_refuses_every_entry_point_and_tears_down_without_han
     assert alive["rc_second"] == -7 and alive["seconds_second"] < 2.0, rep
     for name in ("msm", "ntt", "sync", "h2d"):
         assert alive["rc_" + name] == -7 and alive["seconds_" + name] < 1.0, (name, rep)
-    assert alive["seconds_teardown"] < 8.0, rep
+    assert alive["seconds_teardown"] < 12.0, rep      # three bounded polls of 2 s (prover, communicator, context) + the frees that are skipped
 
 
 @pytest.mark.parametrize("ranks,log_gates,env", [(3, 13, {}), (2, 12, {"PLONK_SHARD_QUOTIENT": "0"})])
