@@ -288,7 +288,12 @@ int plonk_prover_peek(plonk_prover* p, int which, uint64_t offset, uint64_t coun
  * challenge (probability of missing it <= 5n/q); PLONK_QUOTIENT_DOMAIN=8 in the environment selects the
  * reference's 8n evaluation with its exact degree test.
  * One deviation: when the evaluation challenge z or z * omega is ZERO (probability 2^-254) the opening quotients are
- * computed with 1 / z, and the call returns PLONK_ERR_STATE where the reference would go on to emit a proof. */
+ * computed with 1 / z, and the call returns PLONK_ERR_STATE where the reference would go on to emit a proof.
+ * Cost of the host columns: they cross PCIe inside the call, one after the other on a copy stream; from 2^19 gates on the
+ * library commits to column a, then b, then c + d as each lands (plonk_prover_info.wire_group_launches = 3), so only the
+ * FIRST column's copy is exposed — a proof from PINNED columns (plonk_host_alloc) is 0.8-1.15 ms slower than
+ * plonk_prover_prove_dev at 2^20 gates (bench.py: prove_ms_host_wires_pinned, host_wires.pcie_floor_ms).  Pageable memory
+ * works but the copies then stage synchronously and overlap nothing. */
 int plonk_prover_prove(plonk_prover* p, const uint64_t* const wires[4], const uint64_t* pi_idx,
                        const uint64_t* pi_val, uint64_t pi_count, const uint64_t* blinders,
                        uint8_t proof[1008]);
