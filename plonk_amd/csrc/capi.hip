@@ -107,6 +107,11 @@ void prof_end(Ctx* c, int slot) {
   ps->recs.push_back({slot, ps->open[slot], e});
   ps->open[slot] = nullptr;
 }
+void prof_host_add(Ctx* c, int slot, double ms) {
+  if (!c->profile) return;
+  c->acc_ms[slot] += ms;
+  c->acc_n[slot] += 1;
+}
 static int prof_collect(Ctx* c) {
   ProfState* ps = prof_state(c);
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -736,90 +736,78 @@ __global__ void l1_finish_kernel(Fr* __restrict__ l1, uint64_t n8, L1Args a) {
 
 // ---------------------------------------------------------------------------
 // polynomial evaluation (Polynomial::evaluate, polynomial.rs:120-137): each lane runs Horner over
-// 16 coefficients with the point in twiddle form; lanes, then workgroups, are combined by a
-// tree in which the right half is multiplied by x^(distance): x^(2^k) comes from a squaring
-// chain computed once per workgroup — no per-lane exponentiation.
+// 2^LE coefficients with the point in twiddle form; lanes, then workgroups, are combined by a
+// tree in which the right half is multiplied by x^(distance).  The squarings x^(2^b) are computed by
+// the HOST, once per distinct point of a call (two in a proof: z and z w), and ride in the kernel
+// arguments (round 6, second session): until then lane 0 of every workgroup ran the chain (11, then 20
+// dependent squarings) while the other 255 waited for it — with 16 coefficients per lane the two kernels
+// were ~53 dependent products = 72 us at EVERY size up to 2^16 gates.  Small polynomials now take 4
+// coefficients per lane (4 x the workgroups, a quarter of the Horner chain) and the final tree stops at
+// the number of partials: ~20 dependent products.
 // ---------------------------------------------------------------------------
 static constexpr int EV_T = 256;
-static constexpr int EV_E = 16;     // 2^4 coefficients per lane, 2^12 per workgroup
+static constexpr int EV_PW = 22;    // x^(2^b), b < 22: 2^(8 + LE) coefficients per workgroup, 256 partials per final lane step
+static constexpr int EV_POINTS = 2; // distinct evaluation points per call (a proof has two: z and z w)
 struct EvalItemD {
   const Fr* poly;
   uint64_t len;
-  Tw xt;
+  uint32_t point;   // index into pw
 };
 struct EvalArgsD {
   EvalItemD items[16];
+  Tw pw[EV_POINTS][EV_PW];
   Fr* partial;
   uint32_t max_blocks;
 };
-// tree over the 256 lane values; lane t's value stands for x^(step * t) * v_t, pw[s] = x^(step * 2^s)
-__device__ __forceinline__ Fr29 eval_tree(Fr29 acc, uint32_t (*sh)[EV_T], const uint32_t (*pw)[9], int t) {
-  for (int s = 0; s < 8; ++s) {
+// tree over the first 2^levels lane values; lane t's value stands for x^(step * t) * v_t, pw[s] = x^(step * 2^s)
+__device__ __forceinline__ Fr29 eval_tree(Fr29 acc, uint32_t (*sh)[EV_T], const Tw* pw, int t, int levels) {
+  for (int s = 0; s < levels; ++s) {
     const int d = 1 << s;
     lds_put(sh, t, acc);
     __syncthreads();
-    if ((t & (2 * d - 1)) == 0) {
-      Fr29 w;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) w.l[i] = pw[s][i];
-      acc = Fr29::add_csub(acc, Fr29::mul(lds_get(sh, t + d), w));
-    }
+    if ((t & (2 * d - 1)) == 0) acc = Fr29::add_csub(acc, Fr29::mul(lds_get(sh, t + d), tw29(pw[s])));
     __syncthreads();
   }
   return acc;
 }
+template <int LE>   // 2^LE coefficients per lane, 2^(8 + LE) per workgroup
 __global__ void __launch_bounds__(EV_T) eval_kernel(EvalArgsD a) {
+  constexpr int E = 1 << LE;
   __shared__ uint32_t sh[9][EV_T];
-  __shared__ uint32_t pw[8][9];
   const EvalItemD& it = a.items[blockIdx.y];
+  const Tw* pw = a.pw[it.point];
   const int t = threadIdx.x;
-  const Fr29 xt = tw29(it.xt);
-  if (t == 0) {   // x^(2^k), k = 4..11
-    Fr29 p = xt;
-    for (int k = 1; k <= 11; ++k) {
-      p = Fr29::mul(p, p);
-      if (k >= 4)
-        for (int i = 0; i < 9; ++i) pw[k - 4][i] = p.l[i];
-    }
-  }
-  const uint64_t base = ((uint64_t)blockIdx.x * EV_T + t) * EV_E;
+  const Fr29 xt = tw29(pw[0]);
+  const uint64_t base = ((uint64_t)blockIdx.x * EV_T + t) * E;
   Fr29 acc = Fr29::zero();
   if (base < it.len) {
 #pragma unroll
-    for (int k = EV_E - 1; k >= 0; --k) {
+    for (int k = E - 1; k >= 0; --k) {
       acc = Fr29::mul(acc, xt);
       if (base + k < it.len) acc = Fr29::add_csub(acc, ld29_(it.poly + base + k));
     }
   }
-  __syncthreads();
-  acc = eval_tree(acc, sh, pw, t);
+  acc = eval_tree(acc, sh, pw + LE, t, 8);
   if (t == 0) stf(a.partial + (uint64_t)blockIdx.y * a.max_blocks + blockIdx.x, acc.to_fr());
 }
-__global__ void __launch_bounds__(EV_T) eval_final_kernel(EvalArgsD a, uint32_t nblocks, Fr* __restrict__ out) {
+template <int LE>
+__global__ void __launch_bounds__(EV_T) eval_final_kernel(EvalArgsD a, uint32_t nblocks, int levels, Fr* __restrict__ out) {
   __shared__ uint32_t sh[9][EV_T];
-  __shared__ uint32_t pw[9][9];   // x^(2^k), k = 12..19, and x^(2^20)
   const EvalItemD& it = a.items[blockIdx.x];
+  const Tw* pw = a.pw[it.point];
   const int t = threadIdx.x;
-  if (t == 0) {
-    Fr29 p = tw29(it.xt);
-    for (int k = 1; k <= 20; ++k) {
-      p = Fr29::mul(p, p);
-      if (k >= 12)
-        for (int i = 0; i < 9; ++i) pw[k - 12][i] = p.l[i];
-    }
-  }
-  __syncthreads();
-  Fr29 big;
-#pragma unroll
-  for (int i = 0; i < 9; ++i) big.l[i] = pw[8][i];
-  // lane t: Horner in x^(2^20) over workgroup partials t, t + 256, ...
+  // lane t: Horner in x^(2^(16 + LE)) over workgroup partials t, t + 256, ...
   Fr29 acc = Fr29::zero();
   const Fr* part = a.partial + (uint64_t)blockIdx.x * a.max_blocks;
   if ((uint32_t)t < nblocks) {
     const uint32_t last = t + ((nblocks - 1 - t) / EV_T) * EV_T;
-    for (int64_t k = last; k >= t; k -= EV_T) acc = Fr29::add_csub(Fr29::mul(acc, big), ld29_(part + k));
+    acc = ld29_(part + last);
+    if (last != (uint32_t)t) {
+      const Fr29 big = tw29(pw[16 + LE]);
+      for (int64_t k = (int64_t)last - EV_T; k >= t; k -= EV_T) acc = Fr29::add_csub(Fr29::mul(acc, big), ld29_(part + k));
+    }
   }
-  acc = eval_tree(acc, sh, pw, t);
+  acc = eval_tree(acc, sh, pw + 8 + LE, t, levels);
   if (t == 0) stf(out + blockIdx.x, acc.to_fr());
 }
 
@@ -847,30 +835,50 @@ __global__ void __launch_bounds__(256) lincomb_kernel(LinCombArgsD a) {
 
 // ruffini: q_i = z^-(i+1) * sum_{j > i} c_j z^j
 //   step 1: d_j = c_j z^j ; step 2: suffix sums ; step 3: q_i = S_{i+1} * zinv^(i+1)
-// dst[i] = src[i + src_off] * x^(i + exp_off): a wave covers 64 * MP_E consecutive elements, lane l
+// dst[i] = src[i + src_off] * x^(i + exp_off): a wave covers 64 * E consecutive elements, lane l
 // takes l, l + 64, ... (coalesced) and steps its power by x^64.
-static constexpr int MP_E = 16;
+// Round 6 (second session): the lane's first power x^(first + exp_off) is a product over the set bits of the exponent of
+// the squarings x^(2^b), which the HOST computes once per call (a few microseconds of 64-bit arithmetic while the device
+// runs the previous kernel) and passes in the kernel arguments — until then every lane ran its own square-and-multiply
+// chain (~26 dependent products before its first element, 64 with the 32 of its 16 elements), which made the kernel pure
+// latency below 2^18 coefficients: 40-44 us per call at 2^12 ... 2^16 gates and on every rank of a sharded proof, four calls
+// per proof.  Now 6 products for the lane bits + one per set bit above them, and E follows the size (1 / 4 / 16 elements per
+// lane) so that small arrays spread over the chip instead of serialising 16 elements per lane.
+static constexpr int MP_BITS = 30;
 struct MulPowArgs {
-  Tw xt, one_t;
-  Fr addend;   // added to every source element before the multiplication (the suffix-sum carry of the ranks above)
+  Tw pw[MP_BITS];   // x^(2^b) in twiddle form, b < nbits
+  Tw one_t;
+  Fr addend;        // added to every source element before the multiplication (the suffix-sum carry of the ranks above)
+  uint32_t nbits;   // bits of the largest exponent of the call
+  uint64_t zero_at; // dst[zero_at] = 0 (ruffini's dropped slot; ~0: none) — saves a launch of its own
 };
+template <int E>
 __global__ void __launch_bounds__(256) mul_powers_kernel(const Fr* __restrict__ src, Fr* __restrict__ dst, uint64_t n,
                                                          MulPowArgs a, uint64_t src_off, uint64_t exp_off) {
   const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g == 0 && a.zero_at != ~0ull) stf(dst + a.zero_at, Fr::zero());
   const uint64_t wave = g >> 6, lane = g & 63;
-  const uint64_t first = wave * (64 * MP_E) + lane;
+  const uint64_t first = wave * (64 * E) + lane;
   if (first >= n) return;
-  const Fr29 xt = tw29(a.xt), one_t = tw29(a.one_t), add = Fr29::from_fr(a.addend);
-  Fr29 p = pow_tw(xt, first + exp_off, one_t);
-  Fr29 step = xt;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) step = Fr29::mul(step, step);   // x^64
+  const Fr29 add = Fr29::from_fr(a.addend);
+  const uint64_t e = first + exp_off;
+  Fr29 p = tw29(a.one_t);
+  bool started = false;
 #pragma unroll 1
-  for (int k = 0; k < MP_E; ++k) {
+  for (uint32_t b = 0; b < a.nbits; ++b) {
+    if ((e >> b) & 1) {
+      const Fr29 w = tw29(a.pw[b]);
+      p = started ? Fr29::mul(p, w) : w;
+      started = true;
+    }
+  }
+  const Fr29 step = tw29(a.pw[6]);   // x^64
+#pragma unroll 1
+  for (int k = 0; k < E; ++k) {
     const uint64_t i = first + 64ull * k;
     if (i >= n) break;
     stf(dst + i, Fr29::mul(Fr29::add_csub(ld29_(src + i + src_off), add), p).to_fr());
-    p = Fr29::mul(p, step);
+    if (E > 1) p = Fr29::mul(p, step);
   }
 }
 
@@ -1112,18 +1120,42 @@ int poly_l1(Ctx* c, const Fr* linear, Fr* l1, uint64_t n8, const L1Args& a) {
   return PLONK_OK;
 }
 int poly_eval(Ctx* c, EvalArgs& a, int count, uint64_t max_len, Fr* out_dev) {
-  const uint32_t nb = (uint32_t)((max_len + (uint64_t)EV_T * EV_E - 1) / ((uint64_t)EV_T * EV_E));
-  if (nb > a.max_blocks || count > 16) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  if (count > 16 || max_len == 0) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
+  // coefficients per lane by size: 4 up to 2^17 (the chain of dependent products is what a small evaluation costs), else 16
+  const int le = max_len <= (1ull << 17) ? 2 : 4;
+  const uint64_t per_wg = (uint64_t)EV_T << le;
+  const uint32_t nb = (uint32_t)((max_len + per_wg - 1) / per_wg);
+  if (nb > a.max_blocks || (uint64_t)nb > 256ull * 64) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // (x^(2^(16 + LE)) is the last power: the lanes' own Horner takes the rest)
   EvalArgsD d;
+  Fr pts[EV_POINTS];
+  int npts = 0;
   for (int k = 0; k < count; ++k) {
     d.items[k].poly = a.items[k].poly;
     d.items[k].len = a.items[k].len;
-    d.items[k].xt = tw_of(a.items[k].x);
+    int w = 0;
+    while (w < npts && !(pts[w] == a.items[k].x)) ++w;
+    if (w == npts) {
+      if (npts == EV_POINTS) return (plonk::set_last_error("invalid argument", "poly_eval: more than 2 distinct points", __FILE__, __LINE__), PLONK_ERR_ARG);
+      pts[npts++] = a.items[k].x;
+      Fr29 p = Fr29::twiddle_from_fr(a.items[k].x);
+      for (int b = 0; b < EV_PW; ++b) {
+        for (int i = 0; i < 9; ++i) d.pw[w][b].w[i] = p.l[i];
+        p = Fr29::mul(p, p);
+      }
+    }
+    d.items[k].point = (uint32_t)w;
   }
   d.partial = a.partial;
   d.max_blocks = a.max_blocks;
-  hipLaunchKernelGGL(eval_kernel, dim3(nb, count), dim3(EV_T), 0, c->stream, d);
-  hipLaunchKernelGGL(eval_final_kernel, dim3(count), dim3(EV_T), 0, c->stream, d, nb, out_dev);
+  int levels = 0;
+  while (levels < 8 && (1u << levels) < nb) ++levels;
+  if (le == 2) {
+    hipLaunchKernelGGL(eval_kernel<2>, dim3(nb, count), dim3(EV_T), 0, c->stream, d);
+    hipLaunchKernelGGL(eval_final_kernel<2>, dim3(count), dim3(EV_T), 0, c->stream, d, nb, levels, out_dev);
+  } else {
+    hipLaunchKernelGGL(eval_kernel<4>, dim3(nb, count), dim3(EV_T), 0, c->stream, d);
+    hipLaunchKernelGGL(eval_final_kernel<4>, dim3(count), dim3(EV_T), 0, c->stream, d, nb, levels, out_dev);
+  }
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
@@ -1143,13 +1175,28 @@ int poly_lincomb(Ctx* c, const LinCombArgs& a) {
   return PLONK_OK;
 }
 static void launch_mul_powers(Ctx* c, const Fr* src, Fr* dst, uint64_t n, const Fr& x, uint64_t src_off, uint64_t exp_off,
-                              const Fr& addend = Fr::zero()) {
-  if (!n) return;
+                              const Fr& addend = Fr::zero(), uint64_t zero_at = ~0ull) {
+  if (!n) {
+    if (zero_at != ~0ull) (void)poly_fill_zero(c, dst + zero_at, 1);
+    return;
+  }
   MulPowArgs a;
-  a.xt = tw_of(x);
+  const uint64_t emax = n - 1 + exp_off;
+  uint32_t nbits = 7;                                   // pw[6] = x^64 is the lanes' step
+  while (nbits < MP_BITS && (emax >> nbits)) ++nbits;   // (exponents stay below 2^30: n <= 2^25 + a range offset)
+  Fr29 p = Fr29::twiddle_from_fr(x);
+  for (uint32_t b = 0; b < nbits; ++b) {
+    for (int i = 0; i < 9; ++i) a.pw[b].w[i] = p.l[i];
+    p = Fr29::mul(p, p);                                // twiddle form is closed under the product: (x R'')^2 / R'' = x^2 R''
+  }
   a.one_t = tw_of(Fr::one());
   a.addend = addend;
-  hipLaunchKernelGGL(mul_powers_kernel, grid1((n + MP_E - 1) / MP_E, 256), dim3(256), 0, c->stream, src, dst, n, a, src_off, exp_off);
+  a.nbits = nbits;
+  a.zero_at = zero_at;
+  // elements per lane by size: the kernel is latency below ~2^18 coefficients (one product chain per lane), throughput above
+  if (n <= (1ull << 17)) hipLaunchKernelGGL(mul_powers_kernel<1>, grid1(n, 256), dim3(256), 0, c->stream, src, dst, n, a, src_off, exp_off);
+  else if (n <= (1ull << 19)) hipLaunchKernelGGL(mul_powers_kernel<4>, grid1((n + 3) / 4 + 64, 256), dim3(256), 0, c->stream, src, dst, n, a, src_off, exp_off);
+  else hipLaunchKernelGGL(mul_powers_kernel<16>, grid1((n + 15) / 16 + 64, 256), dim3(256), 0, c->stream, src, dst, n, a, src_off, exp_off);
 }
 // quotient of src[0..len) by (X - z) -> dst[0..len-1); dst[len-1] = 0.  scratch: len Fr + totals.
 int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, const Fr& zinv, Fr* scratch, Fr* totals) {
@@ -1157,10 +1204,9 @@ int poly_ruffini(Ctx* c, const Fr* src, Fr* dst, uint64_t len, const Fr& z, cons
   int rc = scan_suffix_sum(c, scratch, len, totals);
   if (rc) return rc;
   // q_i = S_{i+1} * zinv^(i+1), i < len - 1
-  launch_mul_powers(c, scratch, dst, len - 1, zinv, 1, 1);
-  rc = poly_fill_zero(c, dst + (len - 1), 1);
+  launch_mul_powers(c, scratch, dst, len - 1, zinv, 1, 1, Fr::zero(), len - 1);   // (+ dst[len - 1] = 0)
   HIP_TRY(hipGetLastError());
-  return rc;
+  return PLONK_OK;
 }
 
 int poly_fold(Ctx* c, const Fr* src, Fr* dst, uint64_t n, uint32_t extra, const Fr& cn) {

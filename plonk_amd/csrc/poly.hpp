@@ -111,6 +111,7 @@ int poly_ruffini_finish(Ctx* c, const Fr* scratch, Fr* dst, uint64_t lo, uint64_
 
 void prof_begin(Ctx* c, int slot);
 void prof_end(Ctx* c, int slot);
+void prof_host_add(Ctx* c, int slot, double ms);   // host wall time on a slot (no events): prover.hip HostGap
 
 int poly_fill_zero(Ctx* c, Fr* p, uint64_t n);
 int poly_blind(Ctx* c, Fr* coeffs, uint64_t n, const BlindArgs& a);

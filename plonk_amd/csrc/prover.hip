@@ -15,6 +15,8 @@
 
 #include "poly.hpp"
 #include "transcript.hpp"
+#include <chrono>
+
 #include "hostg1.hpp"
 #include "widgets.hpp"
 #include "permutation.hpp"
@@ -181,6 +183,32 @@ struct SideJoin {   // never leave side work in flight when prove() returns (buf
   ~SideJoin() { (void)hipStreamSynchronize(c->side_stream); }
 };
 
+// Host time of a proof (slots 8-10 of plonk_profile_read, only while profiling is on): what the HOST does while the device
+// waits for it.  prove() has five points where the transcript needs device results before the next kernels can be queued
+// (four commitment groups and the 15 evaluations): slot 10 = time blocked in those synchronisations (the device is
+// working), slot 8 = the host arithmetic that turns bit sums into compressed commitments (finish_bit_sums, the shared
+// inversion, compression), slot 9 = from the return of a synchronisation to the next launch on the main stream (slot 8
+// included) — the device's main stream is idle for exactly that long, plus the launch latency.
+struct HostGap {
+  using clock = std::chrono::steady_clock;
+  Ctx* c;
+  clock::time_point t_sync;
+  bool open = false;
+  static double ms(clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); }
+  void synced(clock::time_point before) {   // a synchronisation just returned
+    if (!c->profile) return;
+    t_sync = clock::now();
+    open = true;
+    prof_host_add(c, 10, ms(before, t_sync));
+  }
+  void launching() {                        // the next main-stream launch follows
+    if (!c->profile || !open) return;
+    open = false;
+    prof_host_add(c, 9, ms(t_sync, clock::now()));
+  }
+};
+static thread_local HostGap* tl_gap = nullptr;   // the proof in flight on this thread (fetch_commitments reports through it)
+
 static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 17 bit sums per commitment (msm_bits_kernel)
 
 // CommitKey::commit (key.rs:376-388) on the rank's slice of the SRS: points
@@ -295,8 +323,11 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
                          hipMemcpyDeviceToHost, c->stream));
   // a sharded proof queues collectives on this stream (the quotient's all-to-all precedes the t commitments): never a
   // blocking wait behind one — comm_sync polls and aborts the communicator on time-out (a dead peer must not hang the rest)
+  const auto t_before = HostGap::clock::now();
   if (p->world > 1) PTRY(comm_sync(c, c->stream));
   else HIP_TRY(hipStreamSynchronize(c->stream));
+  if (tl_gap) tl_gap->synced(t_before);
+  const auto t_fin = HostGap::clock::now();
   std::vector<G1> sums(count);
   for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)), p->res_rowbits[first + i], p->res_bitpos[first + i]);
   if (p->world > 1) {
@@ -316,6 +347,7 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
   uint8_t aff[16][97];
   batch_xyzz_to_affine97(sums.data(), count, aff);
   for (int i = 0; i < count; ++i) g1_compress97(aff[i], out48[i]);
+  if (tl_gap) prof_host_add(c, 8, HostGap::ms(t_fin, HostGap::clock::now()));
   return PLONK_OK;
 }
 
@@ -495,7 +527,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
   ALLOC(p->wit2, np);
   ALLOC(p->scratch, 2 * np);
   ALLOC(p->totals, 256 * 64 + 1);   // scan block totals (poly.hip: SCAN_T * SCAN_MAXPER)
-  p->ev_max_blocks = (uint32_t)((np + 4095) / 4096);
+  p->ev_max_blocks = (uint32_t)((np + 1023) / 1024);   // poly_eval: 2^10 coefficients per workgroup for small polynomials, 2^12 above
   ALLOC(p->evpart, 16 * (uint64_t)p->ev_max_blocks);
   ALLOC(p->evout, 16);
   ALLOC(p->res, 16 * RES_STRIDE);
@@ -811,6 +843,8 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   seed_transcript(tr, p, pi_val, pi_count);
 
   uint8_t comm[11][48];
+  HostGap gap{c};
+  struct GapScope { HostGap* g; GapScope(HostGap* x) : g(x) { tl_gap = g; } ~GapScope() { g->launching(); tl_gap = nullptr; } } gap_scope(&gap);   // (the last gap — after the opening commitments — closes at return)
   // ---- round 1 (prover.rs:444-479)
   const bool lag = p->lag_on;
   // iNTT + blinding of the four columns and their lowest coefficients (quotient_low), on the CURRENT stream
@@ -950,6 +984,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     pa.ks[0] = Fr::one(); pa.ks[1] = fr_small(7); pa.ks[2] = fr_small(13); pa.ks[3] = fr_small(17);
     pa.tw_lo29 = tbn->tw_lo29; pa.tw_hi29 = tbn->tw_hi29; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
     pa.num = p->scratch; pa.den = p->scratch + np;
+    gap.launching();
     HIP_TRY(hipMemsetAsync(p->flag_dev, 0, sizeof(int), c->stream));
     PTRY(poly_perm_terms(c, pa));
     // numerators / denominators stay in twiddle form (x * 2^261) from perm_terms to the end of the scan
@@ -1016,6 +1051,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     quotient_const(alpha.sqr(), 0, q.k.alpha_sq);
     for (int i = 0; i < 8; ++i) quotient_const(p->vinv[i], 0, q.k.vinv[i]);
     q.out = p->tbuf;
+    gap.launching();
     PTRY(poly_quotient(c, q));
     PTRY(ntt_device(c, p->tbuf, p->tbuf, p->tmp8, L + p->lq, true, true, n8));
   }
@@ -1089,9 +1125,12 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       ea.items[k].len = len[k];
       ea.items[k].x = (k >= 4 && k <= 6) || k == 14 ? zw : z_ch;
     }
+    gap.launching();
     PTRY(poly_eval(c, ea, 15, n + 3, p->evout));
     HIP_TRY(hipMemcpyAsync(p->ev_host, p->evout, 15 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    const auto t_before = HostGap::clock::now();
     HIP_TRY(hipStreamSynchronize(c->stream));
+    gap.synced(t_before);
     const Fr* h = p->ev_host;
     ev.a = h[0]; ev.b = h[1]; ev.c = h[2]; ev.d = h[3]; ev.a_w = h[4]; ev.b_w = h[5]; ev.d_w = h[6];
     ev.q_arith = h[7]; ev.q_c = h[8]; ev.q_l = h[9]; ev.q_r = h[10]; ev.s1 = h[11]; ev.s2 = h[12]; ev.s3 = h[13]; ev.z = h[14];
@@ -1167,6 +1206,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     la.len = np - 1;
     la.constant = pi_eval;
     la.out = p->agg;
+    gap.launching();
     PTRY(poly_lincomb(c, la));
   }
   PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : inv_z, p->scratch, p->totals));
@@ -1546,11 +1586,17 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     PTRY(comm_allgather_host(c, p->link, p->ev_host, all.data(), 15 * sizeof(Fr)));
     Fr h[15];
     for (int k = 0; k < 15; ++k) h[k] = Fr::zero();
-    for (uint32_t r = 0; r < W; ++r) {                         // sum_r x^(lo_r) * partial_r
-      uint64_t lo_r = p->per * r;
-      if (lo_r > n + 7) lo_r = n + 7;
-      const Fr pz = z_ch.pow_u64(lo_r), pzw = zw.pow_u64(lo_r);
+    // sum_r x^(lo_r) * partial_r.  The powers step by x^per from rank to rank (one product each); only a clamped range start
+    // takes an exponentiation of its own — the host sits between two device phases here (2 W square-and-multiply chains of
+    // 64 steps were ~0.15 ms of every 8-rank proof)
+    const Fr step_z = z_ch.pow_u64(p->per), step_zw = zw.pow_u64(p->per);
+    Fr pz = Fr::one(), pzw = Fr::one();
+    for (uint32_t r = 0; r < W; ++r) {
+      const uint64_t lo_r = p->per * r;
+      if (lo_r > n + 7) { pz = z_ch.pow_u64(n + 7); pzw = zw.pow_u64(n + 7); }
       for (int k = 0; k < 15; ++k) h[k] = h[k] + all[15 * r + k] * (((k >= 4 && k <= 6) || k == 14) ? pzw : pz);
+      pz = pz * step_z;
+      pzw = pzw * step_zw;
     }
     ev.a = h[0]; ev.b = h[1]; ev.c = h[2]; ev.d = h[3]; ev.a_w = h[4]; ev.b_w = h[5]; ev.d_w = h[6];
     ev.q_arith = h[7]; ev.q_c = h[8]; ev.q_l = h[9]; ev.q_r = h[10]; ev.s1 = h[11]; ev.s2 = h[12]; ev.s3 = h[13]; ev.z = h[14];
