@@ -1228,8 +1228,12 @@ uint32_t msm_ksl(const Ctx* c, uint64_t m) {
   return r;
 }
 
-// lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default where slices are 32 entries long
-bool msm_acc_ordered(const Ctx* c, uint32_t ksl) { return c->cfg.order >= 0 ? c->cfg.order == 1 : ksl >= 32; }
+// lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default from 16-entry slices on.
+// Until round 6 from 32-entry slices on (m > 2^17.4).  Same-box A/B at 16-entry slices, three repetitions
+// (profiles/r06b/order17.jsonl): a 2^17-gate proof 6.69 / 6.69 / 6.70 -> 6.57 / 6.52 / 6.50 ms (accumulate 3.57 -> 3.39), a
+// rank of 8 alone at 2^20 gates (2^17-point slices) 6.66 / 6.63 / 6.59 -> 6.60 / 6.53 / 6.59; at 8-entry slices (2^16
+// gates) no difference (4.62-4.68 either way), so shorter slices keep the bucket order and save the ordering launch.
+bool msm_acc_ordered(const Ctx* c, uint32_t ksl) { return c->cfg.order >= 0 ? c->cfg.order == 1 : ksl >= 16; }
 
 #if PLONK_MSM_NB_BITS > 15
 // ---- reduction tail for MANY buckets: throughput first ---------------------------------------------------------------
@@ -1379,10 +1383,10 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int p
   // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
   // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
   const bool acc_lds = c->cfg.acc_lds;
-  // lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default where slices are 32
-  // entries long (m > 2^19; r03a same-box A/B at 2^20: accumulate 26.5 -> 25.7 ms per proof, the waves no longer wait
-  // for their longest lane); shorter slices (smaller m) leave the accumulation latency-bound and the ordering loses
-  // (r02e: +1.1 ms at 2^16).  PLONK_MSM_ORDER=1 / 0 forces either.
+  // lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default from 16-entry slices on
+  // (r03a same-box A/B at 2^20: accumulate 26.5 -> 25.7 ms per proof, the waves no longer wait for their longest lane;
+  // round 6: also at 16-entry slices, msm_acc_ordered); with 4- / 8-entry slices the accumulation is latency-bound and the
+  // ordering gains nothing (r02e: +1.1 ms at 2^16 with the kernels of the time; round 6: +-0).  PLONK_MSM_ORDER=1 / 0 forces either.
   const bool acc_ordered = msm_acc_ordered(c, bt.ksl);
   if (acc_ordered && !acc_lds) {
     rc = msm_order_slices(c, bt);

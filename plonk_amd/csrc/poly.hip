@@ -398,16 +398,20 @@ __device__ __forceinline__ Fr29 ps_lanes(Fr29 acc, uint32_t (*sh)[SCAN_T], int t
   *tot = ps_get(sh, SCAN_T - 1);
   return excl;
 }
-template <bool FINAL>   // FINAL: single workgroup, results leave in the data domain
+// Elements per lane (round 6, second session): 8 for large arrays (throughput), 2 up to 2^17 elements — below that the three
+// kernels are chains of dependent products on a mostly idle chip (8 + 8 + 8 in the block pass, 2 + 8 in the apply pass:
+// 27 + 20 + 21 us at 2^16 elements), and a quarter of the elements per lane is a quarter of the serial part.
+static inline int pscan_e(uint64_t n) { return n <= (1ull << 17) ? 2 : 8; }
+template <bool FINAL, int E>   // FINAL: single workgroup, results leave in the data domain
 __global__ void __launch_bounds__(SCAN_T) pscan_block_kernel(Fr* __restrict__ data, uint64_t n, Fr* __restrict__ totals, PScanArgs a) {
   __shared__ uint32_t sh[9][SCAN_T];
   const int t = threadIdx.x;
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)t * SCAN_E;
+  const uint64_t base = (uint64_t)blockIdx.x * (SCAN_T * E) + (uint64_t)t * E;
   const Fr29 one_t = tw29(a.one_t);
-  Fr29 v[SCAN_E];
+  Fr29 v[E];
   Fr29 acc = one_t;
 #pragma unroll
-  for (int k = 0; k < SCAN_E; ++k) {
+  for (int k = 0; k < E; ++k) {
     if (base + k < n) acc = Fr29::mul(acc, ld29_(data + base + k));
     v[k] = acc;
   }
@@ -416,7 +420,7 @@ __global__ void __launch_bounds__(SCAN_T) pscan_block_kernel(Fr* __restrict__ da
   if (t == 0) stf(totals + blockIdx.x, tot.to_fr());
   const Fr29 post = FINAL ? Fr29::mul(excl, tw29(a.one_r)) : excl;   // (x R'') * R / R'' = x R
 #pragma unroll
-  for (int k = 0; k < SCAN_E; ++k)
+  for (int k = 0; k < E; ++k)
     if (base + k < n) stf(data + base + k, Fr29::mul(post, v[k]).to_fr());
 }
 __global__ void __launch_bounds__(SCAN_T) pscan_totals_kernel(Fr* __restrict__ totals, uint32_t nb, uint32_t per, PScanArgs a) {
@@ -438,41 +442,55 @@ __global__ void __launch_bounds__(SCAN_T) pscan_totals_kernel(Fr* __restrict__ t
     }
   }
 }
+template <int E>
 __global__ void __launch_bounds__(SCAN_T) pscan_apply_kernel(Fr* __restrict__ data, uint64_t n, const Fr* __restrict__ totals, PScanArgs a) {
   // block 0 only converts; the others also multiply by the product of everything before them
   Fr29 off = tw29(a.one_r);
   if (a.has_carry) off = Fr29::mul(tw29(a.carry_t), off);   // a range of a longer product: everything before the range
   if (blockIdx.x) off = Fr29::mul(ld29_(totals + blockIdx.x - 1), off);
-  const uint64_t base = (uint64_t)blockIdx.x * SCAN_BLOCK + (uint64_t)threadIdx.x * SCAN_E;
+  const uint64_t base = (uint64_t)blockIdx.x * (SCAN_T * E) + (uint64_t)threadIdx.x * E;
 #pragma unroll
-  for (int k = 0; k < SCAN_E; ++k)
+  for (int k = 0; k < E; ++k)
     if (base + k < n) stf(data + base + k, Fr29::mul(ld29_(data + base + k), off).to_fr());
+}
+uint32_t scan_prefix_blocks(uint64_t n) { const uint64_t blk = (uint64_t)SCAN_T * pscan_e(n); return (uint32_t)((n + blk - 1) / blk); }
+static void pscan_launch_block(Ctx* c, bool final, uint32_t nb, Fr* data, uint64_t n, Fr* totals, const PScanArgs& a) {
+  if (pscan_e(n) == 2) {
+    if (final) hipLaunchKernelGGL((pscan_block_kernel<true, 2>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+    else hipLaunchKernelGGL((pscan_block_kernel<false, 2>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  } else {
+    if (final) hipLaunchKernelGGL((pscan_block_kernel<true, 8>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+    else hipLaunchKernelGGL((pscan_block_kernel<false, 8>), dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  }
+}
+static void pscan_launch_apply(Ctx* c, uint32_t nb, Fr* data, uint64_t n, const Fr* totals, const PScanArgs& a) {
+  if (pscan_e(n) == 2) hipLaunchKernelGGL(pscan_apply_kernel<2>, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  else hipLaunchKernelGGL(pscan_apply_kernel<8>, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
 }
 // data: twiddle form in, data domain (Montgomery R = 2^256) out
 int scan_prefix_product(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
-  const uint32_t nb = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  const uint32_t nb = scan_prefix_blocks(n);
   if (nb > SCAN_T * SCAN_MAXPER) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);   // n <= 2^25
   PScanArgs a{};
   a.one_t = tw_of(Fr::one());
   a.one_r = tw_plain(Fr::one());
   if (nb == 1) {
-    hipLaunchKernelGGL(pscan_block_kernel<true>, dim3(1), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+    pscan_launch_block(c, true, 1, data, n, totals, a);
   } else {
-    hipLaunchKernelGGL(pscan_block_kernel<false>, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+    pscan_launch_block(c, false, nb, data, n, totals, a);
     hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb, (nb + SCAN_T - 1) / SCAN_T, a);
-    hipLaunchKernelGGL(pscan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+    pscan_launch_apply(c, nb, data, n, totals, a);
   }
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }
-uint32_t scan_prefix_blocks(uint64_t n) { return (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK); }
 int scan_prefix_product_local(Ctx* c, Fr* data, uint64_t n, Fr* totals) {
   const uint32_t nb = scan_prefix_blocks(n);
   if (nb == 0 || nb > SCAN_T * SCAN_MAXPER) return (plonk::set_last_error("invalid argument", __func__, __FILE__, __LINE__), PLONK_ERR_ARG);
   PScanArgs a{};
   a.one_t = tw_of(Fr::one());
   a.one_r = tw_plain(Fr::one());
-  hipLaunchKernelGGL(pscan_block_kernel<false>, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  pscan_launch_block(c, false, nb, data, n, totals, a);
   hipLaunchKernelGGL(pscan_totals_kernel, dim3(1), dim3(SCAN_T), 0, c->stream, totals, nb, (nb + SCAN_T - 1) / SCAN_T, a);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
@@ -484,7 +502,7 @@ int scan_prefix_product_apply(Ctx* c, Fr* data, uint64_t n, const Fr* totals, co
   a.one_r = tw_plain(Fr::one());
   a.carry_t = tw_plain(carry_twiddle);   // already x * 2^261: re-sliced, not converted
   a.has_carry = 1;
-  hipLaunchKernelGGL(pscan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, c->stream, data, n, totals, a);
+  pscan_launch_apply(c, nb, data, n, totals, a);
   HIP_TRY(hipGetLastError());
   return PLONK_OK;
 }

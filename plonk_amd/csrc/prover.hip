@@ -1153,6 +1153,29 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     inv_z = iab * b;
     inv_zm1 = iab * a;
   }
+  if (z_zero || zw.is_zero()) return PLONK_ERR_STATE;   // probability 2^-255; (X - 0) division is a shift — not worth a code path
+  // W_z's commitment is not absorbed before v_w is drawn (prover.rs:727-730): both opening witnesses are committed as one
+  // group, and the second one — W_zw = (z + v_w a + v_w^2 b + v_w^3 d) / (X - z w), which needs nothing but z and v_w — is
+  // built on the SIDE stream (round 6, second session) while the host is still computing the linearisation scalars of the
+  // first and the main stream builds that: below 2^18 gates the two chains of ~6 latency-bound kernels ran back to back.
+  // Buffers: the transform scratch (no transform runs after round 3), the upper half of `scratch`, the upper half of `totals`.
+  const Fr v_w = tr.challenge_scalar("v_w_challenge");
+  {
+    gap.launching();
+    SideScope side(c, p->ev_ready);
+    LinCombArgs la;
+    la.t[0].p = p->zpoly; la.t[0].len = n + 3; la.t[0].s = one;
+    la.t[1].p = p->wpoly; la.t[1].len = n + 2; la.t[1].s = v_w;
+    la.t[2].p = p->wpoly + np; la.t[2].len = n + 2; la.t[2].s = v_w.sqr();
+    la.t[3].p = p->wpoly + 3 * np; la.t[3].len = n + 2; la.t[3].s = v_w.sqr() * v_w;
+    la.count = 4;
+    la.len = np - 1;
+    la.constant = Fr::zero();
+    la.out = p->tmp8;
+    PTRY(poly_lincomb(c, la));
+    PTRY(poly_ruffini(c, p->tmp8, p->wit2, np - 1, zw, inv_z * p->omega_inv, p->scratch + np, p->totals + 8192));
+    HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+  }
   const Fr pi_eval = public_input_eval(p, pi_idx, pi_val, pi_count, z_ch, zh);
   // permutation linearisation scalars (permutation/proverkey.rs:127-269)
   const Fr bz = beta * z_ch;
@@ -1209,29 +1232,12 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     gap.launching();
     PTRY(poly_lincomb(c, la));
   }
-  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_zero ? one : z_ch, z_zero ? one : inv_z, p->scratch, p->totals));
+  PTRY(poly_ruffini(c, p->agg, p->wit, np - 1, z_ch, inv_z, p->scratch, p->totals));
   // ruffini's suffix scan leaves sum_j c_j z^j = (W_z numerator)(z) in scratch[0]: keep it for the
   // quotient-identity check below
   HIP_TRY(hipMemcpyAsync(p->evout + 15, p->scratch, sizeof(Fr), hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(p->ev_host + 15, p->evout + 15, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-  if (z_zero) return PLONK_ERR_STATE;   // probability 2^-255; (X - 0) division is a shift — not worth a code path
-  // W_z's commitment is not absorbed before v_w is drawn (prover.rs:727-730), so both opening
-  // witnesses can be committed as one group.
-  const Fr v_w = tr.challenge_scalar("v_w_challenge");
-  {
-    LinCombArgs la;
-    la.t[0].p = p->zpoly; la.t[0].len = n + 3; la.t[0].s = one;
-    la.t[1].p = p->wpoly; la.t[1].len = n + 2; la.t[1].s = v_w;
-    la.t[2].p = p->wpoly + np; la.t[2].len = n + 2; la.t[2].s = v_w.sqr();
-    la.t[3].p = p->wpoly + 3 * np; la.t[3].len = n + 2; la.t[3].s = v_w.sqr() * v_w;
-    la.count = 4;
-    la.len = np - 1;
-    la.constant = Fr::zero();
-    la.out = p->agg;
-    PTRY(poly_lincomb(c, la));
-  }
-  if (zw.is_zero()) return PLONK_ERR_STATE;
-  PTRY(poly_ruffini(c, p->agg, p->wit2, np - 1, zw, inv_z * p->omega_inv, p->scratch, p->totals));
+  HIP_TRY(hipStreamWaitEvent(c->main_stream, p->ev_side, 0));   // W_zw (side stream, above)
   {
     const Fr* sc[2] = {p->wit, p->wit2};
     const uint64_t ms[2] = {np - 2, np - 2};
