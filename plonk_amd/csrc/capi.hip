@@ -209,10 +209,13 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '0') g.wire_by_column = -1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '1') g.wire_by_column = 1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '2') g.wire_by_column = 2;
+  if (getenv("PLONK_HOST_THREADS")) g.host_threads = env_int("PLONK_HOST_THREADS", -1);
   // ---- resolution
   if (g.table_mode != (int)MSM_ROWS_WINDOW && g.table_mode != (int)MSM_ROWS_HALFPOS && g.table_mode != (int)MSM_ROWS_BITPOS) g.table_mode = 0;
   if (g.ntt_elog != 2 && g.ntt_elog != 3) g.ntt_elog = 0;
   if (g.side_cus < 0) g.side_cus = 0;
+  if (g.host_threads < 0) g.host_threads = std::thread::hardware_concurrency() >= 8 ? 3 : 0;
+  if (g.host_threads > 7) g.host_threads = 7;
   if (g.table_budget == 0) {
     size_t total = 0;   // (takes the device ordinal: the calling thread's current device is left alone)
     if (hipDeviceTotalMem(&total, device) != hipSuccess || total == 0) total = 256ull << 30;
@@ -400,6 +403,7 @@ void plonk_ctx_destroy(plonk_ctx* ctx) {
   if (!ctx) return;
   (void)plonk_comm_destroy(ctx);
   Ctx& c = ctx->c;
+  finish_pool_release(&c);   // host helper threads (asleep between proofs): joined on every path, nothing of the device is touched
   (void)hipSetDevice(c.device);
   if (ctx_abandon(&c)) {   // poisoned and still busy: every wait / hipFree / hipStreamDestroy below would hang — leak the device side
     prof_forget(&c);

@@ -232,6 +232,25 @@ static G1 finish_bit_sums(const G1* bits, int rb, bool bitpos) {
   return r;
 }
 
+// sum of n XYZZ points `stride` bytes apart (the per-rank partial sums of one commitment after the all-gather of a sharded
+// proof): the 64-bit-limb additions above, ~0.4 us each — the generic 32-bit-limb G1::add this replaces took ~3 us, i.e.
+// ~0.25 ms of host time per 8-rank proof between device phases
+static G1 h1_sum_strided(const uint8_t* first, size_t stride, int n) {
+  H1 acc;
+  memset(&acc, 0, sizeof acc);
+  for (int r = 0; r < n; ++r) {
+    G1 g;
+    memcpy(&g, first + (size_t)r * stride, sizeof(G1));
+    H1 h;
+    memcpy(h.X.l, g.X.l, 48); memcpy(h.Y.l, g.Y.l, 48); memcpy(h.ZZ.l, g.ZZ.l, 48); memcpy(h.ZZZ.l, g.ZZZ.l, 48);
+    acc = h1_add(acc, h);
+  }
+  if (acc.inf()) return G1::identity();
+  G1 out;
+  memcpy(out.X.l, acc.X.l, 48); memcpy(out.Y.l, acc.Y.l, 48); memcpy(out.ZZ.l, acc.ZZ.l, 48); memcpy(out.ZZZ.l, acc.ZZZ.l, 48);
+  return out;
+}
+
 static Fp64 to64(const Fp& x) { Fp64 r; memcpy(r.l, x.l, 48); return r; }
 static Fp from64(const Fp64& x) { Fp r; memcpy(r.l, x.l, 48); return r; }
 

@@ -31,6 +31,7 @@ struct Ctx;
 // Every entry point that queues work on a context or waits for it therefore goes in through CTX_ENTER (the mutex + a
 // refusal with PLONK_ERR_STATE), and the destroy paths ask ctx_abandon() whether the device side has to be leaked.
 int ctx_refuse_poisoned(const char* api_fn);          // capi.hip: sets the last-error text, returns PLONK_ERR_STATE
+void finish_pool_release(Ctx* c);                     // prover.hip: joins and deletes the context's host helper threads
 bool ctx_abandon(Ctx* c);                             // capi.hip: poisoned AND the streams did not drain within a bounded poll
 #define CTX_ENTER(C, FN)                      \
   std::lock_guard<std::mutex> lk((C).mu);     \
@@ -177,6 +178,7 @@ struct Config {
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
   int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN: 0 -> -1 (host wire columns commit as ONE grouped launch after the last copy, round 5), 1 / 2 -> by column at every size (a, b, c + d / one launch each); unset: by column from 2^19 gates on
   int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
+  int host_threads = -1;            // PLONK_HOST_THREADS=k: helper threads for the host arithmetic between device phases (finish_pool.hpp); -1: 3 on hosts with >= 8 hardware threads, else 0
 };
 
 struct plonk_msm_plan_internal {   // what msm_batch_device chose (mirrors plonk_msm_plan)
@@ -226,6 +228,7 @@ struct Ctx {
   const char* comm_warning = "";   // static text left by plonk_comm_init (plonk_comm_warning); never the last-error string
   bool comm_poisoned = false;      // comm_sync timed out and the stream never drained: sharded proofs and new communicators are refused
   bool comm_loopback = false;      // measurement only: collectives return the rank's own contribution (plonk_comm_measure_loopback)
+  void* finish_pool = nullptr;     // FinishPool* (finish_pool.hpp), created by the first commitment group of a prover (prover.hip), freed by finish_pool_release
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -18,6 +18,7 @@
 #include <chrono>
 
 #include "hostg1.hpp"
+#include "finish_pool.hpp"
 #include "widgets.hpp"
 #include "permutation.hpp"
 
@@ -317,10 +318,32 @@ static int check_lagrange_key(Prover* p, uint32_t L) {
 // to affine on the host (one Fp inversion each) and compress.
 // local_mask: bit i set = slot first + i is NOT summed over the ranks — it holds a sum this rank computed whole (the
 // Lagrange-key check of a rank that holds the whole key); the all-gather still runs (every rank calls in the same order).
+// The context's host helper threads (finish_pool.hpp): created by the first commitment group that has more than one
+// commitment, joined by plonk_ctx_destroy.
+static FinishPool* finish_pool_of(Ctx* c) {
+  if (!c->finish_pool && c->cfg.host_threads > 0) c->finish_pool = new FinishPool(c->cfg.host_threads);
+  return (FinishPool*)c->finish_pool;
+}
+void finish_pool_release(Ctx* c) {
+  delete (FinishPool*)c->finish_pool;
+  c->finish_pool = nullptr;
+}
+struct FinishJob {
+  const Prover* p;
+  int first;
+  G1* sums;
+};
+static void finish_task(void* arg, int i) {
+  const FinishJob* j = (const FinishJob*)arg;
+  j->sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(j->p->res_host + RES_STRIDE * (j->first + i)), j->p->res_rowbits[j->first + i], j->p->res_bitpos[j->first + i]);
+}
 static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[48], uint32_t local_mask) {
   Ctx* c = p->c;
   HIP_TRY(hipMemcpyAsync(p->res_host + RES_STRIDE * first, p->res + RES_STRIDE * first, RES_STRIDE * (size_t)count,
                          hipMemcpyDeviceToHost, c->stream));
+  // the Horner chains of the group's commitments are independent: helper threads are woken NOW, while this thread blocks in
+  // the synchronisation, and take their share as soon as the bit sums are here (finish_pool.hpp)
+  Armed helpers(count >= 2 ? finish_pool_of(c) : nullptr);
   // a sharded proof queues collectives on this stream (the quotient's all-to-all precedes the t commitments): never a
   // blocking wait behind one — comm_sync polls and aborts the communicator on time-out (a dead peer must not hang the rest)
   const auto t_before = HostGap::clock::now();
@@ -329,19 +352,14 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
   if (tl_gap) tl_gap->synced(t_before);
   const auto t_fin = HostGap::clock::now();
   std::vector<G1> sums(count);
-  for (int i = 0; i < count; ++i) sums[i] = finish_bit_sums(reinterpret_cast<const G1*>(p->res_host + RES_STRIDE * (first + i)), p->res_rowbits[first + i], p->res_bitpos[first + i]);
+  FinishJob job{p, first, sums.data()};
+  helpers.run(finish_task, &job, count);
   if (p->world > 1) {
     const size_t bytes = sizeof(G1) * (size_t)count;
     PTRY(comm_allgather_host(c, p->link, sums.data(), p->gather_host, bytes));
     for (int i = 0; i < count; ++i) {
       if (local_mask >> i & 1) continue;
-      G1 acc = G1::identity();
-      for (int r = 0; r < p->world; ++r) {
-        G1 part;
-        memcpy(&part, p->gather_host + (size_t)r * bytes + sizeof(G1) * i, sizeof(G1));
-        acc = acc.add(part);
-      }
-      sums[i] = acc;
+      sums[i] = h1_sum_strided(p->gather_host + sizeof(G1) * i, bytes, (int)p->world);
     }
   }
   uint8_t aff[16][97];

@@ -197,6 +197,67 @@ extern "C" void h_batch_compress(const uint8_t* pts96, int count, uint8_t* out48
   for (int k = 0; k < count; ++k) g1_compress97(aff[k], out48 + 48 * k);
 }
 
+// sum of `n` points (affine in, made projective with odd scalings) with the 64-bit-limb additions of a sharded proof's
+// partial-sum step (h1_sum_strided) -> compressed
+extern "C" void h_sum_strided(const uint8_t* pts96, int n, uint8_t out48[48]) {
+  using namespace plonk;
+  G1 p[64];
+  for (int k = 0; k < n; ++k) {
+    G1Affine a;
+    memcpy(&a, pts96 + 96 * k, 96);
+    if (a.x.is_zero() && a.y.is_zero()) { p[k] = G1::identity(); continue; }
+    p[k] = G1::from_affine(a);
+    for (int j = 0; j < k % 3; ++j) p[k] = p[k].dbl().add(p[k].neg());
+  }
+  const G1 w = h1_sum_strided(reinterpret_cast<const uint8_t*>(p), sizeof(G1), n);
+  uint8_t aff[1][97];
+  batch_xyzz_to_affine97(&w, 1, aff);
+  g1_compress97(aff[0], out48);
+}
+// ---- finish_pool.hpp: the host helper threads of fetch_commitments ----
+#include "../../plonk_amd/csrc/finish_pool.hpp"
+namespace {
+struct PoolProbe { std::atomic<int> hits[16]; std::atomic<long> sum; int spin; };
+void pool_probe_task(void* arg, int i) {
+  PoolProbe* pp = (PoolProbe*)arg;
+  volatile unsigned x = 1;
+  for (int k = 0; k < pp->spin; ++k) x = x * 1664525u + 1013904223u;   // a few hundred ns .. a few us of work
+  pp->hits[i].fetch_add(1);
+  pp->sum.fetch_add(i + 1);
+}
+}
+// `rounds` jobs of 0..16 tasks with every arming pattern fetch_commitments can produce (armed + run, armed + withdrawn,
+// late arming, jobs back to back): returns 0 when every task of every job ran exactly once and run() returned only after
+// the last one; workers == 0 is the inline path.
+extern "C" int h_finish_pool_selftest(int workers, int rounds) {
+  using namespace plonk;
+  FinishPool pool(workers);
+  if (pool.workers() != (workers < 0 ? 0 : (workers > 7 ? 7 : workers))) return -1;
+  unsigned lcg = 12345u + (unsigned)workers;
+  for (int r = 0; r < rounds; ++r) {
+    lcg = lcg * 1664525u + 1013904223u;
+    const int count = (int)((lcg >> 8) % 17);
+    const int pattern = (int)((lcg >> 16) % 4);
+    PoolProbe probe;
+    for (auto& h : probe.hits) h.store(0);
+    probe.sum.store(0);
+    probe.spin = (int)((lcg >> 20) % 2000);
+    if (pattern == 1) { Armed withdrawn(workers > 0 ? &pool : nullptr); }   // armed, nothing to do (an early return)
+    {
+      Armed a(pattern == 2 ? nullptr : (workers > 0 ? &pool : nullptr));     // pattern 2: the inline path of a one-commitment group
+      if (pattern == 3) std::this_thread::sleep_for(std::chrono::microseconds(200));   // workers awake and spinning before the job
+      a.run(pool_probe_task, &probe, count);
+    }
+    long want = 0;
+    for (int i = 0; i < 16; ++i) {
+      if (probe.hits[i].load() != (i < count ? 1 : 0)) return 100 + r;
+      if (i < count) want += i + 1;
+    }
+    if (probe.sum.load() != want) return 200 + r;
+  }
+  return 0;
+}
+
 // ---- permutation.hpp: copy constraints -> sigma mappings (Permutation::compute_sigma_permutations) ----
 #include "../../plonk_amd/csrc/permutation.hpp"
 extern "C" int h_sigma_mappings(const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d, uint64_t constraints,

@@ -20,9 +20,9 @@ def build_host_lib():
     src = os.path.join(HERE, "csrc", "host_arith.cpp")
     hdrs = [os.path.join(HERE, "..", "plonk_amd", "csrc", h)
             for h in ("field.cuh", "curve.cuh", "fp28.cuh", "curve28.cuh", "fr29.cuh", "transcript.hpp", "widgets.hpp", "hostg1.hpp", "permutation.hpp", "g1codec.cuh",
-                      "msm_recode.cuh", "fp_safegcd.cuh", "hostg2.hpp", "api_guard.hpp")]
+                      "msm_recode.cuh", "fp_safegcd.cuh", "hostg2.hpp", "api_guard.hpp", "finish_pool.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(f) > os.path.getmtime(SO) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", src, "-o", SO])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", src, "-o", SO])
     return ctypes.CDLL(SO)
 
 
@@ -532,3 +532,35 @@ def test_cooperative_16_lane_product_model(lib):
     got = list(out)
     assert got[14] == 0 and got[15] == 0 and all(v < (1 << 30) for v in got)
     assert value(got[:14]) % P == value(top) * value(top) * rinv % P
+
+
+def test_partial_sums_of_a_sharded_commitment_on_host(lib):
+    """hostg1.hpp h1_sum_strided: the per-rank partial sums of a commitment added in 64-bit-limb arithmetic (identity
+    contributions, equal contributions -> the doubling branch, opposite ones -> the identity) against the oracle."""
+    rnd = random.Random(65)
+    G = E.G1_GEN
+    for trial in range(8):
+        n = [1, 2, 3, 4, 8, 8, 5, 2][trial]
+        pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(n)]
+        if trial == 4:
+            pts = [pts[0]] * n                     # loop-back: every rank contributes the same point
+        if trial == 5:
+            pts[2] = None
+            pts[7] = None                          # ranks with an empty slice
+        if trial == 7:
+            pts[1] = E.g1_mul(pts[0], Q - 1)       # P + (-P)
+        raw = b"".join(E.g1_to_raw96(p) if p is not None else bytes(96) for p in pts)
+        out = (ctypes.c_uint8 * 48)()
+        lib.h_sum_strided(raw, n, out)
+        want = None
+        for p in pts:
+            if p is not None:
+                want = E.g1_add(want, p)
+        assert bytes(out) == E.g1_compress(want), trial
+
+
+@pytest.mark.parametrize("workers", [0, 1, 3, 7])
+def test_host_helper_threads_run_every_task_exactly_once(lib, workers):
+    """finish_pool.hpp: jobs of 0..16 tasks under every arming pattern of fetch_commitments (armed and run, armed and
+    withdrawn, not armed, workers already spinning): each task runs once, run() returns after the last."""
+    assert lib.h_finish_pool_selftest(workers, 3000) == 0
