@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   st_g1r(partial + s, acc);
 }
 
-// msm_accumulate_kernel with the lanes in order of slice length (PLONK_MSM_ORDER=1; msm_sort.hip msm_order_kernel): lane
+// msm_accumulate_kernel with the lanes in order of slice length (PLONK_MSM_ORDER=1; msm_sort.hip msm_slices_kernel<true>): lane
 // s < F owns full slice s - full_off[b] of the bucket b found by the same two-level search, the lanes after them own the
 // partial slice of bucket part_list[s - F].  The additions are the ones above; the partial sum goes to the slice's usual
 // slot slice_off[b] + q.
@@ -871,6 +871,9 @@ __global__ void __launch_bounds__(256) msm_bits_quad_kernel(MsmBatch bt, const G
   __shared__ G1R sh[64];
   const G1RSlot* __restrict__ rc = rc_all + (uint64_t)blockIdx.y * rc_stride;
   const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
+  // S (block 16) is only read for bit-position entries (2 W - S, finish_bit_sums): for window / even-position digits the block
+  // — the longest chain of this launch, 256 points against 128 — does not run, and the kernel ends with the bit sums
+  if (u == 16 && bt.rows != MSM_ROWS_BITPOS) return;
   G1* __restrict__ out = bt.out[blockIdx.y] + (u < 17 ? u + extra : u - 17);
   G1R acc = G1R::identity();
   for (uint32_t i = L; i < (u == 16 ? 256u : 128u); i += 64) {
@@ -1228,7 +1231,7 @@ uint32_t msm_ksl(const Ctx* c, uint64_t m) {
   return r;
 }
 
-// lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default from 16-entry slices on.
+// lanes in order of slice length (msm_slices_kernel<true> + msm_accumulate_ordered_kernel): the default from 16-entry slices on.
 // Until round 6 from 32-entry slices on (m > 2^17.4).  Same-box A/B at 16-entry slices, three repetitions
 // (profiles/r06b/order17.jsonl): a 2^17-gate proof 6.69 / 6.69 / 6.70 -> 6.57 / 6.52 / 6.50 ms (accumulate 3.57 -> 3.39), a
 // rank of 8 alone at 2^20 gates (2^17-point slices) 6.66 / 6.63 / 6.59 -> 6.60 / 6.53 / 6.59; at 8-entry slices (2^16
@@ -1370,6 +1373,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int p
 #define FINE_END(ph) do { if (fine) prof_end(c, fbase + (ph)); } while (0)
   const bool tail_quad = !c->cfg.tail_serial;
   if (phase & 1) {
+  bt.ordered = (msm_acc_ordered(c, bt.ksl) && !c->cfg.acc_lds) ? 1u : 0u;
   prof_begin(c, 2);
   FINE_BEGIN(0);
   rc = msm_group_sort(c, bt, mmax);
@@ -1383,7 +1387,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int p
   // PLONK_MSM_ACC=lds: the three-waves-per-SIMD variant (table entries prefetched into LDS) — measured EQUAL to the
   // default on the same box (26.6-26.8 vs 26.8-26.9 ms per proof): the kernel is bound by VALU issue, not by occupancy
   const bool acc_lds = c->cfg.acc_lds;
-  // lanes in order of slice length (msm_order_kernel + msm_accumulate_ordered_kernel): the default from 16-entry slices on
+  // lanes in order of slice length (msm_slices_kernel<true> + msm_accumulate_ordered_kernel): the default from 16-entry slices on
   // (r03a same-box A/B at 2^20: accumulate 26.5 -> 25.7 ms per proof, the waves no longer wait for their longest lane;
   // round 6: also at 16-entry slices, msm_acc_ordered); with 4- / 8-entry slices the accumulation is latency-bound and the
   // ordering gains nothing (r02e: +1.1 ms at 2^16 with the kernels of the time; round 6: +-0).  PLONK_MSM_ORDER=1 / 0 forces either.

@@ -587,10 +587,23 @@ __global__ void __launch_bounds__(BIG_T) msm_big_scatter_kernel(MsmBatch bt, con
 // Also lists the HEAVY buckets (more than heavy_thresh slices: skewed digits) with their 256-slice segments —
 // nheavy[2 kb] buckets, nheavy[2 kb + 1] segments — for the segment workers inside msm_bucket_sum (msm.hip).
 static constexpr uint32_t HEAVY_SEG_SLICES = 128;   // = HEAVY_SEG of msm.hip
+// ORDER: also the layout of msm_accumulate_ordered_kernel — lanes in order of slice LENGTH.  In bucket
+// order every wave of msm_accumulate holds a few partial slices (the last slice of each bucket) next to full ones and waits
+// for the full ones: 3 % idle lane-steps at 32-entry slices, 6 % at 64, 45 % at m = 2^16 with 32 (tools/slice_order_sim.py).
+// Ordered, the full slices come first — full_off = exclusive scan of floor(count / ksl) — and then the partial slice of
+// every bucket in order of decreasing length (a counting sort over the ksl - 1 lengths into part_list; part_list[NB] = their
+// number).  The partial sums keep their slots slice_off[b] + q, so nothing after the accumulation changes.
+// tests/msm_wide_model.py::slice_order is the executable statement of this map.
+// Until round 6 a kernel of its own (msm_order_kernel: three passes of dependent reads over the offsets, 51-54 us per
+// commitment group after the 24 us of this one); since the rule orders the lanes from 16-entry slices on, every group of a
+// 2^17 ... 2^18-gate proof and of a rank of 8 at 2^20 paid it.  Here it shares the batch of offset loads.
+template <bool ORDER>
 __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __restrict__ offsets_all,
                                                             uint32_t* __restrict__ slice_off_all, uint32_t ksl, uint32_t heavy_thresh,
-                                                            uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all, int kb0) {
+                                                            uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all, int kb0,
+                                                            uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ part_list_all) {
   __shared__ uint32_t sh[SORT_T];
+  __shared__ uint32_t hist[129];   // ksl <= 128
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
   uint32_t* __restrict__ slice_off = slice_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
   uint32_t* __restrict__ nheavy = nheavy_all + 2 * (blockIdx.x + (uint32_t)kb0);
@@ -603,11 +616,12 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
 #pragma unroll
   for (uint32_t k = 0; k <= PER; ++k) o[k] = offsets[t * PER + k];
   const uint32_t sh_ksl = 31u - (uint32_t)__builtin_clz(ksl);   // ksl is a power of two (msm_ksl)
+  if (ORDER && t < 129) hist[t] = 0;
   uint32_t mine = 0;
 #pragma unroll
   for (uint32_t k = 0; k < PER; ++k) mine += (o[k + 1] - o[k] + ksl - 1) >> sh_ksl;
   uint32_t total;
-  uint32_t run = block_exclusive_scan(mine, sh, &total);
+  uint32_t run = block_exclusive_scan(mine, sh, &total);   // (its barriers also publish the cleared histogram)
 #pragma unroll
   for (uint32_t k = 0; k < PER; ++k) {
     slice_off[t * PER + k] = run;
@@ -623,53 +637,38 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
     }
   }
   if (t == SORT_T - 1) slice_off[MSM_NB] = total;
-}
-
-// ---- optional: lanes in order of slice LENGTH (PLONK_MSM_ORDER=1) ---------------------------
-// In bucket order every wave of msm_accumulate holds a few partial slices (the last slice of each bucket) next to full
-// ones and waits for the full ones: 3 % idle lane-steps at 32-entry slices, 6 % at 64, 45 % at m = 2^16 with 32
-// (tools/slice_order_sim.py).  Here the full slices come first — full_off = exclusive scan of floor(count / ksl) — and then
-// the partial slice of every bucket in order of decreasing length (a counting sort over the ksl - 1 lengths into
-// part_list; part_list[NB] = their number).  The partial sums keep their slots slice_off[b] + q, so nothing after the
-// accumulation changes.  tests/msm_wide_model.py::slice_order is the executable statement of this map.
-__global__ void __launch_bounds__(SORT_T) msm_order_kernel(const uint32_t* __restrict__ offsets_all, uint32_t* __restrict__ full_off_all,
-                                                           uint32_t* __restrict__ part_list_all, uint32_t ksl, int kb0) {
-  __shared__ uint32_t sh[SORT_T];
-  __shared__ uint32_t hist[129];   // ksl <= 128
-  const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
-  uint32_t* __restrict__ full_off = full_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
-  uint32_t* __restrict__ part_list = part_list_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
-  constexpr uint32_t PER = MSM_NB / SORT_T;
-  const uint32_t t = threadIdx.x;
-  if (t < 129) hist[t] = 0;
-  __syncthreads();
-  uint32_t mine = 0;
-  for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
-    mine += c / ksl;
-    const uint32_t r = c % ksl;
-    if (r) atomicAdd(&hist[r], 1u);
+  if constexpr (ORDER) {
+    uint32_t* __restrict__ full_off = full_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
+    uint32_t* __restrict__ part_list = part_list_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
+    uint32_t mine_f = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t c = o[k + 1] - o[k];
+      mine_f += c >> sh_ksl;
+      const uint32_t r = c & (ksl - 1);
+      if (r) atomicAdd(&hist[r], 1u);
+    }
+    uint32_t total_f;
+    uint32_t run_f = block_exclusive_scan(mine_f, sh, &total_f);   // (its barriers also complete the histogram)
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      full_off[t * PER + k] = run_f;
+      run_f += (o[k + 1] - o[k]) >> sh_ksl;
+    }
+    if (t == SORT_T - 1) full_off[MSM_NB] = total_f;
+    if (t == 0) {   // start of every length class, longest first; hist[0] = number of partial slices
+      uint32_t acc = 0;
+      for (uint32_t r = ksl - 1; r >= 1; --r) { const uint32_t h = hist[r]; hist[r] = acc; acc += h; }
+      hist[0] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      const uint32_t r = (o[k + 1] - o[k]) & (ksl - 1);
+      if (r) part_list[atomicAdd(&hist[r], 1u)] = t * PER + k;
+    }
+    if (t == 0) part_list[MSM_NB] = hist[0];
   }
-  uint32_t total;
-  uint32_t run = block_exclusive_scan(mine, sh, &total);   // (its barriers also complete the histogram)
-  for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t c = offsets[t * PER + k + 1] - offsets[t * PER + k];
-    full_off[t * PER + k] = run;
-    run += c / ksl;
-  }
-  if (t == SORT_T - 1) full_off[MSM_NB] = total;
-  if (t == 0) {   // start of every length class, longest first; hist[0] = number of partial slices
-    uint32_t acc = 0;
-    for (uint32_t r = ksl - 1; r >= 1; --r) { const uint32_t h = hist[r]; hist[r] = acc; acc += h; }
-    hist[0] = acc;
-  }
-  __syncthreads();
-  for (uint32_t k = 0; k < PER; ++k) {
-    const uint32_t b = t * PER + k;
-    const uint32_t r = (offsets[b + 1] - offsets[b]) % ksl;
-    if (r) part_list[atomicAdd(&hist[r], 1u)] = b;
-  }
-  if (t == 0) part_list[MSM_NB] = hist[0];
 }
 #if PLONK_MSM_NB_BITS > 15
 // ---- the same two layouts (slice offsets + heavy list, full-slice offsets + partial slices by length) for MANY buckets --
@@ -785,16 +784,8 @@ __global__ void __launch_bounds__(SORT_T) msm_layout_apply_kernel(const uint32_t
 #endif
 
 int msm_order_slices(Ctx* c, const MsmBatch& bt) {
-#if PLONK_MSM_NB_BITS > 15
   (void)c; (void)bt;
-  return PLONK_OK;   // msm_group_sort's layout kernels already wrote full_off / part_list
-#else
-  MsmWork& w = c->msm;
-  if (bt.ksl > 128) return (set_last_error("msm_order_slices", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
-  hipLaunchKernelGGL(msm_order_kernel, dim3(bt.count), dim3(SORT_T), 0, c->stream, w.offsets, w.full_off, w.part_list, bt.ksl, bt.kb0);
-  HIP_TRY(hipGetLastError());
-  return PLONK_OK;
-#endif
+  return PLONK_OK;   // msm_group_sort already wrote full_off / part_list (bt.ordered): the layout kernels (many buckets) or msm_slices_kernel<true>
 }
 
 // Host side: everything between the scalars and msm_accumulate for one commitment group.
@@ -860,8 +851,14 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
   hipLaunchKernelGGL(msm_layout_apply_kernel, dim3(LAY_NBLK, bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, w.full_off, w.part_list,
                      (const uint32_t*)w.layout, bt.ksl, bt.heavy_thresh, w.nheavy, (HeavyItem*)w.heavy_list, (uint4*)w.buckets, w.multi_list, kb0);
 #else
-  hipLaunchKernelGGL(msm_slices_kernel, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
-                     w.nheavy, (HeavyItem*)w.heavy_list, kb0);
+  if (bt.ordered) {
+    if (bt.ksl > 128) return (set_last_error("msm_group_sort", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
+    hipLaunchKernelGGL(msm_slices_kernel<true>, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
+                       w.nheavy, (HeavyItem*)w.heavy_list, kb0, w.full_off, w.part_list);
+  } else {
+    hipLaunchKernelGGL(msm_slices_kernel<false>, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
+                       w.nheavy, (HeavyItem*)w.heavy_list, kb0, (uint32_t*)nullptr, (uint32_t*)nullptr);
+  }
 #endif
   HIP_TRY(hipGetLastError());
   return PLONK_OK;

@@ -100,6 +100,7 @@ struct MsmBatch {   // one commitment group: up to MSM_MAX_BATCH MSMs over the s
   const void* table;   // tables the entries index: the context's commit key, or a prover's Lagrange-basis key
   uint64_t table_n;    // points per row of `table`
   uint32_t rows;       // MSM_ROWS_WINDOW (16), MSM_ROWS_BITPOS (256) or MSM_ROWS_HALFPOS (128): which recoding the entries come from
+  uint32_t ordered;    // lanes of the accumulation in order of slice length: the sort also writes full_off / part_list
   uint32_t wide;       // the coarse-partitioned words are 64-bit (rows * table_n above 2^27)
   uint32_t heavy_thresh;   // a bucket with more slices than this is "heavy" (msm_slices_kernel lists it, msm.hip sums it by segments)
   // scalars of commitment k: scalars[k][i] for i < split[k], tail[k][i - split[k]] above (a wire column in place + its
