@@ -1312,9 +1312,15 @@ __global__ void __launch_bounds__(128) msm_rowcol_tp_kernel(const G1RSlot* __res
   }
   if (s == 0) st_g1r(rc1 + out, sh[t]);        // partial 0 of the thread's own sum: slot t
 }
-// stage 1.5 (quad additions, 64 logical lanes per sum): rc2 = [G_g (256) | C_l (128) | identity (128) | H_r (2^E)]
-__global__ void __launch_bounds__(256) msm_fold_quad_kernel(const G1RSlot* __restrict__ rc1_all, G1RSlot* __restrict__ rc2_all) {
-  __shared__ G1R sh[64];
+// stage 1.5 (quad additions): rc2 = [G_g (256) | C_l (128) | identity (128) | P[sg][r] (16 x 2^E)]
+// One WAVE per sum (16 logical lanes; round 6, second session).  A sum has 16 points (G_g, P[sg][r]) or 32 (C_l); until then
+// a sum was a 256-thread workgroup of 64 logical lanes of which 16 or 32 held a point, running a 6-step tree with two
+// workgroup barriers per step: 2560 four-wave workgroups per group of four commitments at two per CU — five rounds of the
+// chip, 150-250 us per launch at 2^20 gates for ~10 k quad additions.  A wave per sum is a quarter of the waves, a 4-step
+// tree and no workgroup barriers to wait at.
+static constexpr uint32_t FOLD_LL = 16;   // logical lanes (quads) per sum
+__global__ void __launch_bounds__(64) msm_fold_quad_kernel(const G1RSlot* __restrict__ rc1_all, G1RSlot* __restrict__ rc2_all) {
+  __shared__ G1R sh[FOLD_LL];
   const G1RSlot* __restrict__ rc1 = rc1_all + (uint64_t)blockIdx.y * TP_RC1;
   G1RSlot* __restrict__ rc2 = rc2_all + (uint64_t)blockIdx.y * TP_RC2;
   const uint32_t u = blockIdx.x, t = threadIdx.x, q = t & 3, L = t >> 2;
@@ -1326,8 +1332,8 @@ __global__ void __launch_bounds__(256) msm_fold_quad_kernel(const G1RSlot* __res
   }
   else { const uint32_t l0 = u - 256 - TP_NP; npts = TP_PARTS; first = TP_ROWS + l0; stride = 128; dst = RC_ROWS + l0; }   // C_l
   G1R acc = G1R::identity();
-  for (uint32_t i = L; i < npts; i += 64) acc = g1r_add_quad(acc, ld_g1r(rc1 + first + (uint64_t)i * stride), q);
-  for (uint32_t d = 32; d >= 1; d >>= 1) {
+  for (uint32_t i = L; i < npts; i += FOLD_LL) acc = g1r_add_quad(acc, ld_g1r(rc1 + first + (uint64_t)i * stride), q);
+  for (uint32_t d = FOLD_LL / 2; d >= 1; d >>= 1) {
     if (q == 0) sh[L] = acc;
     __syncthreads();
     if (L < d) acc = g1r_add_quad(acc, sh[L + d], q);
@@ -1475,7 +1481,7 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int p
     FINE_BEGIN(4);
     if (lps == 4) TPK(4); else if (lps == 8) TPK(8); else if (lps == 16) TPK(16); else TPK(32);
 #undef TPK
-    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + TP_NP + 128, count_g), dim3(256), 0, st, (const G1RSlot*)rc1, rc2);
+    hipLaunchKernelGGL(msm_fold_quad_kernel, dim3(256 + TP_NP + 128, count_g), dim3(64), 0, st, (const G1RSlot*)rc1, rc2);
     FINE_END(4);
     FINE_BEGIN(5);
     hipLaunchKernelGGL(msm_bits_quad_kernel, dim3(17 + TP_E, count_g), dim3(256), 0, st, bt, (const G1RSlot*)rc2, (uint32_t)TP_RC2, (uint32_t)TP_E);
