@@ -488,7 +488,17 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
  *   polynomials: what stays replicated on every rank of a multi-GPU run).
  *   With PLONK_PROF_FINE=1 in the environment also, per phase of a commitment group (groups of >= 3 commitments: 16 + phase,
  *   smaller groups: 24 + phase): 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums, 5 bit sums.
- *   Slots 0 .. 31 are valid. */
+ *   HOST time of plonk_prover_prove* on a single device (wall clock, no events; `launches` = occurrences): 8 the arithmetic
+ *   that turns the bit sums of a commitment group into compressed commitments, 9 from the return of each of the five
+ *   synchronisations of a proof to the next launch (slot 8 included: the device's main stream is idle for that long),
+ *   10 the time blocked in those synchronisations.
+ *   Slots 0 .. 31 are valid.
+ *
+ * Host threads.  A context starts up to 3 helper threads (none on hosts with fewer than 8 hardware threads) with its first
+ * commitment group of more than one commitment: they take the independent finishing chains of a group (slot 8) beside the
+ * calling thread.  They are woken when the caller blocks in the group's synchronisation and SPIN until the bit sums have
+ * arrived — up to one device phase per group — and sleep otherwise; plonk_ctx_destroy joins them.  PLONK_HOST_THREADS=k in
+ * the environment (read at context creation) sets their number, 0 switches them off. */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_read(plonk_ctx* ctx, int slot, double* total_ms, uint64_t* launches);
 int plonk_profile_reset(plonk_ctx* ctx);
