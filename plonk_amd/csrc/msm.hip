@@ -1369,6 +1369,9 @@ int msm_batch_device_v(Ctx* c, MsmBatch& bt, uint64_t mmax, bool bit_sums, int p
     const uint64_t avg_slices = (MSM_W * mmax) / bt.ksl / MSM_NB;   // per bucket, uniform digits
     // heavy = well above the expected slice count (skewed digits): twice the uniform average, at least 16 slices
     bt.heavy_thresh = (uint32_t)(2 * avg_slices > 16 ? 2 * avg_slices : 16);
+    // (round 6, measured: a threshold of 4 or 8 slices for the many-bucket variant — the listed buckets' chains of up to 15
+    // dependent quad additions are the longest of msm_bucket_sum — moves the dense 2^20 proof by -0.1 ms, bench-like by 0 and
+    // the widget workload by +0.1: not adopted, profiles/r06b/heavy_ab.jsonl)
   }
   // PLONK_PROF_FINE=1: every phase of the group on its own slot (16 + phase for groups of >= 3 commitments, 24 + phase below;
   // phases: 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums (+ fold), 5 bit sums) —
