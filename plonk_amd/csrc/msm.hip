@@ -792,11 +792,16 @@ __device__ __forceinline__ Fp28 quad_get(const Fp28& v) {   // lane K of the qua
 }
 __device__ __forceinline__ Fp28 quad_sel(uint32_t q, const Fp28& a0, const Fp28& a1, const Fp28& a2, const Fp28& a3) {
   // bit masks, not ?: — the compiler turns a four-way conditional over arrays into a pointer select with the
-  // operands parked in scratch memory, which is the last thing a latency-bound chain needs
-  const uint32_t k0 = 0u - (uint32_t)(q == 0), k1 = 0u - (uint32_t)(q == 1), k2 = 0u - (uint32_t)(q == 2), k3 = 0u - (uint32_t)(q == 3);
+  // operands parked in scratch memory, which is the last thing a latency-bound chain needs.  Two levels of (m & x) | (~m & y),
+  // which is ONE v_bfi_b32 each: 3 instructions per limb (round 6, second session; until then four ANDs and two ORs per
+  // limb — 672 of the ~3.3 k instructions of a quad addition were these selects).
+  const bool b0 = (q & 1u) != 0, b1 = (q & 2u) != 0;
   Fp28 r;
 #pragma unroll
-  for (int i = 0; i < Fp28::N; ++i) r.l[i] = (a0.l[i] & k0) | (a1.l[i] & k1) | (a2.l[i] & k2) | (a3.l[i] & k3);
+  for (int i = 0; i < Fp28::N; ++i) {
+    const uint32_t lo = b0 ? a1.l[i] : a0.l[i], hi = b0 ? a3.l[i] : a2.l[i];   // per-limb selects on two lane masks: v_cndmask_b32
+    r.l[i] = b1 ? hi : lo;
+  }
   return r;
 }
 // a + b, both replicated over the quad; q = lane & 3.  Same bounds as G1R::add (Y3 < 4p here: two reductions
