@@ -491,7 +491,7 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
  *   HOST time of plonk_prover_prove* on a single device (wall clock, no events; `launches` = occurrences): 8 the arithmetic
  *   that turns the bit sums of a commitment group into compressed commitments, 9 from the return of each of the five
  *   synchronisations of a proof to the next launch (slot 8 included: the device's main stream is idle for that long),
- *   10 the time blocked in those synchronisations.
+ *   10 the time blocked in those synchronisations; 11 (a count, not a time) the helper threads each commitment group had.
  *   Slots 0 .. 31 are valid.
  *
  * Host threads.  A context starts up to 3 helper threads (none on hosts with fewer than 8 hardware threads) with its first

@@ -233,7 +233,7 @@ struct Ctx {
   // instrumentation: hipEvent pairs around the dominant kernels
   bool profile = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  static constexpr int PROF_SLOTS = 32;   // 0-7: the bench line's slots; 8-10: HOST time of prove() (prover.hip HostGap); 16-21 / 24-29: MSM phases of groups of >= 3 / <= 2 commitments (PLONK_PROF_FINE=1)
+  static constexpr int PROF_SLOTS = 32;   // 0-7: the bench line's slots; 8-10: HOST time of prove() (prover.hip HostGap), 11: helper threads per commitment group (a count); 16-21 / 24-29: MSM phases of groups of >= 3 / <= 2 commitments (PLONK_PROF_FINE=1)
   double acc_ms[PROF_SLOTS] = {0};
   uint64_t acc_n[PROF_SLOTS] = {0};
 };

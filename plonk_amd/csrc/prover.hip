@@ -343,7 +343,9 @@ static int fetch_commitments(Prover* p, int first, int count, uint8_t (*out48)[4
                          hipMemcpyDeviceToHost, c->stream));
   // the Horner chains of the group's commitments are independent: helper threads are woken NOW, while this thread blocks in
   // the synchronisation, and take their share as soon as the bit sums are here (finish_pool.hpp)
-  Armed helpers(count >= 2 ? finish_pool_of(c) : nullptr);
+  FinishPool* const pool = count >= 2 ? finish_pool_of(c) : nullptr;
+  if (tl_gap) prof_host_add(c, 11, pool ? pool->workers() : 0);   // slot 11: helper threads of this group (a count, not a time)
+  Armed helpers(pool);
   // a sharded proof queues collectives on this stream (the quotient's all-to-all precedes the t commitments): never a
   // blocking wait behind one — comm_sync polls and aborts the communicator on time-out (a dead peer must not hang the rest)
   const auto t_before = HostGap::clock::now();

@@ -180,6 +180,32 @@ def test_full_size_closed_form(ctx, logm):
     assert len(plonk_amd.g1_compress(got)) == 48
 
 
+def test_ordered_lanes_from_16_entry_slices_on(ctx):
+    """Round 6: a 2^17-point MSM takes 16-entry slices with the lanes in order of slice length (until then only from
+    32-entry slices on) — the layout msm_slices_kernel<true> now writes itself; the plan says so and the result is the
+    closed form.  Skewed scalars in the same key: full slices, partial slices of every length and heavy buckets together."""
+    if any(k in __import__("os").environ for k in ("PLONK_MSM_ORDER", "PLONK_MSM_KSL", "PLONK_MSM_TABLE", "PLONK_MSM_BUCKETS", "PLONK_MSM_ACC")):
+        pytest.skip("the default plan is what this test pins")
+    import json
+    r = random.Random(1717)
+    n = (1 << 17) + 7
+    tau, g = r.randrange(1, Q), r.randrange(1, Q)
+    buf = _gen_srs_dev(ctx, n, tau, g)
+    ctx.srs_load_dev(buf.ptr, n)
+    buf.free()
+    m = (1 << 17) + 6
+    for sc in ([r.randrange(Q) for _ in range(m)],
+               [r.randrange(Q) if i % 5 else r.randrange(4) for i in range(m)]):       # a fifth of the scalars < 4: heavy low buckets
+        acc, p = 0, 1
+        for s in sc:
+            acc = (acc + s * p) % Q
+            p = p * tau % Q
+        assert ctx.msm(sc) == E.g1_mul(E.G1_GEN, g * acc % Q)
+        plan = ctx.last_msm()
+        assert (plan["bucket_bits"], plan["slice_entries"], plan["ordered_lanes"], plan["accumulate_kernel"]) == \
+            (15, 16, 1, "nb15::msm_accumulate_ordered_kernel"), json.dumps(plan)
+
+
 def test_skewed_scalars_take_the_heavy_bucket_path(ctx):
     """Equal coefficients put every term of a window into ONE bucket (m/32 slices): the
     segmented heavy-bucket kernels must give the same group element; mixed with uniform

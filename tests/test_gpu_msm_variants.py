@@ -41,10 +41,12 @@ VARIANTS = [
 ]
 
 
+# (round 6: + the host helper threads of fetch_commitments off and at their maximum — the same proofs either way)
 PROVER_VARIANTS = [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"},
+                   {"PLONK_HOST_THREADS": "0"}, {"PLONK_HOST_THREADS": "7"},
                    {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},
                    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"}]
-PROVER_SELECT = "deterministic_v3 or random_arithmetic or (proof_bytes_equal_c_oracle and not 16 and not 2p20)"
+PROVER_SELECT = "deterministic_v3 or random_arithmetic or host_time_slots or (proof_bytes_equal_c_oracle and not 16 and not 2p20)"
 # round 6: the phased launches of msm_batch_device (host wire columns committed as they arrive) forced at small sizes, over both
 # bucket-count variants; the child's test_host_wire_schedule_is_the_one_asked_for compares plonk_prover_describe
 SCHEDULE_VARIANTS = [({"PLONK_WIRE_BY_COLUMN": "1"}, 3), ({"PLONK_WIRE_BY_COLUMN": "2"}, 4),

@@ -266,3 +266,42 @@ def test_host_wire_schedule_is_the_one_asked_for(ctx, kat_setup):
     cp.close()
     wbuf.free()
     gp.close()
+
+
+def test_host_time_slots_count_the_five_synchronisations_of_a_proof(ctx, kat_setup):
+    """plonk_profile_read slots 8-10 (round 6): per proof four commitment groups are finished on the host (slot 8), five
+    synchronisations return and are followed by a launch (slot 9), five waits are timed (slot 10); the times are host wall
+    time inside prove() and cannot exceed it."""
+    import time
+    import plonk_amd
+    from tests import circuits as C
+    comp = C.big_widget_circuit(1 << 11, seed=78)()
+    case = C.compile_fast(comp, b"host-slots")
+    srs = C.synthetic_srs(case["size"] + 7)
+    ctx.srs_load_bytes(srs, len(srs) // 96)
+    gp = plonk_amd.Prover(ctx, case["constraints"], case["label"], case["polys"])
+    bl = C.blinders(11)
+    n = case["size"]
+    wbuf = ctx.alloc(4 * 32 * n)
+    for k in range(4):
+        wbuf.upload(case["wires"][k], 32 * n * k)
+    first = gp.prove_dev(wbuf.ptr, case["pi"], bl)
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        assert gp.prove_dev(wbuf.ptr, case["pi"], bl) == first
+    ctx.sync()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    got = {slot: ctx.profile_read(slot) for slot in (8, 9, 10, 11)}
+    ctx.profile(False)
+    assert [got[s][1] for s in (8, 9, 10, 11)] == [12, 15, 15, 12], got
+    # slot 11 sums the helper threads of every group: groups of 4, 1, 4, 2 commitments — the group of one has none.  A
+    # PLONK_HOST_THREADS the library ignored fails here (tests/test_gpu_msm_variants.py runs this file with 0 and 7).
+    import os
+    env = os.environ.get("PLONK_HOST_THREADS")
+    workers = int(env) if env is not None else (3 if (os.cpu_count() or 1) >= 8 else 0)
+    assert got[11][0] == 3 * 3 * workers, (got[11], workers)
+    assert 0 < got[8][0] <= got[9][0] < wall_ms and 0 < got[10][0] < wall_ms, (got, wall_ms)
+    gp.close()
+    wbuf.free()
