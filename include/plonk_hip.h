@@ -494,7 +494,7 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
  *   10 the time blocked in those synchronisations; 11 (a count, not a time) the helper threads each commitment group had.
  *   Slots 0 .. 31 are valid.
  *
- * Host threads.  A context starts up to 3 helper threads (none on hosts with fewer than 8 hardware threads) with its first
+ * Host threads.  A context starts up to 3 helper threads (none when the process may run on fewer than 8 CPUs: sched_getaffinity) with its first
  * commitment group of more than one commitment: they take the independent finishing chains of a group (slot 8) beside the
  * calling thread.  They are woken when the caller blocks in the group's synchronisation and SPIN until the bit sums have
  * arrived — up to one device phase per group — and sleep otherwise; plonk_ctx_destroy joins them.  PLONK_HOST_THREADS=k in

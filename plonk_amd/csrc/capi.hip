@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <sched.h>
 #include <thread>
 
 #include "plonk_internal.hpp"
@@ -214,7 +215,12 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   if (g.table_mode != (int)MSM_ROWS_WINDOW && g.table_mode != (int)MSM_ROWS_HALFPOS && g.table_mode != (int)MSM_ROWS_BITPOS) g.table_mode = 0;
   if (g.ntt_elog != 2 && g.ntt_elog != 3) g.ntt_elog = 0;
   if (g.side_cus < 0) g.side_cus = 0;
-  if (g.host_threads < 0) g.host_threads = std::thread::hardware_concurrency() >= 8 ? 3 : 0;
+  if (g.host_threads < 0) {   // the CPUs this process may run on (taskset / cpuset), not the machine's: helper threads spin
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const int cpus = sched_getaffinity(0, sizeof set, &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    g.host_threads = cpus >= 8 ? 3 : 0;
+  }
   if (g.host_threads > 7) g.host_threads = 7;
   if (g.table_budget == 0) {
     size_t total = 0;   // (takes the device ordinal: the calling thread's current device is left alone)

@@ -8,7 +8,7 @@
 // that precedes the arithmetic, i.e. hundreds of microseconds before the work exists — and then spin on an atomic until
 // the job is posted (or the arming is withdrawn); between commitment groups they sleep.  What it costs: up to `workers`
 // host threads spinning while the device runs a commitment group's tail.  plonk_gpu_config has no field for it;
-// PLONK_HOST_THREADS=0 switches it off, the default is 3 workers on hosts with at least 8 hardware threads, else none.
+// PLONK_HOST_THREADS=0 switches it off, the default is 3 workers when the process may run on at least 8 CPUs (sched_getaffinity), else none.
 // Included by prover.hip and by the CPU test harness (tests/csrc/host_arith.cpp).
 #pragma once
 #include <atomic>

@@ -179,7 +179,7 @@ struct Config {
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
   int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN: 0 -> -1 (host wire columns commit as ONE grouped launch after the last copy, round 5), 1 / 2 -> by column at every size (a, b, c + d / one launch each); unset: by column from 2^19 gates on
   int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
-  int host_threads = -1;            // PLONK_HOST_THREADS=k: helper threads for the host arithmetic between device phases (finish_pool.hpp); -1: 3 on hosts with >= 8 hardware threads, else 0
+  int host_threads = -1;            // PLONK_HOST_THREADS=k: helper threads for the host arithmetic between device phases (finish_pool.hpp); -1: 3 when the process may run on >= 8 CPUs, else 0
 };
 
 struct plonk_msm_plan_internal {   // what msm_batch_device chose (mirrors plonk_msm_plan)

@@ -300,7 +300,7 @@ def test_host_time_slots_count_the_five_synchronisations_of_a_proof(ctx, kat_set
     # PLONK_HOST_THREADS the library ignored fails here (tests/test_gpu_msm_variants.py runs this file with 0 and 7).
     import os
     env = os.environ.get("PLONK_HOST_THREADS")
-    workers = int(env) if env is not None else (3 if (os.cpu_count() or 1) >= 8 else 0)
+    workers = int(env) if env is not None else (3 if len(os.sched_getaffinity(0)) >= 8 else 0)
     assert got[11][0] == 3 * 3 * workers, (got[11], workers)
     assert 0 < got[8][0] <= got[9][0] < wall_ms and 0 < got[10][0] < wall_ms, (got, wall_ms)
     gp.close()
