@@ -597,11 +597,20 @@ static constexpr uint32_t HEAVY_SEG_SLICES = 128;   // = HEAVY_SEG of msm.hip
 // Until round 6 a kernel of its own (msm_order_kernel: three passes of dependent reads over the offsets, 51-54 us per
 // commitment group after the 24 us of this one); since the rule orders the lanes from 16-entry slices on, every group of a
 // 2^17 ... 2^18-gate proof and of a rank of 8 at 2^20 paid it.  Here it shares the batch of offset loads.
+// Memory access (round 6, second session): a thread owns PER = NB / 1024 CONSECUTIVE buckets — the scan needs that — so its
+// direct loads and stores had a stride of PER words between lanes: every one of the ~130 load / store instructions of a wave
+// touched 64 different cache lines (24 us per commitment group for the unordered layout, 38 with the ordering).  The offsets
+// are now loaded and the results stored COALESCED through a padded LDS staging array (word i at i + i / 32: the threads'
+// strided LDS accesses are conflict-free).
+static constexpr uint32_t SLICES_STAGE_WORDS = MSM_NB + MSM_NB / 32 + 2;
+static constexpr size_t SLICES_LDS = sizeof(uint32_t) * SLICES_STAGE_WORDS;
+__device__ __forceinline__ uint32_t stage_at(uint32_t i) { return i + (i >> 5); }
 template <bool ORDER>
 __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __restrict__ offsets_all,
                                                             uint32_t* __restrict__ slice_off_all, uint32_t ksl, uint32_t heavy_thresh,
                                                             uint32_t* __restrict__ nheavy_all, HeavyItem* __restrict__ heavy_list_all, int kb0,
                                                             uint32_t* __restrict__ full_off_all, uint32_t* __restrict__ part_list_all) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t stage[];   // SLICES_STAGE_WORDS
   __shared__ uint32_t sh[SORT_T];
   __shared__ uint32_t hist[129];   // ksl <= 128
   const uint32_t* __restrict__ offsets = offsets_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
@@ -610,21 +619,21 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
   HeavyItem* __restrict__ heavy_list = heavy_list_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * MSM_NB;
   constexpr uint32_t PER = MSM_NB / SORT_T;
   const uint32_t t = threadIdx.x;
-  // the thread's PER + 1 bucket offsets in ONE batch of independent loads (r04: the two loops of dependent reads this
-  // replaces made the kernel 50 us of pure load latency — a third of the whole bucket sort of a 2^16-term group)
+  for (uint32_t i = t; i <= MSM_NB; i += SORT_T) stage[stage_at(i)] = offsets[i];
+  if (ORDER && t < 129) hist[t] = 0;
+  __syncthreads();
   uint32_t o[PER + 1];
 #pragma unroll
-  for (uint32_t k = 0; k <= PER; ++k) o[k] = offsets[t * PER + k];
+  for (uint32_t k = 0; k <= PER; ++k) o[k] = stage[stage_at(t * PER + k)];
   const uint32_t sh_ksl = 31u - (uint32_t)__builtin_clz(ksl);   // ksl is a power of two (msm_ksl)
-  if (ORDER && t < 129) hist[t] = 0;
   uint32_t mine = 0;
 #pragma unroll
   for (uint32_t k = 0; k < PER; ++k) mine += (o[k + 1] - o[k] + ksl - 1) >> sh_ksl;
   uint32_t total;
-  uint32_t run = block_exclusive_scan(mine, sh, &total);   // (its barriers also publish the cleared histogram)
+  uint32_t run = block_exclusive_scan(mine, sh, &total);   // (its barriers: every thread has read its offsets from the staging array)
 #pragma unroll
   for (uint32_t k = 0; k < PER; ++k) {
-    slice_off[t * PER + k] = run;
+    stage[stage_at(t * PER + k)] = run;
     const uint32_t ns = (o[k + 1] - o[k] + ksl - 1) >> sh_ksl;
     run += ns;
     if (ns > heavy_thresh) {
@@ -636,6 +645,8 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
       heavy_list[atomicAdd(&nheavy[0], 1u)] = it;
     }
   }
+  __syncthreads();
+  for (uint32_t i = t; i < MSM_NB; i += SORT_T) slice_off[i] = stage[stage_at(i)];
   if (t == SORT_T - 1) slice_off[MSM_NB] = total;
   if constexpr (ORDER) {
     uint32_t* __restrict__ full_off = full_off_all + (uint64_t)(blockIdx.x + (uint32_t)kb0) * (MSM_NB + 1);
@@ -649,19 +660,20 @@ __global__ void __launch_bounds__(SORT_T) msm_slices_kernel(const uint32_t* __re
       if (r) atomicAdd(&hist[r], 1u);
     }
     uint32_t total_f;
-    uint32_t run_f = block_exclusive_scan(mine_f, sh, &total_f);   // (its barriers also complete the histogram)
+    uint32_t run_f = block_exclusive_scan(mine_f, sh, &total_f);   // (its barriers also complete the histogram and the copy-out above)
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
-      full_off[t * PER + k] = run_f;
+      stage[stage_at(t * PER + k)] = run_f;
       run_f += (o[k + 1] - o[k]) >> sh_ksl;
     }
-    if (t == SORT_T - 1) full_off[MSM_NB] = total_f;
     if (t == 0) {   // start of every length class, longest first; hist[0] = number of partial slices
       uint32_t acc = 0;
       for (uint32_t r = ksl - 1; r >= 1; --r) { const uint32_t h = hist[r]; hist[r] = acc; acc += h; }
       hist[0] = acc;
     }
     __syncthreads();
+    for (uint32_t i = t; i < MSM_NB; i += SORT_T) full_off[i] = stage[stage_at(i)];
+    if (t == SORT_T - 1) full_off[MSM_NB] = total_f;
 #pragma unroll
     for (uint32_t k = 0; k < PER; ++k) {
       const uint32_t r = (o[k + 1] - o[k]) & (ksl - 1);
@@ -853,10 +865,12 @@ static int msm_group_sort_t(Ctx* c, const MsmBatch& bt, uint64_t mmax) {
 #else
   if (bt.ordered) {
     if (bt.ksl > 128) return (set_last_error("msm_group_sort", "slice length above 128", __FILE__, __LINE__), PLONK_ERR_ARG);
-    hipLaunchKernelGGL(msm_slices_kernel<true>, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
+    smem_opt_in(c, (const void*)msm_slices_kernel<true>, SLICES_LDS);
+    hipLaunchKernelGGL(msm_slices_kernel<true>, dim3(bt.count), dim3(SORT_T), SLICES_LDS, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
                        w.nheavy, (HeavyItem*)w.heavy_list, kb0, w.full_off, w.part_list);
   } else {
-    hipLaunchKernelGGL(msm_slices_kernel<false>, dim3(bt.count), dim3(SORT_T), 0, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
+    smem_opt_in(c, (const void*)msm_slices_kernel<false>, SLICES_LDS);
+    hipLaunchKernelGGL(msm_slices_kernel<false>, dim3(bt.count), dim3(SORT_T), SLICES_LDS, st, w.offsets, w.slice_off, bt.ksl, bt.heavy_thresh,
                        w.nheavy, (HeavyItem*)w.heavy_list, kb0, (uint32_t*)nullptr, (uint32_t*)nullptr);
   }
 #endif
