@@ -30,8 +30,16 @@ namespace plonk {
 class FinishPool {
  public:
   typedef void (*TaskFn)(void* arg, int index);
-  explicit FinishPool(int workers) : nth_(workers < 0 ? 0 : (workers > MAXW ? MAXW : workers)) {
-    for (int i = 0; i < nth_; ++i) th_[i] = std::thread([this] { worker(); });
+  explicit FinishPool(int workers) : nth_(0) {
+    const int want = workers < 0 ? 0 : (workers > MAXW ? MAXW : workers);
+    for (int i = 0; i < want; ++i) {
+      try {
+        th_[i] = std::thread([this] { worker(); });
+      } catch (...) {   // the process is out of threads: work with the ones that started (none: everything runs on the caller)
+        break;
+      }
+      nth_ = i + 1;
+    }
   }
   ~FinishPool() {
     {
