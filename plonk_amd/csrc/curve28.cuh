@@ -96,6 +96,29 @@ struct G1R {
     return r;
   }
 
+  // (x1, y1) + (x2, y2), BOTH affine and neither the identity: the first addition of every accumulation lane.  With
+  // ZZ = ZZZ = 1 on the left, four of add_affine's ten products are multiplications by one (U2 = x2, S2 = y2, ZZ3 = PP,
+  // ZZZ3 = PPP): 4 products + 2 squarings, 5 Montgomery reductions.  x1, x2 < 2p normalised; y1, y2 < 4p, possibly lazy
+  // (the sign of a table entry is applied as 4p - y without carry propagation).  `pair_distinct` must hold — equal or
+  // opposite points (x1 = x2) take the general path, which doubles or cancels.  Out: X<14p Y<2p ZZ,ZZZ<2p, as add_affine.
+  HD static bool pair_distinct(const Fp28& x1, const Fp28& x2) { return !maybe_zero(Fp28::sub_lazy<4>(x2, x1)); }   // (no false "distinct": exact zero always passes maybe_zero)
+  HD static G1R add_affine_pair(const Fp28& x1, const Fp28& y1, const Fp28& x2, const Fp28& y2) {
+    const Fp28 P_ = Fp28::sub_lazy<4>(x2, x1);                // < 6p, lazy limbs
+    const Fp28 y1n = y1.normalized();                         // < 4p
+    const Fp28 R_ = Fp28::sub<8>(y2, y1n);                    // 4p - (<4p) + 8p   -> < 12p, normalised
+    const Fp28 PP = P_.sqr();                                 // 6*6               -> < 2p
+    const Fp28 PPP = Fp28::mul(P_, PP);                       // 6*2               -> < 2p
+    const Fp28 Q_ = Fp28::mul(x1, PP);                        // 2*2               -> < 2p
+    G1R r;
+    r.X = Fp28::sub<8>(Fp28::sub_lazy<4>(R_.sqr(), PPP),      // 12*12 = 144; 2p + 4p
+                       Fp28::add_lazy(Q_, Q_));               // - (<4p) + 8p      -> < 14p
+    r.Y = Fp28::mul2(R_, Fp28::sub_lazy<32>(Q_, r.X),         // 12 * (2+32=34) = 408
+                     PPP, Fp28::neg_lazy<8>(y1n));            // + 2 * 8 = 424     -> < 2p
+    r.ZZ = PP;
+    r.ZZZ = PPP;
+    return r;
+  }
+
   // full addition (same bounds in and out)
   HD G1R add(const G1R& b) const {
     if (is_identity()) return b;

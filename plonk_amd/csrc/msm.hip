@@ -221,6 +221,33 @@ namespace PLONK_MSM_NS {   // ---- per bucket count: accumulation, bucket sums, 
 // ---------------------------------------------------------------------------
 // accumulation
 // ---------------------------------------------------------------------------
+// The first TWO entries of a lane are both affine table points: their sum takes 4 products + 2 squarings with 5 reductions
+// (G1R::add_affine_pair) instead of the copy + the general mixed addition's 8 + 2 with 9 — four of those products were
+// multiplications by ZZ = ZZZ = 1 (round 6, second session).  One addition in ~23 per lane at 2^20 gates, one in 8 at 2^16.
+// The macro consumes entries k0 and k0 + 1, leaves the NEXT entry prefetched in (ent, x, y) as the loop expects and advances
+// k0; a lane with one entry, or whose first two points share their x (equal or opposite: the general path doubles or
+// cancels), is left untouched.
+#define ACC_FIRST_PAIR(acc, ent, x, y, k0, end)                                                                   \
+  do {                                                                                                            \
+    if ((k0) + 1 < (end)) {                                                                                       \
+      const uint32_t ent_b_ = entries[(k0) + 1];                                                                  \
+      const Fp28 xb_ = ld_f28(&table[ent_b_ & 0x7fffffffu].x);                                                    \
+      const Fp28 yb_ = ld_f28(&table[ent_b_ & 0x7fffffffu].y);                                                    \
+      if (G1R::pair_distinct((x), xb_)) {                                                                         \
+        const uint32_t ent_a_ = (ent);                                                                            \
+        const Fp28 xa_ = (x), ya_ = (y);                                                                          \
+        if ((k0) + 2 < (end)) {                                                                                   \
+          (ent) = entries[(k0) + 2];                                                                              \
+          (x) = ld_f28(&table[(ent) & 0x7fffffffu].x);                                                            \
+          (y) = ld_f28(&table[(ent) & 0x7fffffffu].y);                                                            \
+        }                                                                                                         \
+        (acc) = G1R::add_affine_pair(xa_, acc_signed_y(ya_, (ent_a_ & 0x80000000u) != 0), xb_,                    \
+                                     acc_signed_y(yb_, (ent_b_ & 0x80000000u) != 0));                             \
+        (k0) += 2;                                                                                                \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+__device__ __forceinline__ Fp28 acc_signed_y(const Fp28& y, bool neg);
 __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __restrict__ table, MsmBatch bt,
                                                              const uint32_t* __restrict__ entries_all,
                                                              const uint32_t* __restrict__ offsets_all,
@@ -263,7 +290,9 @@ __global__ void __launch_bounds__(128) msm_accumulate_kernel(const G1AffineR* __
   uint32_t ent = entries[beg];
   Fp28 x = ld_f28(&table[ent & 0x7fffffffu].x);
   Fp28 y = ld_f28(&table[ent & 0x7fffffffu].y);
-  for (uint32_t k = beg; k < end; ++k) {
+  uint32_t k0 = beg;
+  ACC_FIRST_PAIR(acc, ent, x, y, k0, end);
+  for (uint32_t k = k0; k < end; ++k) {
     const uint32_t ent_c = ent;
     const Fp28 xc = x, yc = y;
     if (k + 1 < end) {
@@ -352,7 +381,9 @@ __global__ void __launch_bounds__(128) msm_accumulate_ordered_kernel(const G1Aff
   uint32_t ent = entries[beg];
   Fp28 x = ld_f28(&table[ent & 0x7fffffffu].x);
   Fp28 y = ld_f28(&table[ent & 0x7fffffffu].y);
-  for (uint32_t k = beg; k < end; ++k) {
+  uint32_t k0 = beg;
+  ACC_FIRST_PAIR(acc, ent, x, y, k0, end);
+  for (uint32_t k = k0; k < end; ++k) {
     const uint32_t ent_c = ent;
     const Fp28 xc = x, yc = y;
     if (k + 1 < end) {

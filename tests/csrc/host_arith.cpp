@@ -89,6 +89,33 @@ int h_g1r_tree(const uint8_t* pts, int n, uint32_t k, uint8_t* o) {
   s = s.add(s);            // doubling through add()
   return out_aff_r(s.mul_u32(k), o);
 }
+// The accumulation lanes' first step (msm.hip ACC_FIRST_PAIR): entries 0 and 1 through add_affine_pair when their x differ
+// (signs applied lazily as 4p - y, as the kernels do), then the rest through add_affine.  Returns like h_g1r_accumulate;
+// *used_pair = 1 when the pair formula ran.
+int h_g1r_accumulate_pair_first(const uint8_t* pts, const uint8_t* neg, int n, uint8_t* o, int* used_pair) {
+  auto signed_y = [](const Fp28& y, bool ng) {
+    Fp28 r;
+    for (int i = 0; i < Fp28::N; ++i) r.l[i] = ng ? Fp28::pad<4>(i) - y.l[i] : y.l[i];
+    return r;
+  };
+  G1R acc = G1R::identity();
+  int k0 = 0;
+  *used_pair = 0;
+  if (n >= 2) {
+    G1Affine a, b; memcpy(&a, pts, 96); memcpy(&b, pts + 96, 96);
+    const Fp28 xa = Fp28::from_fp(a.x), ya = Fp28::from_fp(a.y), xb = Fp28::from_fp(b.x), yb = Fp28::from_fp(b.y);
+    if (G1R::pair_distinct(xa, xb)) {
+      acc = G1R::add_affine_pair(xa, signed_y(ya, neg[0] != 0), xb, signed_y(yb, neg[1] != 0));
+      k0 = 2;
+      *used_pair = 1;
+    }
+  }
+  for (int i = k0; i < n; ++i) {
+    G1Affine a; memcpy(&a, pts + 96 * i, 96);
+    acc = acc.add_affine(Fp28::from_fp(a.x), signed_y(Fp28::from_fp(a.y), neg[i] != 0));
+  }
+  return out_aff_r(acc, o);
+}
 int h_g1r_affine_roundtrip(const uint8_t* pt, uint8_t* o) {
   G1Affine p; memcpy(&p, pt, 96);
   G1R q = G1R::from_affine(Fp28::from_fp(p.x), Fp28::from_fp(p.y)).dbl().dbl();

@@ -564,3 +564,35 @@ def test_host_helper_threads_run_every_task_exactly_once(lib, workers):
     """finish_pool.hpp: jobs of 0..16 tasks under every arming pattern of fetch_commitments (armed and run, armed and
     withdrawn, not armed, workers already spinning): each task runs once, run() returns after the last."""
     assert lib.h_finish_pool_selftest(workers, 3000) == 0
+
+
+def test_first_two_entries_of_a_lane_through_the_affine_pair_formula(lib):
+    """curve28.cuh add_affine_pair (msm.hip ACC_FIRST_PAIR): the sum of two affine table points with 4 products + 2 squarings,
+    every sign combination (signs applied lazily as 4p - y), followed by a chain of mixed additions (the output bounds must
+    be add_affine's input bounds); equal and opposite first points fall back to the general path."""
+    rnd = random.Random(6201)
+    G = E.G1_GEN
+    pts = [E.g1_mul(G, rnd.randrange(1, Q)) for _ in range(24)]
+    out = (ctypes.c_uint8 * 96)()
+    used = ctypes.c_int(0)
+    for trial in range(40):
+        n = [2, 2, 2, 2, 3, 8, 24][trial % 7]
+        sel = [pts[rnd.randrange(len(pts))] for _ in range(n)]
+        if trial % 7 == 0:
+            sel[1] = pts[(pts.index(sel[0]) + 1) % len(pts)]
+        neg = bytes([(trial >> 0) & 1, (trial >> 1) & 1] + [rnd.randrange(2) for _ in range(n - 2)])
+        raw = b"".join(E.g1_to_raw96(p) for p in sel)
+        ok = lib.h_g1r_accumulate_pair_first(raw, neg, n, out, ctypes.byref(used))
+        exp = None
+        for p, s in zip(sel, neg):
+            exp = E.g1_add(exp, (p[0], (E.P - p[1]) % E.P) if s else p)
+        assert (ok == 1) == (exp is not None), trial
+        if exp is not None:
+            assert E.g1_from_raw96(bytes(out)) == exp, trial
+        assert used.value == (1 if sel[0][0] != sel[1][0] else 0), trial
+    # equal first points (doubling) and opposite ones (cancellation) never take the pair formula
+    rep = E.g1_to_raw96(pts[0]) * 5
+    assert lib.h_g1r_accumulate_pair_first(rep, bytes(5), 5, out, ctypes.byref(used)) == 1 and used.value == 0
+    assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[0], 5)
+    assert lib.h_g1r_accumulate_pair_first(rep, bytes([0, 1, 0, 0, 0]), 5, out, ctypes.byref(used)) == 1 and used.value == 0
+    assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[0], 3)
