@@ -186,6 +186,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   if (env_chr("PLONK_QUOTIENT_DOMAIN") == '8') g.quotient_domain = 8;
   if (env_chr("PLONK_QUOTIENT_DOMAIN") == '4') g.quotient_domain = 4;
   if (env_chr("PLONK_WIRE_COMMIT") == 'c') g.wire_commit_coeff = 1;
+  if (env_chr("PLONK_Z_COMMIT") == 'c') g.z_commit_coeff = 1;
   if (const char v = env_chr("PLONK_SHARD_QUOTIENT")) g.shard_quotient = v == '0' ? -1 : 1;
   if (const char v = env_chr("PLONK_SHARD_Z")) g.shard_z = v == '1' ? 1 : -1;
   if (const char v = env_chr("PLONK_SHARD_SIDE")) g.shard_side = v == '0' ? -1 : 1;

@@ -1170,6 +1170,32 @@ __global__ void __launch_bounds__(64) ecfft_finish_kernel(const G1RSlot* __restr
   st_aff(out + i, a);
 }
 
+// out[j] = [tau^(n + k0 + j)] G - [tau^(k0 + j)] G for j < cnt: the points the blinding terms b_k X^k (X^n - 1) of a blinded
+// polynomial commit over (k = 0, 1 for the wires — part of the Lagrange-basis key — and k = 2 for z, prover.hip)
+__global__ void lagrange_blind_points_kernel(const G1AffineR* __restrict__ row0, uint64_t n, uint32_t k0, uint32_t cnt, G1Affine* __restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  const uint64_t k = k0 + j;
+  const G1R p = G1R::from_affine(ld_f28(&row0[n + k].x), ld_f28(&row0[n + k].y))
+                    .add(g1r_neg(G1R::from_affine(ld_f28(&row0[k].x), ld_f28(&row0[k].y))));
+  G1Affine a;
+  if (p.is_identity()) {
+    for (int i = 0; i < 12; ++i) { a.x.l[i] = 0; a.y.l[i] = 0; }
+  } else {
+    Fp28 x, y;
+    g1r_to_affine(p, &x, &y);
+    a.x = x.to_fp();
+    a.y = y.to_fp();
+  }
+  st_aff(out + j, a);
+}
+int lagrange_blind_points_device(Ctx* c, uint64_t n, uint32_t k0, uint32_t cnt, G1Affine* out_dev) {
+  if (!c->srs_table || c->srs_n < n + k0 + cnt) return (plonk::set_last_error("invalid argument", "blinding points need size + k commit-key points", __FILE__, __LINE__), PLONK_ERR_DEGREE);
+  hipLaunchKernelGGL(lagrange_blind_points_kernel, dim3(1), dim3(64), 0, c->stream, (const G1AffineR*)c->srs_table, n, k0, cnt, out_dev);
+  HIP_TRY(hipGetLastError());
+  return PLONK_OK;
+}
+
 int lagrange_points_device(Ctx* c, uint32_t L, G1Affine* out_dev) {
   const uint64_t n = 1ull << L;
   if (!c->srs_table || c->srs_n < n + 2) return (plonk::set_last_error("invalid argument", "Lagrange key needs size + 2 commit-key points", __FILE__, __LINE__), PLONK_ERR_DEGREE);

@@ -156,6 +156,7 @@ struct Config {
   int bucket_bits = 0;              // 0 by the number of terms, 15, 17 (A/B build), 19
   int quotient_domain = 4;          // 4 or 8
   int wire_commit_coeff = 0;        // 1: coefficient-form wire commitments
+  int z_commit_coeff = 0;           // PLONK_Z_COMMIT=coeff (A/B): commit to z in coefficient form although the Lagrange table could take its evaluations
   int shard_quotient = 0;           // 0 default, 1 on, -1 off
   int shard_z = 0;
   int shard_side = 0;
@@ -318,6 +319,7 @@ void srs_table_release(Ctx* c, void* table, uint32_t rows, uint64_t n);   // fre
 // [L_i(tau)] G for the size-n domain (n = 2^L) from the context's commit key (needs n + 2 points), followed by the
 // two blinding points [tau^n] G - G and [tau^(n+1)] G - [tau] G: n + 2 affine points (an EC inverse FFT)
 int lagrange_points_device(Ctx* c, uint32_t L, G1Affine* out_dev);
+int lagrange_blind_points_device(Ctx* c, uint64_t n, uint32_t k0, uint32_t cnt, G1Affine* out_dev);   // [tau^(n+k)] G - [tau^k] G, k = k0 .. k0 + cnt - 1
 int xyzz_to_affine97_device(Ctx* c, const G1* in_dev, uint8_t* out97_dev);
 // host-side affine normalisation of an XYZZ result: out = x || y || infinity flag
 void xyzz_to_affine97_host(const G1& p, uint8_t out[97]);

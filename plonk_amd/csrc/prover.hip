@@ -108,8 +108,10 @@ struct Prover {
   uint64_t lag_n = 0;              // points in lag_table
   uint32_t lag_rows = 0;           // its rows: 256 (a row per bit position) or 16 (window rows)
   bool lag_on = false;             // wire commitments over the Lagrange key (lag_n may be 0 for a rank without a slice)
+  bool lag_z = false;              // single GPU: the table holds a third blinding point ([tau^(n+2)] G - [tau^2] G): z is committed from its evaluations too
+  hipEvent_t ev_zlow = nullptr;    // z's lowest coefficients have reached low_host (they come from the side stream when lag_z)
   bool lag_whole = false;          // sharded prover holding the WHOLE Lagrange key: the wire group is split by commitment, not by point range
-  Fr* wscal = nullptr;             // [8] the wire blinders on the device (tail scalars of the four Lagrange-key MSMs)
+  Fr* wscal = nullptr;             // [11] the wire blinders (8) and z's (3) on the device: tail scalars of the Lagrange-key MSMs
   Fr* agg2 = nullptr;              // [np] second linear combination (W_zw numerator)
   Fr* scratch2 = nullptr;          // [np + 1]
   plonk_allgather_fn allgather = nullptr;
@@ -385,6 +387,7 @@ static void prover_free(Prover* p) {
   if (p->ev_side) (void)hipEventDestroy(p->ev_side);
   if (p->ev_acc) (void)hipEventDestroy(p->ev_acc);
   if (p->ev_pi) (void)hipEventDestroy(p->ev_pi);
+  if (p->ev_zlow) (void)hipEventDestroy(p->ev_zlow);
   for (int k = 0; k < 4; ++k) if (p->ev_wire[k]) (void)hipEventDestroy(p->ev_wire[k]);
   if (p->low_host) (void)hipHostFree(p->low_host);
   if (p->res_host) (void)hipHostFree(p->res_host);
@@ -566,6 +569,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
   HIP_TRY(hipEventCreateWithFlags(&p->ev_side, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_acc, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_pi, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_zlow, hipEventDisableTiming));
   for (int k = 0; k < 4; ++k) HIP_TRY(hipEventCreateWithFlags(&p->ev_wire[k], hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&p->low_host, 42 * sizeof(Fr), hipHostMallocDefault));
   HIP_TRY(hipHostMalloc((void**)&p->res_host, 16 * RES_STRIDE, hipHostMallocDefault));
@@ -679,18 +683,26 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
     if (p->world == 1 && !c->cfg.wire_commit_coeff && c->srs_n >= n + 2 && n >= 2) {
       if (d->lagrange_xy96 && d->lagrange_count != n + 2)
         return (plonk::set_last_error("invalid argument", "lagrange_count is not size + 2", __FILE__, __LINE__), PLONK_ERR_ARG);
+      // Round 6, second session: a THIRD blinding point, [tau^(n+2)] G - [tau^2] G, behind the n + 2 points of the key — z
+      // is blinded with b0 + b1 X + b2 X^2, so with it the commitment of z is an MSM of its EVALUATIONS as well (round 2 of
+      // prove()), and z's inverse transform leaves the critical path.  The point comes from the context's commit key either
+      // way (plonk_lagrange_key and lagrange_xy96 stay at n + 2 points); a key too short for it keeps the coefficient form.
+      const bool third = c->srs_n >= n + 3 && !c->cfg.z_commit_coeff;
+      const uint64_t lag_cnt = n + 2 + (third ? 1 : 0);
       G1Affine* lag_pts = nullptr;
-      HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * (n + 2)));
+      HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * lag_cnt));
       int rc = PLONK_OK;
       if (d->lagrange_xy96) {   // a key the caller kept from an earlier plonk_lagrange_key: skips the group FFT
         if (hipMemcpyAsync(lag_pts, d->lagrange_xy96, sizeof(G1Affine) * (n + 2), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
       } else {
         rc = lagrange_points_device(c, L, lag_pts);
       }
+      if (rc == PLONK_OK && third) rc = lagrange_blind_points_device(c, n, 2, 1, lag_pts + (n + 2));
       if (rc == PLONK_OK && d->lagrange_xy96) rc = srs_validate_device(c, lag_pts, n + 2, p->flag_dev);   // on the curve, in the subgroup
-      if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, n + 2, &p->lag_table, &p->lag_rows);
-      p->lag_n = n + 2;
+      if (rc == PLONK_OK) rc = srs_table_build(c, lag_pts, lag_cnt, &p->lag_table, &p->lag_rows);
+      p->lag_n = lag_cnt;
       p->lag_on = true;
+      p->lag_z = third;
       if (rc == PLONK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = PLONK_ERR_HIP;
       (void)hipFree(lag_pts);
       if (rc) return rc;
@@ -700,7 +712,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
         if (bad) return (plonk::set_last_error("lagrange_xy96", "point off the curve or outside the prime-order subgroup", __FILE__, __LINE__), PLONK_ERR_POINT);
         PTRY(check_lagrange_key(p, L));
       }
-      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
+      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 11));
     } else if (p->world > 1 && !c->cfg.wire_commit_coeff && d->lagrange_xy96) {
       // multi-GPU: the rank's slice [shard_lo, shard_lo + count) of the (n + 2)-point Lagrange key, computed where the whole
       // commit key was available (plonk_lagrange_key)
@@ -733,7 +745,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
       }
       p->lag_n = want;
       p->lag_on = true;
-      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 8));
+      HIP_TRY(hipMalloc((void**)&p->wscal, sizeof(Fr) * 11));
     }
     if (p->world > 1) {
       // every rank derives its mode from ITS OWN descriptor — no key (coefficient-form wire commitments), its slice,
@@ -921,6 +933,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const int side_defer_env = c->cfg.side_defer;
   const bool side_defer = side_defer_env >= 0 ? side_defer_env >= 1 : L <= 18;          // round 1: a, b, c, d (+ PI)
   const bool side_defer_z = side_defer_env >= 0 ? side_defer_env == 1 : L <= 18;         // round 2: z ("2" = round 1 only)
+  const bool z_from_evals = lag && p->lag_z && L <= 18;                                   // z committed from its evaluations (round 2)
   auto side_round1 = [&]() -> int {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
     // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments; with the
@@ -1011,15 +1024,61 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(poly_batch_inverse(c, pa.den, n, true));
     PTRY(poly_mul_arrays(c, pa.num, pa.den, n, p->flag_dev));
     PTRY(scan_prefix_product(c, pa.num, n, p->totals));
-    PTRY(ntt_device(c, pa.num, p->zpoly, p->tmp8, L, true, false, n));
+    if (!z_from_evals) {
+      PTRY(ntt_device(c, pa.num, p->zpoly, p->tmp8, L, true, false, n));
+      BlindArgs ba;
+      ba.count = 3;
+      ba.b[0] = bl[8]; ba.b[1] = bl[9]; ba.b[2] = bl[10];
+      PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
+      PTRY(poly_blind(c, p->zpoly, n, ba));
+    }
+    prof_end(c, 4);
+  }
+  // z(X) in coefficient form (needed from round 3 on), its lowest coefficients and its coset transform, on the CURRENT stream
+  auto z_polynomial = [&](Fr* ntt_tmp) -> int {
+    PTRY(ntt_device(c, p->scratch, p->zpoly, ntt_tmp, L, true, false, n));
     BlindArgs ba;
     ba.count = 3;
     ba.b[0] = bl[8]; ba.b[1] = bl[9]; ba.b[2] = bl[10];
     PTRY(poly_fill_zero(c, p->zpoly + n, np - n));
     PTRY(poly_blind(c, p->zpoly, n, ba));
-    prof_end(c, 4);
-  }
+    return PLONK_OK;
+  };
+  if (z_from_evals) {
+    // Round 6, second session: z(X) = sum_i z_i L_i(X) + (b0 + b1 X + b2 X^2)(X^n - 1), so — like the wires — its commitment is
+    // an MSM of the n EVALUATIONS the scan just wrote and the three blinders over the Lagrange-basis key and its blinding
+    // points: the inverse transform, the blinding and the copy of the low coefficients leave the critical path (the side
+    // stream runs them before z's coset transform; `scratch` keeps the evaluations until round 5 reuses it).  Up to 2^18 gates
+    // only: same-box A/B 2^12 2.04 -> 2.01 ms, 2^16 4.09 -> 4.03, 2^17 5.88 -> 5.86; at 2^20 the transform that left the main
+    // stream competes with the commitment's sort on the side stream instead and nothing is gained (32.2 against 32.3), so
+    // large circuits keep the coefficient form (profiles/r06b/zcommit_ab.jsonl).
+    HIP_TRY(hipMemcpyAsync(p->wscal + 8, bl + 8, 3 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+    if (!side_defer_z) {
+      SideScope side(c, p->ev_ready);
+      PTRY(z_polynomial(p->tmp8b));
+      HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipEventRecord(p->ev_zlow, c->stream));
+      PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
+      HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+    }
+    {
+      AccMark mark(c, side_defer_z ? p->ev_acc : nullptr);
+      const Fr* sc[1] = {p->scratch};
+      const Fr* tl[1] = {p->wscal + 8};
+      const uint64_t ms[1] = {n + 3}, sp[1] = {n};
+      PTRY(msm_group(p, sc, ms, 1, 4, p->lag_table, p->lag_n, tl, sp));
+    }
+    if (side_defer_z) {
+      SideScopeAfter side(c, p->ev_acc);
+      PTRY(z_polynomial(p->tmp8b));
+      HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipEventRecord(p->ev_zlow, c->stream));
+      PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
+      HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+    }
+  } else {
   HIP_TRY(hipMemcpyAsync(p->low_host + 28, p->zpoly, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(p->ev_zlow, c->stream));
   if (!side_defer_z) {
     SideScope side(c, p->ev_ready);   // z's coset FFT only needs z(X): overlap with its commitment
     PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
@@ -1033,6 +1092,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     SideScopeAfter side(c, p->ev_acc);
     PTRY(ntt_device(c, p->zpoly, p->cos, p->tmp8b, L + p->lq, false, true, n + 3));
     HIP_TRY(hipEventRecord(p->ev_side, c->side_stream));
+  }
   }
   PTRY(fetch_commitments(p, 4, 1, comm + 4));
   tr.append_commitment("z_comm", comm[4]);
@@ -1076,7 +1136,8 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     PTRY(ntt_device(c, p->tbuf, p->tbuf, p->tmp8, L + p->lq, true, true, n8));
   }
   if (p->qf == 4) {   // de-alias the 4n interpolation with the host-computed low coefficients (see quotient_low)
-    HIP_TRY(hipEventSynchronize(p->ev_pi));   // wire / z lows were complete at the round-1/2 synchronisations
+    HIP_TRY(hipEventSynchronize(p->ev_pi));   // wire lows were complete at the round-1 synchronisation
+    HIP_TRY(hipEventSynchronize(p->ev_zlow)); // z's come from the side stream when z is committed from its evaluations
     QuotientLowIn qi;
     qi.low = p->low_host;
     qi.alpha = alpha; qi.beta = beta; qi.gamma = gamma;

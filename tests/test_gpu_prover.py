@@ -286,6 +286,11 @@ def test_host_time_slots_count_the_five_synchronisations_of_a_proof(ctx, kat_set
     for k in range(4):
         wbuf.upload(case["wires"][k], 32 * n * k)
     first = gp.prove_dev(wbuf.ptr, case["pi"], bl)
+    # round 6: the Lagrange-basis table carries a third blinding point and z is committed from its evaluations, unless
+    # PLONK_Z_COMMIT=coeff (a variant child) keeps the coefficient form — the library reports which
+    import os
+    if os.environ.get("PLONK_WIRE_COMMIT") != "coeff":
+        assert gp.describe()["lagrange_points"] == n + (2 if os.environ.get("PLONK_Z_COMMIT") == "coeff" else 3)
     ctx.profile(True)
     ctx.profile_reset()
     t0 = time.perf_counter()
