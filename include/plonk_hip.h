@@ -488,9 +488,10 @@ int plonk_srs_load_public_parameters(plonk_ctx* ctx, const uint8_t* bytes, uint6
  *   polynomials: what stays replicated on every rank of a multi-GPU run).
  *   With PLONK_PROF_FINE=1 in the environment also, per phase of a commitment group (groups of >= 3 commitments: 16 + phase,
  *   smaller groups: 24 + phase): 0 bucket sort, 1 accumulation, 2 bucket sums, 3 heavy buckets, 4 row / column sums, 5 bit sums.
- *   HOST time of plonk_prover_prove* on a single device (wall clock, no events; `launches` = occurrences): 8 the arithmetic
+ *   HOST time of plonk_prover_prove* (wall clock, no events; `launches` = occurrences): 8 the arithmetic
  *   that turns the bit sums of a commitment group into compressed commitments, 9 from the return of each of the five
- *   synchronisations of a proof to the next launch (slot 8 included: the device's main stream is idle for that long),
+ *   synchronisations of a proof (six or seven for a rank of a sharded proof: the grand product's and the opening
+ *   quotients' range totals are exchanged too) to the next launch (slot 8 included: the device's main stream is idle for that long),
  *   10 the time blocked in those synchronisations; 11 (a count, not a time) the helper threads each commitment group had.
  *   Slots 0 .. 31 are valid.
  *

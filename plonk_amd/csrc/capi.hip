@@ -187,6 +187,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   if (env_chr("PLONK_QUOTIENT_DOMAIN") == '4') g.quotient_domain = 4;
   if (env_chr("PLONK_WIRE_COMMIT") == 'c') g.wire_commit_coeff = 1;
   if (env_chr("PLONK_Z_COMMIT") == 'c') g.z_commit_coeff = 1;
+  if (env_chr("PLONK_Z_COMMIT") == 'e') g.z_commit_coeff = -1;
   if (const char v = env_chr("PLONK_SHARD_QUOTIENT")) g.shard_quotient = v == '0' ? -1 : 1;
   if (const char v = env_chr("PLONK_SHARD_Z")) g.shard_z = v == '1' ? 1 : -1;
   if (const char v = env_chr("PLONK_SHARD_SIDE")) g.shard_side = v == '0' ? -1 : 1;
@@ -208,6 +209,7 @@ void config_resolve(const plonk_gpu_config* user, int device, Config* out) {
   g.bi_cfg = env_int("PLONK_BI_CFG", -1);
   if (const char v = env_chr("PLONK_SIDE_DEFER")) g.side_defer = v == '1' ? 1 : (v == '2' ? 2 : 0);
   if (const char v = env_chr("PLONK_SIDE_AFTER_ELOG"); v == '2' || v == '3') g.side_after_elog = v - '0';
+  if (const char v = env_chr("PLONK_WIRE_POLYS_SIDE")) g.wire_polys_side = v == '1' ? 1 : 0;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '0') g.wire_by_column = -1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '1') g.wire_by_column = 1;
   if (env_chr("PLONK_WIRE_BY_COLUMN") == '2') g.wire_by_column = 2;

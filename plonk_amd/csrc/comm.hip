@@ -103,11 +103,16 @@ static long comm_timeout_ms(const Ctx* c) { return c->cfg.comm_timeout_ms > 0 ? 
 int comm_sync(Ctx* c, hipStream_t st) {
   if (!c->nccl_comm) { HIP_TRY(hipStreamSynchronize(st)); return PLONK_OK; }
   const auto t0 = std::chrono::steady_clock::now();
+  bool slow = false;
   for (uint32_t spin = 0;; ++spin) {
     const hipError_t e = hipStreamQuery(st);
     if (e == hipSuccess) return PLONK_OK;
     if (e != hipErrorNotReady) { set_last_error("hipStreamQuery", hipGetErrorString(e), __FILE__, __LINE__); return PLONK_ERR_HIP; }
-    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));   // first ~ms: busy poll (collectives take tens of us)
+    // busy poll for the first 40 ms — a rank's longest device phase at 2^20 gates is under 10 ms, and a sleep's wake-up
+    // latency (50-100 us) would be paid at each of the five synchronisations of a proof; after that (2^22 gates and two
+    // ranks, or a peer that is late or dead) sleep between polls
+    if ((spin & 255) == 255) slow = std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(40);
+    if (slow) std::this_thread::sleep_for(std::chrono::microseconds(50));
     if ((spin & 1023) == 1023 &&
         std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_ms(c)) {
       RcclApi* api = rccl_api();

@@ -156,7 +156,7 @@ struct Config {
   int bucket_bits = 0;              // 0 by the number of terms, 15, 17 (A/B build), 19
   int quotient_domain = 4;          // 4 or 8
   int wire_commit_coeff = 0;        // 1: coefficient-form wire commitments
-  int z_commit_coeff = 0;           // PLONK_Z_COMMIT=coeff (A/B): commit to z in coefficient form although the Lagrange table could take its evaluations
+  int z_commit_coeff = 0;           // PLONK_Z_COMMIT=coeff (A/B): commit to z in coefficient form although the Lagrange table could take its evaluations (1); =evals: from its evaluations at every size (-1)
   int shard_quotient = 0;           // 0 default, 1 on, -1 off
   int shard_z = 0;
   int shard_side = 0;
@@ -179,6 +179,7 @@ struct Config {
   int bi_cfg = -1;                  // PLONK_BI_CFG=0..3: batch-inversion geometry
   int side_defer = -1;              // PLONK_SIDE_DEFER=0/1/2
   int wire_by_column = 0;           // PLONK_WIRE_BY_COLUMN: 0 -> -1 (host wire columns commit as ONE grouped launch after the last copy, round 5), 1 / 2 -> by column at every size (a, b, c + d / one launch each); unset: by column from 2^19 gates on
+  int wire_polys_side = -1;         // PLONK_WIRE_POLYS_SIDE=0/1 (A/B): the wire inverse transforms on the side stream under their commitments; unset: up to 2^18 gates
   int side_after_elog = 0;          // PLONK_SIDE_AFTER_ELOG=2/3: pass geometry of side transforms issued after a group's accumulation
   int host_threads = -1;            // PLONK_HOST_THREADS=k: helper threads for the host arithmetic between device phases (finish_pool.hpp); -1: 3 when the process may run on >= 8 CPUs, else 0
 };

@@ -211,6 +211,11 @@ struct HostGap {
   }
 };
 static thread_local HostGap* tl_gap = nullptr;   // the proof in flight on this thread (fetch_commitments reports through it)
+struct GapScope {   // (the last gap of a proof — after the opening commitments — closes at return)
+  HostGap* g;
+  explicit GapScope(HostGap* x) : g(x) { tl_gap = g; }
+  ~GapScope() { g->launching(); tl_gap = nullptr; }
+};
 
 static constexpr int RES_STRIDE = MSM_BIT_SUMS * (int)sizeof(G1);   // 17 bit sums per commitment (msm_bits_kernel)
 
@@ -687,7 +692,7 @@ static int prover_build(Ctx* c, const plonk_prover_desc* d, const CircuitSrc* ci
       // is blinded with b0 + b1 X + b2 X^2, so with it the commitment of z is an MSM of its EVALUATIONS as well (round 2 of
       // prove()), and z's inverse transform leaves the critical path.  The point comes from the context's commit key either
       // way (plonk_lagrange_key and lagrange_xy96 stay at n + 2 points); a key too short for it keeps the coefficient form.
-      const bool third = c->srs_n >= n + 3 && !c->cfg.z_commit_coeff;
+      const bool third = c->srs_n >= n + 3 && c->cfg.z_commit_coeff <= 0;
       const uint64_t lag_cnt = n + 2 + (third ? 1 : 0);
       G1Affine* lag_pts = nullptr;
       HIP_TRY(hipMalloc((void**)&lag_pts, sizeof(G1Affine) * lag_cnt));
@@ -876,7 +881,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
 
   uint8_t comm[11][48];
   HostGap gap{c};
-  struct GapScope { HostGap* g; GapScope(HostGap* x) : g(x) { tl_gap = g; } ~GapScope() { g->launching(); tl_gap = nullptr; } } gap_scope(&gap);   // (the last gap — after the opening commitments — closes at return)
+  GapScope gap_scope(&gap);
   // ---- round 1 (prover.rs:444-479)
   const bool lag = p->lag_on;
   // iNTT + blinding of the four columns and their lowest coefficients (quotient_low), on the CURRENT stream
@@ -898,14 +903,17 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
       HIP_TRY(hipMemcpyAsync(p->low_host + 7 * k, p->wpoly + k * np, 7 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
     return PLONK_OK;
   };
-  // Up to 2^18 gates the GPU is not saturated by the commitment pipeline and the wire polynomials (needed from round 3
-  // on) ride on the side stream under it; above, the accumulation owns the VALU and the side stream would only fall
-  // behind (A/B at 2^20, r02: +0.7 ms), so they keep their place in front of the commitment.
+  // Up to 2^19 gates the wire polynomials (needed from round 3 on) ride on the side stream under the commitment pipeline,
+  // started after the group's accumulation (side_defer below): they fill its latency-bound reduction tail.  At 2^20 the
+  // accumulation owns the VALU and its register file (two waves of 256 VGPRs per SIMD: no transform wave fits beside
+  // them), the tails of the four groups are too short for the 6 ms of side transforms, and the inverse transforms keep
+  // their place in front of the commitment (same-box A/B, profiles/r06b/polys_side_*.jsonl: 2^19 18.1-18.3 -> 17.4-17.7 ms
+  // with both moved, 2^20 32.17 -> 32.07-32.44).  PLONK_WIRE_POLYS_SIDE=0/1 forces it.
   // plonk_gpu_config has no field for it; PLONK_WIRE_BY_COLUMN: 0 = never, 1 / 2 = at EVERY size (a, b, c + d / one launch per
   // column: what the variant tests use to run the phased launches on small circuits), unset = from 2^19 gates on
   const int bc_cfg = c->cfg.wire_by_column;
   const bool by_column = lag && p->wires_pending && p->world == 1 && bc_cfg >= 0 && (L > 18 || bc_cfg > 0);
-  const bool polys_on_side = lag && L <= 18 && !by_column;
+  const bool polys_on_side = lag && !by_column && (c->cfg.wire_polys_side >= 0 ? c->cfg.wire_polys_side == 1 : L <= 19);
   // Host wire columns (plonk_prover_prove, round 6): column k lands over PCIe 32 n bytes after column k - 1 (0.65 ms apart at
   // 2^20 gates), and until round 5 the commitment group waited for all four before its grouped bucket sort — 2.1 ms of every
   // such proof with nothing but the four inverse transforms to hide in.  Now each column's transform is followed at once by
@@ -929,11 +937,13 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   // Side transforms either start with the group (they then compete with its bandwidth-bound sort) or wait for the end of
   // its accumulation and fill the latency-bound tail.  Same-box A/B (r02e): waiting wins up to 2^18 gates (2^16: 5.19 vs
   // 5.33 ms) and on the widget workload (38.1 vs 38.5 ms) but loses on the dense 2^20 headline (37.2-37.4 vs 36.6-36.8 ms:
-  // z's transform no longer fits between its commitment and the quotient), so it follows the size.  PLONK_SIDE_DEFER=0/1 forces it.
+  // z's transform no longer fits between its commitment and the quotient), so it follows the size; round 6: 2^19 gates
+  // wait too, together with the wire inverse transforms (above).  PLONK_SIDE_DEFER=0/1 forces it.
   const int side_defer_env = c->cfg.side_defer;
-  const bool side_defer = side_defer_env >= 0 ? side_defer_env >= 1 : L <= 18;          // round 1: a, b, c, d (+ PI)
-  const bool side_defer_z = side_defer_env >= 0 ? side_defer_env == 1 : L <= 18;         // round 2: z ("2" = round 1 only)
-  const bool z_from_evals = lag && p->lag_z && L <= 18;                                   // z committed from its evaluations (round 2)
+  const bool defer_size = L <= 18 || (L == 19 && !by_column);   // (host wire columns at 2^19 gates keep the phased launches' order)
+  const bool side_defer = side_defer_env >= 0 ? side_defer_env >= 1 : defer_size;       // round 1: a, b, c, d (+ PI)
+  const bool side_defer_z = side_defer_env >= 0 ? side_defer_env == 1 : defer_size;      // round 2: z ("2" = round 1 only)
+  const bool z_from_evals = lag && p->lag_z && (L <= 18 || c->cfg.z_commit_coeff < 0);                                   // z committed from its evaluations (round 2)
   auto side_round1 = [&]() -> int {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
     // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments; with the
@@ -1355,6 +1365,8 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
 
   Transcript tr((const uint8_t*)p->label.data(), p->label.size());
   seed_transcript(tr, p, pi_val, pi_count);
+  HostGap gap{c};   // host time between the device phases of this rank (slots 8-10 of plonk_profile_read; the sharded proof has up to seven synchronisations)
+  GapScope gap_scope(&gap);
 
   uint8_t comm[11][48];
   // ---- round 1 (replicated polynomials, sharded commitments)
@@ -1485,6 +1497,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     pa.ks[0] = Fr::one(); pa.ks[1] = fr_small(7); pa.ks[2] = fr_small(13); pa.ks[3] = fr_small(17);
     pa.tw_lo29 = tbn->tw_lo29; pa.tw_hi29 = tbn->tw_hi29; pa.lobits = L < 13 ? L : 13; pa.use_hi = L > 13;
     pa.num = p->scratch; pa.den = p->scratch + np;
+    gap.launching();
     HIP_TRY(hipMemsetAsync(p->flag_dev, 0, sizeof(int), c->stream));
     // Round 4: the grand product (permutation.rs:213-294) split over the ranks from 2^19 gates and four ranks on.  Rank r forms the n / W
     // numerator / denominator terms of ITS evaluation indices, inverts, multiplies and scans them locally; the ranks exchange
@@ -1513,7 +1526,9 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
       memset(&mine, 0, sizeof mine);
       HIP_TRY(hipMemcpyAsync(p->ev_host, p->totals + (scan_prefix_blocks(cnt) - 1), sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipMemcpyAsync(p->flag_host, p->flag_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      const auto t_before = HostGap::clock::now();
       PTRY(comm_sync(c, c->stream));
+      gap.synced(t_before);
       mine.total = p->ev_host[0];
       mine.flag = *p->flag_host;
       std::vector<uint8_t> gathered(sizeof(mine) * (size_t)W);
@@ -1527,6 +1542,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
         if (r < (uint32_t)p->rank) carry = carry * all[r].total * p->inv32;
       }
       if (any_zero) return (plonk::set_last_error("invalid argument", "zero denominator in the permutation grand product", __FILE__, __LINE__), PLONK_ERR_ARG);
+      gap.launching();
       PTRY(scan_prefix_product_apply(c, pa.num + first, cnt, p->totals, carry));
       PTRY(comm_allgather_dev(c, p->link, pa.num, sizeof(Fr) * cnt));
     }
@@ -1569,6 +1585,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   const Fr fixed_ch = tr.challenge_scalar("fixed base separation challenge");
   const Fr var_ch = tr.challenge_scalar("variable base separation challenge");
   const Fr edwards_d = p->edwards_d;
+  gap.launching();
   HIP_TRY(hipStreamWaitEvent(c->main_stream, p->ev_side, 0));
   for (uint32_t k = 0; k < cpr; ++k) {
     QuotientArgs q;
@@ -1666,9 +1683,12 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
       ea.items[k].x = (k >= 4 && k <= 6) || k == 14 ? zw : z_ch;
       if (ea.items[k].len > max_len) max_len = ea.items[k].len;
     }
+    gap.launching();
     PTRY(poly_eval(c, ea, 15, max_len, p->evout));
     HIP_TRY(hipMemcpyAsync(p->ev_host, p->evout, 15 * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
-    PTRY(comm_sync(c, c->stream));   // the all-to-all of the quotient precedes this on the stream: never hang on a dead peer
+    const auto t_before = HostGap::clock::now();
+    PTRY(comm_sync(c, c->stream));
+    gap.synced(t_before);   // the all-to-all of the quotient precedes this on the stream: never hang on a dead peer
     std::vector<Fr> all(15 * (size_t)W);
     PTRY(comm_allgather_host(c, p->link, p->ev_host, all.data(), 15 * sizeof(Fr)));
     Fr h[15];
@@ -1718,6 +1738,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   vp[0] = one;
   for (int k = 1; k < 12; ++k) vp[k] = vp[k - 1] * v;
   const uint64_t rlen = hi - lo;                               // owned part of the n + 7 numerator coefficients
+  gap.launching();
   {
     LinCombArgs la;
     int k = 0;
@@ -1770,7 +1791,9 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
   // the suffix sums of the ranges above this one: all-gather of (total_z, total_zw) per rank
   HIP_TRY(hipMemcpyAsync(p->ev_host, p->scratch, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(p->ev_host + 1, p->scratch2, sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+  const auto t_before_tot = HostGap::clock::now();
   PTRY(comm_sync(c, c->stream));
+  gap.synced(t_before_tot);
   std::vector<Fr> tot(2 * (size_t)W);
   PTRY(comm_allgather_host(c, p->link, p->ev_host, tot.data(), 2 * sizeof(Fr)));
   Fr carry_z = Fr::zero(), carry_zw = Fr::zero(), num_at_z = Fr::zero();
@@ -1778,6 +1801,7 @@ static int prover_prove_sharded(Prover* p, const Fr* wires_dev, const uint64_t* 
     num_at_z = num_at_z + tot[2 * r];
     if (r > (uint32_t)p->rank) { carry_z = carry_z + tot[2 * r]; carry_zw = carry_zw + tot[2 * r + 1]; }
   }
+  gap.launching();
   PTRY(poly_ruffini_finish(c, p->scratch, p->wit, lo, rlen, inv_z, carry_z, n + 6));
   PTRY(poly_ruffini_finish(c, p->scratch2, p->wit2, lo, rlen, inv_z * p->omega_inv, carry_zw, n + 6));
   {

@@ -44,6 +44,7 @@ VARIANTS = [
 # (round 6: + the host helper threads of fetch_commitments off and at their maximum — the same proofs either way)
 PROVER_VARIANTS = [{"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19"}, {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "15"},
                    {"PLONK_HOST_THREADS": "0"}, {"PLONK_HOST_THREADS": "7"}, {"PLONK_Z_COMMIT": "coeff"},
+                   {"PLONK_WIRE_POLYS_SIDE": "0", "PLONK_SIDE_DEFER": "0"},   # the schedule of circuits above 2^19 gates: wire transforms in front of their commitments, side transforms with them
                    {"PLONK_MSM_TABLE": "halfpos", "PLONK_MSM_BUCKETS": "19"},
                    {"PLONK_MSM_TABLE": "bitpos", "PLONK_MSM_BUCKETS": "19", "PLONK_MSM_SORT13": "1"}]
 PROVER_SELECT = "deterministic_v3 or random_arithmetic or host_time_slots or (proof_bytes_equal_c_oracle and not 16 and not 2p20)"

@@ -47,4 +47,4 @@ def run(log_n, steps):
 if __name__ == "__main__":
     sizes = [int(x) for x in sys.argv[1:]] or [12, 16, 20]
     for lg in sizes:
-        print(json.dumps(run(lg, 20 if lg <= 18 else 5)), flush=True)
+        print(json.dumps(run(lg, int(os.environ.get("HG_STEPS", 20 if lg <= 18 else 5)))), flush=True)

@@ -50,8 +50,13 @@ def run(log_n, world, rank, steps):
     for name, slot in (("ntt", 0), ("msm_accumulate", 1), ("msm_other", 2), ("quotient_pointwise", 3), ("rounds_1_2_polynomials", 4)):
         total, _ = ctx.profile_read(slot)
         slots[name] = round(total / steps, 3)
+    host = {}   # host time on the rank's critical path (slots 8-10, prover.hip HostGap): ms per proof, synchronisations per proof
+    for name, slot in (("finish_commitments", 8), ("sync_to_next_launch", 9), ("blocked_in_sync", 10)):
+        total, cnt = ctx.profile_read(slot)
+        host[name + "_ms"] = round(total / steps, 4)
+        host[name + "_n"] = cnt / steps
     lo, hi = plonk_amd.shard_range(srs_total, rank, world)
-    out = {"log_gates": log_n, "world": world, "rank": rank, "points": hi - lo, "prove_ms_rank_alone": round(ms, 3), "kernel_ms": slots,
+    out = {"log_gates": log_n, "world": world, "rank": rank, "points": hi - lo, "prove_ms_rank_alone": round(ms, 3), "kernel_ms": slots, "host_ms": host,
            "table_rows": ctx.table_rows() if hasattr(ctx, "table_rows") else None, "callback_calls": calls[0],
            "wire_split": getattr(bench.build_prover, "wire_split", "range") if world > 1 else None,   # PLONK_BENCH_WIRE_SPLIT=commitment
            "lagrange_points": prover.describe()["lagrange_points"],
