@@ -197,6 +197,56 @@ HD Fp28 fp28_inv(const Fp28& a) {
 #include "fp_safegcd.cuh"
 namespace plonk {
 
+// ---- [k] P for a full-width scalar through the curve's endomorphism (setup only: the group FFT of the Lagrange-basis key) ----
+// phi(x, y) = (BETA x, y) = [LAMBDA] (x, y) on G1, LAMBDA = z^2 - 1 for the curve parameter z = -0xd201000000010000, and the
+// group order is r = LAMBDA^2 + LAMBDA + 1 EXACTLY, so k = k1 + k2 LAMBDA with k2 = floor(k / LAMBDA) <= LAMBDA + 1 < 2^128 and
+// k1 = k mod LAMBDA < 2^128: [k] P = [k1] P + [k2] phi(P) is one interleaved double-and-add of 128 steps over {P, phi(P),
+// P + phi(P)} — 128 doublings + ~96 additions instead of 255 + ~127.
+struct GlvScalar { uint64_t k1[2], k2[2]; };
+// k (8 x 32-bit limbs, canonical, < r) -> (k mod LAMBDA, k div LAMBDA): restoring division, 255 steps on a 129-bit remainder
+HD GlvScalar glv_split(const uint32_t* k /*8*/) {
+  constexpr uint64_t LH = 0xac45a4010001a402ull, LL = 0x00000000ffffffffull;   // LAMBDA
+  uint64_t rh = 0, rl = 0, qh = 0, ql = 0;
+  for (int i = 254; i >= 0; --i) {
+    const uint64_t top = rh >> 63;                            // the remainder is < LAMBDA < 2^128 before the shift, < 2^129 after
+    rh = (rh << 1) | (rl >> 63);
+    rl = (rl << 1) | ((k[i >> 5] >> (i & 31)) & 1u);
+    const bool ge = top || rh > LH || (rh == LH && rl >= LL);
+    if (ge) {                                                 // < 2 LAMBDA - LAMBDA: fits 128 bits again
+      const uint64_t borrow = rl < LL ? 1u : 0u;
+      rl -= LL;
+      rh -= LH + borrow;
+    }
+    qh = (qh << 1) | (ql >> 63);                              // (the quotient's bits above 127 are zero: k < r)
+    ql = (ql << 1) | (ge ? 1u : 0u);
+  }
+  GlvScalar g;
+  g.k1[0] = rl; g.k1[1] = rh; g.k2[0] = ql; g.k2[1] = qh;
+  return g;
+}
+HD Fp28 glv_beta() {   // BETA * R' mod p, BETA = 0x1a0111ea...aaac (the cube root of unity that goes with LAMBDA: oracle check in tests/test_field_host.py)
+  constexpr uint32_t V[Fp28::N] = {0x2421b59u, 0xbee4867u, 0x1d31002u, 0x4760184u, 0x4cc5086u, 0xc76dc00u, 0xaae891bu,
+                                   0xac70ad2u, 0xfe377c4u, 0xe4686b8u, 0x5ed1568u, 0x8f5a180u, 0x02b5c1fu, 0x000d1a4u};
+  Fp28 r;
+#pragma unroll
+  for (int i = 0; i < Fp28::N; ++i) r.l[i] = V[i];
+  return r;
+}
+// [k] p, k canonical (8 x 32-bit limbs, < r); p with the bounds of G1R::add's operands
+HD G1R g1r_mul_glv(const G1R& p, const uint32_t* k /*8*/) {
+  const GlvScalar g = glv_split(k);
+  G1R p2 = p;
+  p2.X = Fp28::mul(p.X, glv_beta());                          // 16 * 1 -> < 2p
+  const G1R p3 = p.add(p2);
+  G1R acc = G1R::identity();
+  for (int b = 127; b >= 0; --b) {
+    acc = acc.dbl();
+    const uint32_t s = (uint32_t)((g.k1[b >> 6] >> (b & 63)) & 1u) | ((uint32_t)((g.k2[b >> 6] >> (b & 63)) & 1u) << 1);
+    if (s) acc = acc.add(s == 1 ? p : (s == 2 ? p2 : p3));
+  }
+  return acc;
+}
+
 // affine coordinates (x, y) < 2p of a finite point (safegcd inverse: ~23 k instructions instead of ~300 k)
 HD void g1r_to_affine(const G1R& p, Fp28* x, Fp28* y) {
   const Fp28 inv = fp28_inv_gcd(Fp28::mul(p.ZZ, p.ZZZ));

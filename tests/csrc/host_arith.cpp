@@ -116,6 +116,18 @@ int h_g1r_accumulate_pair_first(const uint8_t* pts, const uint8_t* neg, int n, u
   }
   return out_aff_r(acc, o);
 }
+// [k] P through the endomorphism (curve28.cuh g1r_mul_glv: the group FFT's scalar multiplication); k: 8 x 32-bit limbs, canonical.
+// pre = doublings applied to P first (an operand with the bounds the FFT's butterflies hand over, not a fresh affine point)
+int h_g1r_mul_glv(const uint8_t* pt, const uint32_t* k, int pre, uint8_t* o) {
+  G1Affine p; memcpy(&p, pt, 96);
+  G1R q = G1R::from_affine(Fp28::from_fp(p.x), Fp28::from_fp(p.y));
+  for (int i = 0; i < pre; ++i) q = q.add(q);
+  return out_aff_r(g1r_mul_glv(q, k), o);
+}
+void h_glv_split(const uint32_t* k, uint64_t* out4) {
+  const GlvScalar g = glv_split(k);
+  out4[0] = g.k1[0]; out4[1] = g.k1[1]; out4[2] = g.k2[0]; out4[3] = g.k2[1];
+}
 int h_g1r_affine_roundtrip(const uint8_t* pt, uint8_t* o) {
   G1Affine p; memcpy(&p, pt, 96);
   G1R q = G1R::from_affine(Fp28::from_fp(p.x), Fp28::from_fp(p.y)).dbl().dbl();

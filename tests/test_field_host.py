@@ -596,3 +596,32 @@ def test_first_two_entries_of_a_lane_through_the_affine_pair_formula(lib):
     assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[0], 5)
     assert lib.h_g1r_accumulate_pair_first(rep, bytes([0, 1, 0, 0, 0]), 5, out, ctypes.byref(used)) == 1 and used.value == 0
     assert E.g1_from_raw96(bytes(out)) == E.g1_mul(pts[0], 3)
+
+
+def test_scalar_multiplication_through_the_endomorphism(lib):
+    """curve28.cuh glv_split / g1r_mul_glv (the scalar multiplication of the Lagrange-basis key's group FFT, msm.hip):
+    k = k1 + k2 LAMBDA with both halves below 2^128 and r = LAMBDA^2 + LAMBDA + 1; phi(x, y) = (BETA x, y) = [LAMBDA](x, y);
+    [k] P equals the oracle's double-and-add for random, small, extreme and half-empty scalars, also for an operand that
+    comes out of additions (the butterflies' bounds) and for the identity's neighbours (k = 0, 1, r - 1)."""
+    lam = 0xac45a4010001a40200000000ffffffff
+    assert lam * lam + lam + 1 == Q
+    beta = 0x1a0111ea397fe699ec02408663d4de85aa0d857d89759ad4897d29650fb85f9b409427eb4f49fffd8bfd00000000aaac
+    G = E.G1_GEN
+    assert pow(beta, 3, E.P) == 1 and (beta * G[0] % E.P, G[1]) == E.g1_mul(G, lam)
+    rnd = random.Random(6202)
+    ks = [0, 1, 2, lam - 1, lam, lam + 1, 2 * lam, lam * lam, Q - 1, Q - lam, (1 << 128) - 1, 1 << 128, (1 << 254) + 1]
+    ks += [rnd.randrange(Q) for _ in range(40)] + [rnd.randrange(1 << 64) for _ in range(4)] + [rnd.randrange(1 << 64) * lam % Q for _ in range(4)]
+    out4 = (ctypes.c_uint64 * 4)()
+    out = (ctypes.c_uint8 * 96)()
+    for i, k in enumerate(ks):
+        limbs = (ctypes.c_uint32 * 8)(*[(k >> (32 * j)) & 0xffffffff for j in range(8)])
+        lib.h_glv_split(limbs, out4)
+        k1, k2 = out4[0] | out4[1] << 64, out4[2] | out4[3] << 64
+        assert (k1, k2) == (k % lam, k // lam), hex(k)
+        base = E.g1_mul(G, rnd.randrange(1, Q))
+        pre = i % 3
+        ok = lib.h_g1r_mul_glv(E.g1_to_raw96(base), limbs, pre, out)
+        exp = E.g1_mul(base, k * (1 << pre) % Q) if k else None
+        assert (ok == 1) == (exp is not None), hex(k)
+        if exp is not None:
+            assert E.g1_from_raw96(bytes(out)) == exp, hex(k)
