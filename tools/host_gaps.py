@@ -16,7 +16,7 @@ from oracle.bls12_381 import Q  # noqa: E402
 def run(log_n, steps):
     ctx = plonk_amd.Context(0)
     blinders = plonk_amd.fr_to_bytes_mont([(0xB11D0000 + i) * 0x9E3779B97F4A7C15 % Q for i in range(14)])
-    prover, wbuf, _ = bench.build_prover(ctx, log_n, 0, 1, None)
+    prover, wbuf, _ = bench.build_prover(ctx, log_n, 0, 1, None, os.environ.get("HG_PROFILE", "dense"))
     for _ in range(3):
         prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
     ctx.sync()
@@ -32,7 +32,7 @@ def run(log_n, steps):
         prover.prove_dev(wbuf.ptr, prover.public_inputs, blinders)
     ctx.sync()
     prof = (time.perf_counter() - t0) * 1e3 / steps
-    out = {"log_gates": log_n, "lib": os.path.basename(os.environ.get("PLONK_HIP_LIB", "default")), "prove_ms": round(plain, 3), "prove_ms_profiled": round(prof, 3)}
+    out = {"log_gates": log_n, "profile": os.environ.get("HG_PROFILE", "dense"), "lib": os.path.basename(os.environ.get("PLONK_HIP_LIB", "default")), "prove_ms": round(plain, 3), "prove_ms_profiled": round(prof, 3)}
     for name, slot in (("host_finish_commitments", 8), ("host_gap_sync_to_next_launch", 9), ("host_blocked_in_sync", 10)):
         total, cnt = ctx.profile_read(slot)
         out[name + "_ms"] = round(total / steps, 4)
