@@ -18,5 +18,5 @@ cd $R
 export PLONK_CIRCUIT_CACHE=/tmp/plonk_circuits_r6b
 for w in 1 2 4 8; do python tools/rank_alone.py 20 10 $w 2>/dev/null; done > gpurun_out/r6b/final/rank_alone_final_2p20.jsonl
 cut -c1-200 gpurun_out/r6b/final/rank_alone_final_2p20.jsonl
-python tools/host_gaps.py 12 16 17 18 20 2>/dev/null > gpurun_out/r6b/final/host_gaps_final.jsonl
+python tools/host_gaps.py 12 16 17 18 19 20 2>/dev/null > gpurun_out/r6b/final/host_gaps_final.jsonl
 cut -c1-260 gpurun_out/r6b/final/host_gaps_final.jsonl
