@@ -943,7 +943,7 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
   const bool defer_size = L <= 18 || (L == 19 && !by_column);   // (host wire columns at 2^19 gates keep the phased launches' order)
   const bool side_defer = side_defer_env >= 0 ? side_defer_env >= 1 : defer_size;       // round 1: a, b, c, d (+ PI)
   const bool side_defer_z = side_defer_env >= 0 ? side_defer_env == 1 : defer_size;      // round 2: z ("2" = round 1 only)
-  const bool z_from_evals = lag && p->lag_z && (L <= 18 || c->cfg.z_commit_coeff < 0);                                   // z committed from its evaluations (round 2)
+  const bool z_from_evals = lag && p->lag_z && (L <= 17 || c->cfg.z_commit_coeff < 0);                                   // z committed from its evaluations (round 2)
   auto side_round1 = [&]() -> int {
     // quotient_poly.rs:139-157,177: coset FFTs of a, b, c, d and of the public-input polynomial
     // (prover.rs:520-521) need no challenge -> side stream, overlapped with the commitments; with the
@@ -1058,10 +1058,11 @@ static int prover_prove(Prover* p, const Fr* wires_dev, const uint64_t* pi_idx, 
     // Round 6, second session: z(X) = sum_i z_i L_i(X) + (b0 + b1 X + b2 X^2)(X^n - 1), so — like the wires — its commitment is
     // an MSM of the n EVALUATIONS the scan just wrote and the three blinders over the Lagrange-basis key and its blinding
     // points: the inverse transform, the blinding and the copy of the low coefficients leave the critical path (the side
-    // stream runs them before z's coset transform; `scratch` keeps the evaluations until round 5 reuses it).  Up to 2^18 gates
-    // only: same-box A/B 2^12 2.04 -> 2.01 ms, 2^16 4.09 -> 4.03, 2^17 5.88 -> 5.86; at 2^20 the transform that left the main
-    // stream competes with the commitment's sort on the side stream instead and nothing is gained (32.2 against 32.3), so
-    // large circuits keep the coefficient form (profiles/r06b/zcommit_ab.jsonl).
+    // stream runs them before z's coset transform; `scratch` keeps the evaluations until round 5 reuses it).  Up to 2^17 gates
+    // only: same-box A/B 2^12 2.04 -> 2.01 ms, 2^16 4.09 -> 4.03, 2^17 5.88 -> 5.86 (even in a later
+    // five-repetition pair); at 2^18 the coefficient form is 1 % ahead (9.88 against 10.00 ms, mid_sizes_ab.jsonl), at 2^19 too, and
+    // at 2^20 the transform that left the main stream competes with the commitment's sort on the side stream instead (32.2 against
+    // 32.3), so larger circuits keep the coefficient form (profiles/r06b/zcommit_ab.jsonl).
     HIP_TRY(hipMemcpyAsync(p->wscal + 8, bl + 8, 3 * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
     if (!side_defer_z) {
       SideScope side(c, p->ev_ready);
