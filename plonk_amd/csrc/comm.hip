@@ -187,9 +187,16 @@ int comm_allgather_dev(Ctx* c, const CommLink& l, void* buf_dev, size_t bytes_pe
   if (l.world <= 1 || bytes_per_rank == 0) return PLONK_OK;
   uint8_t* buf = (uint8_t*)buf_dev;
   if (comm_loopback(c)) {
-    for (int r = 0; r < l.world; ++r)
-      if (r != l.rank)
-        HIP_TRY(hipMemcpyAsync(buf + bytes_per_rank * (size_t)r, buf + bytes_per_rank * (size_t)l.rank, bytes_per_rank, hipMemcpyDeviceToDevice, c->main_stream));
+    // Peer r's place gets this rank's slice ROTATED by 32 r bytes (round 6, second session).  Until then it got the slice
+    // itself, so the gathered array was periodic: its inverse transform — the z polynomial of a sharded grand product — had
+    // W - 1 of every W coefficients ZERO, and the rank's z commitment measured an eighth of its real accumulation.
+    const uint8_t* mine = buf + bytes_per_rank * (size_t)l.rank;
+    for (int r = 0; r < l.world; ++r) {
+      if (r == l.rank) continue;
+      const size_t rot = (32 * (size_t)(r + 1)) % bytes_per_rank;
+      HIP_TRY(hipMemcpyAsync(buf + bytes_per_rank * (size_t)r, mine + rot, bytes_per_rank - rot, hipMemcpyDeviceToDevice, c->main_stream));
+      if (rot) HIP_TRY(hipMemcpyAsync(buf + bytes_per_rank * (size_t)r + (bytes_per_rank - rot), mine, rot, hipMemcpyDeviceToDevice, c->main_stream));
+    }
     return PLONK_OK;
   }
   if (c->nccl_comm) {
@@ -217,8 +224,12 @@ int comm_alltoall_dev(Ctx* c, const CommLink& l, const void* send_dev, void* rec
     return PLONK_OK;
   }
   if (comm_loopback(c)) {
+    // Source `src`'s place gets the block this rank addressed TO src — W different blocks (round 6, second session).  Until
+    // then every source's place got the block the rank keeps for itself: W identical class residues, whose recombination
+    // leaves ONE non-zero part of the quotient and three ZERO ones, so three of the four t commitments of a rank measured
+    // empty (tools/rank_alone.py read 0.8 ms too little for a rank of 8 at 2^20 gates).
     for (int src = 0; src < l.world; ++src)
-      HIP_TRY(hipMemcpyAsync((uint8_t*)recv_dev + bytes_per_peer * (size_t)src, (const uint8_t*)send_dev + bytes_per_peer * (size_t)l.rank,
+      HIP_TRY(hipMemcpyAsync((uint8_t*)recv_dev + bytes_per_peer * (size_t)src, (const uint8_t*)send_dev + bytes_per_peer * (size_t)src,
                              bytes_per_peer, hipMemcpyDeviceToDevice, c->main_stream));
     return PLONK_OK;
   }
