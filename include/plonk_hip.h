@@ -367,8 +367,10 @@ int plonk_prover_prove_witnesses(plonk_prover* p, const uint64_t* witnesses, uin
  * reports an error (bench.py does: the launcher kills the remaining ranks).
  *
  * Measurement aid, never for production: after plonk_comm_measure_loopback(ctx, 1) every collective of a sharded prover on
- * THIS context returns the rank's own contribution in its peers' places (local copies, no transport), so that one rank of a
- * W-rank job can be timed alone on one GPU (tools/rank_alone.py).  Proofs made that way are wrong by construction:
+ * THIS context returns data of the rank's own in its peers' places (local copies, no transport: the all-to-all the blocks the
+ * rank addressed to each peer, the device all-gather rotated copies of its slice — W different blocks, so that what follows
+ * them works on scalars as dense as a real run's), so that one rank of a W-rank job can be timed alone on one GPU
+ * (tools/rank_alone.py).  Proofs made that way are wrong by construction:
  * plonk_prover_prove* returns PLONK_ERR_UNSAT from its final identity check.  Nothing in the environment switches it on.
  *
  * Transport library: RCCL is looked up as librccl.so(.1) on the loader path, then under /opt/rocm/lib.
